@@ -1,0 +1,157 @@
+/*
+ * nufhe_hip.h -- C ABI of libnufhe_hip.so, the MI355X (gfx950) implementation of nufhe's
+ * bootstrapped-gate hot path.  Called from Python through ctypes (nufhe_amd/_lib.py); every
+ * entry point replaces one Reikna `Computation.__call__` (or a fused group of them) of the
+ * reference (nucypher/nufhe).  Reference citations are relative to the reference repo root.
+ *
+ * Conventions
+ *  - extern "C", POD arguments only, no exceptions cross the boundary.
+ *  - every function returns 0 on success, a negative NUFHE_E* code on failure; the message is
+ *    available (per thread) from nufhe_last_error().
+ *  - pointers named d_* are DEVICE pointers owned by the caller (e.g. torch tensors' data_ptr);
+ *    pointers named h_* are HOST pointers.  Strides are in ELEMENTS.
+ *  - all work is enqueued on the context's HIP stream; nothing synchronises unless stated.
+ *  - scheme parameters are the reference's defaults (nufhe/api_low_level.py:49-61):
+ *    N = 1024, k = 1 (tlwe_mask_size), l = 2, Bg = 2^10, keyswitch t = 8, base 4; the LWE size n
+ *    (500) is a run-time argument, n <= 1024.
+ */
+#ifndef NUFHE_HIP_H
+#define NUFHE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NUFHE_OK 0
+#define NUFHE_EINVAL (-1)   /* bad argument */
+#define NUFHE_EHIP (-2)     /* HIP runtime error */
+#define NUFHE_ENODEV (-3)   /* no usable GPU */
+#define NUFHE_ENOKEY (-4)   /* key part not uploaded */
+
+#define NUFHE_N 1024        /* TLWE polynomial degree */
+#define NUFHE_KS_T 8        /* keyswitch decomposition length */
+#define NUFHE_KS_BASE 4     /* keyswitch base */
+
+typedef struct nufhe_ctx nufhe_ctx;            /* one GPU + one stream; replaces the Reikna Thread */
+typedef struct nufhe_cloudkey nufhe_cloudkey;  /* device copies of BootstrapKey + LweKeyswitchKey */
+
+const char *nufhe_last_error(void);
+const char *nufhe_version(void);
+
+/* ---- device / context (replaces reikna.cluda Thread creation, api_high_level.py:130-181) ---- */
+int nufhe_device_count(int *count);
+int nufhe_device_name(int device, char *buf, size_t buflen);
+/* stream: an existing hipStream_t (e.g. torch's current stream) or NULL to create a private one */
+int nufhe_ctx_create(int device, void *stream, nufhe_ctx **ctx);
+int nufhe_ctx_destroy(nufhe_ctx *ctx);
+int nufhe_ctx_synchronize(nufhe_ctx *ctx);
+int nufhe_ctx_device(nufhe_ctx *ctx, int *device);
+void *nufhe_ctx_stream(nufhe_ctx *ctx);
+
+/* ---- raw device memory (for callers without an allocator of their own) ---- */
+int nufhe_alloc(nufhe_ctx *ctx, size_t bytes, void **d_ptr);
+int nufhe_free(nufhe_ctx *ctx, void *d_ptr);
+int nufhe_h2d(nufhe_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);   /* synchronous */
+int nufhe_d2h(nufhe_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);   /* synchronous */
+
+/* ---- cloud key (BootstrapKey bootstrap.py:44-92, LweKeyswitchKey lwe.py:254-308) ---- */
+int nufhe_cloudkey_create(nufhe_ctx *ctx, int lwe_size, nufhe_cloudkey **key);
+int nufhe_cloudkey_destroy(nufhe_cloudkey *key);
+/* Bootstrapping key in the REFERENCE's storage format: u64 [n][2][2][2][1024], natural-order NTT,
+ * Montgomery-prepared (x * 2^64), as produced by TLweTransformSamples (tlwe_gpu.py:199-236) and
+ * pickled by BootstrapKey.dump (bootstrap.py:78-80).  Host pointer. */
+int nufhe_bk_upload_reference(nufhe_cloudkey *key, const uint64_t *h_bk);
+/* Inverse of the above (for BootstrapKey.dump): writes u64 [n][2][2][2][1024] to the host. */
+int nufhe_bk_download_reference(nufhe_cloudkey *key, uint64_t *h_bk);
+/* Bootstrapping key from coefficient-domain TGSW samples, int32 [n][2][2][2][1024] on the DEVICE
+ * (replaces tgsw_transform_samples, tgsw.py:135-138). */
+int nufhe_bk_from_coeffs(nufhe_cloudkey *key, const int32_t *d_tgsw);
+/* Keyswitch key, reference layout: a int32 [1024][8][4][n], b int32 [1024][8][4],
+ * cv float [1024][8][4] (lwe_gpu.py:139-141).  Host pointers.  The base-0 slice must be zero
+ * (lwe_cpu.py:30-33); it is checked and NUFHE_EINVAL is returned otherwise. */
+int nufhe_ks_upload(nufhe_cloudkey *key, const int32_t *h_ks_a, const int32_t *h_ks_b,
+                    const float *h_ks_cv);
+
+/* ---- LWE sample descriptor: a[bit * a_stride + i], b[bit * b_stride], cv[bit * cv_stride] ---- */
+typedef struct {
+    int32_t *a;
+    int32_t *b;
+    float *cv;          /* may be NULL where the variance is not needed */
+    long a_stride;      /* elements between consecutive bits of a (>= size, or 0 to broadcast) */
+    long b_stride;      /* elements between consecutive bits of b and cv (1, or 0 to broadcast) */
+} nufhe_lwe;
+
+/* ---- hot path ---- */
+
+/* LweLinear (lwe_gpu.py:287-316, lwe_gpu.mako:123-169): res = [res +] p * src on (a, b),
+ * cv = [cv +] p^2 * cv; size = LWE size of both. */
+int nufhe_lwe_linear(nufhe_ctx *ctx, nufhe_lwe res, nufhe_lwe src, int32_t p, int add_result,
+                     long nbits, int size);
+/* LweNoiselessTrivialConstant (lwe_gpu.py:340-344): res = (0, mu), cv = 0 */
+int nufhe_lwe_trivial_const(nufhe_ctx *ctx, nufhe_lwe res, int32_t mu, long nbits, int size);
+
+/* bootstrap (bootstrap.py:206-229) = mod-switch + blind rotate + extract [+ keyswitch].
+ * x: LWE(n) input.  no_keyswitch != 0: result is LWE(1024) (extracted); else LWE(n). */
+int nufhe_bootstrap(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe_lwe x,
+                    int32_t mu, long nbits, int no_keyswitch);
+/* lwe_keyswitch (lwe.py:311-322, lwe_gpu.mako:59-120): LWE(1024) -> LWE(n) */
+int nufhe_keyswitch(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe_lwe src,
+                    long nbits);
+
+/* Fused binary gate: result = KS(BS_mu((0, c) + pa * a + pb * b)).  Covers gate_nand and its nine
+ * siblings (gates.py:81-597), e.g. NAND: c = 2^29, pa = pb = -1, mu = 2^29. */
+int nufhe_gate_binary(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe_lwe a,
+                      nufhe_lwe b, int32_t c, int32_t pa, int32_t pb, int32_t mu, long nbits);
+/* Fused MUX (gates.py:600-664): a ? b : c */
+int nufhe_gate_mux(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe_lwe a, nufhe_lwe b,
+                   nufhe_lwe c, long nbits);
+
+/* ---- per-kernel entry points (reference unit tests' granularity; also used by key generation) */
+
+/* Torus32ToPhase (numeric_functions_gpu.py:39-77) */
+int nufhe_t32_to_phase(nufhe_ctx *ctx, int32_t *d_result, const int32_t *d_phase, long count,
+                       uint32_t mspace_size);
+/* ShiftTorusPolynomial (polynomials_gpu.py:31-86): result/source [batch][polys][1024],
+ * powers [batch * powers_stride + powers_idx] */
+int nufhe_shift_torus_polynomial(nufhe_ctx *ctx, int32_t *d_result, const int32_t *d_source,
+                                 const int32_t *d_powers, long powers_stride, long powers_idx,
+                                 long batch, int polys, int minus_one, int invert_powers);
+/* tlwe_extract_lwe_samples (tlwe_gpu.mako:54-84), k = 1: tlwe [batch][2][1024] */
+int nufhe_tlwe_extract(nufhe_ctx *ctx, int32_t *d_result_a, int32_t *d_result_b,
+                       const int32_t *d_tlwe, long batch);
+/* Transform (transform/computation.py:28-99): batched negacyclic NTT-1024, natural order,
+ * identical values to ntt_transform_ref (transform/ntt.py:30-44). */
+int nufhe_ntt_forward_i32(nufhe_ctx *ctx, uint64_t *d_out, const int32_t *d_in, long batch);
+int nufhe_ntt_forward_u64(nufhe_ctx *ctx, uint64_t *d_out, const uint64_t *d_in, long batch);
+int nufhe_ntt_inverse_i32(nufhe_ctx *ctx, int32_t *d_out, const uint64_t *d_in, long batch);
+int nufhe_ntt_inverse_u64(nufhe_ctx *ctx, uint64_t *d_out, const uint64_t *d_in, long batch);
+/* Negacyclic product mod 2^32 of int32 polynomials through the NTT: out[b] = x[b] * y[b % y_batch] */
+int nufhe_poly_mul_i32(nufhe_ctx *ctx, int32_t *d_out, const int32_t *d_x, const int32_t *d_y,
+                       long batch, long y_batch);
+/* TGswTransformedExternalMul (tgsw_gpu.py:110-169): accum int32 [batch][2][1024] in place,
+ * against row bk_row of the uploaded bootstrapping key */
+int nufhe_external_mul(nufhe_ctx *ctx, nufhe_cloudkey *key, int32_t *d_accum, int bk_row,
+                       long batch);
+/* blind_rotate (bootstrap.py:119-142): accum int32 [batch][2][1024] in place,
+ * bara int32 [batch][bara_stride] in [0, 2N), rows [0, n_rows) of the key */
+int nufhe_blind_rotate(nufhe_ctx *ctx, nufhe_cloudkey *key, int32_t *d_accum,
+                       const int32_t *d_bara, long bara_stride, int n_rows, long batch);
+
+/* ---- key generation helpers ("next" row f1; device side of TLweEncryptZero) ---- */
+/* TLweEncryptZero (tlwe_gpu.py:111-196), k = 1: result_a [batch][2][1024] =
+ * (noises1, noises2 + noises1 * key);  key int32 [1024], noises1/noises2 [batch][1024] */
+int nufhe_tlwe_encrypt_zero(nufhe_ctx *ctx, int32_t *d_result_a, const int32_t *d_key,
+                            const int32_t *d_noises1, const int32_t *d_noises2, long batch);
+
+/* ---- measurement: time of the last fused gate / bootstrap kernels, from HIP events on the
+ * context's stream (milliseconds; blind-rotate kernel and keyswitch kernels separately) ---- */
+int nufhe_profile_enable(nufhe_ctx *ctx, int enable);
+int nufhe_profile_last(nufhe_ctx *ctx, float *blind_rotate_ms, float *keyswitch_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NUFHE_HIP_H */

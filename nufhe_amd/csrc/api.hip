@@ -1,0 +1,634 @@
+// api.hip -- the extern "C" boundary declared in include/nufhe_hip.h.
+// Owns: the HIP stream of a context, the twiddle tables, lazily grown scratch (extracted LWE(1024)
+// samples between the bootstrap and keyswitch kernels, keyswitch accumulators), and the device
+// copies of the cloud key in the layouts the kernels want.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/nufhe_hip.h"
+#include "kernels.h"
+#include "ntt_tables.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fail(NUFHE_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+struct Scratch {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct nufhe_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    u64 *d_tw1f = nullptr;
+    u64 *d_tw1i = nullptr;
+    Scratch ext_a, ext_b, ks_acc;
+    bool profile = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+};
+
+struct nufhe_cloudkey {
+    nufhe_ctx *ctx = nullptr;
+    int n = 0;
+    u64 *d_bk = nullptr;      // wave layout [n][8][1024]
+    i32 *d_ks_a3 = nullptr;   // [1024][8][3][n]
+    i32 *d_ks_b = nullptr;    // [1024][8][4]
+    float *d_ks_cv = nullptr; // [1024][8][4]
+};
+
+namespace {
+
+int ensure(nufhe_ctx *ctx, Scratch &s, size_t bytes)
+{
+    if (s.bytes >= bytes) return NUFHE_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (s.ptr) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipFree(s.ptr));
+        s.ptr = nullptr;
+        s.bytes = 0;
+    }
+    HIP_TRY(hipMalloc(&s.ptr, bytes));
+    s.bytes = bytes;
+    return NUFHE_OK;
+}
+
+inline LweView view(const nufhe_lwe &x) { return LweView{x.a, x.b, x.cv, x.a_stride, x.b_stride}; }
+
+inline BrSource source(const nufhe_lwe &x, i32 p) { return BrSource{x.a, x.b, x.a_stride, x.b_stride, p}; }
+
+int check_ctx(nufhe_ctx *ctx)
+{
+    if (!ctx) return fail(NUFHE_EINVAL, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return NUFHE_OK;
+}
+
+int check_key(nufhe_ctx *ctx, nufhe_cloudkey *key, bool need_bk, bool need_ks)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!key) return fail(NUFHE_EINVAL, "null cloud key");
+    if (key->ctx != ctx) return fail(NUFHE_EINVAL, "cloud key belongs to a different context");
+    if (need_bk && !key->d_bk) return fail(NUFHE_ENOKEY, "bootstrapping key not uploaded");
+    if (need_ks && !key->d_ks_a3) return fail(NUFHE_ENOKEY, "keyswitch key not uploaded");
+    return NUFHE_OK;
+}
+
+int pick_j_per_block(long nbits)
+{
+    const long tiles = (nbits + KS_TILE_BITS - 1) / KS_TILE_BITS;
+    int jsplit = 1;
+    while (jsplit < 64 && tiles * jsplit < 1024) jsplit *= 2;
+    return 1024 / jsplit;
+}
+
+// keyswitch of LWE(1024) src1 (+ src2) (+ constant on b) into `result`
+int run_keyswitch(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result, const i32 *s1a, long s1as,
+                  const i32 *s1b, long s1bs, const i32 *s2a, long s2as, const i32 *s2b, long s2bs, i32 c0,
+                  long nbits)
+{
+    int rc = ensure(ctx, ctx->ks_acc, (size_t)nbits * key->n * sizeof(u32));
+    if (rc) return rc;
+    KsLaunch P;
+    P.acc = (u32 *)ctx->ks_acc.ptr;
+    P.ks_a3 = key->d_ks_a3;
+    P.src1_a = s1a; P.src2_a = s2a;
+    P.src1_stride = s1as; P.src2_stride = s2as;
+    P.nbits = nbits;
+    P.n = key->n;
+    P.j_per_block = pick_j_per_block(nbits);
+    KsFinal F;
+    F.acc = P.acc;
+    F.ks_b = key->d_ks_b; F.ks_cv = key->d_ks_cv;
+    F.src1_a = s1a; F.src2_a = s2a; F.src1_b = s1b; F.src2_b = s2b;
+    F.src1_stride = s1as; F.src2_stride = s2as; F.src1_bstride = s1bs; F.src2_bstride = s2bs;
+    F.c0 = c0;
+    F.out_a = result.a; F.out_b = result.b; F.out_cv = result.cv;
+    F.out_a_stride = result.a_stride; F.out_b_stride = result.b_stride;
+    F.n = key->n;
+    HIP_TRY(launch_keyswitch(P, F, ctx->stream));
+    return NUFHE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *nufhe_last_error(void) { return g_last_error.c_str(); }
+const char *nufhe_version(void) { return "nufhe_hip 0.1 (gfx950)"; }
+
+int nufhe_device_count(int *count)
+{
+    if (!count) return fail(NUFHE_EINVAL, "null argument");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(NUFHE_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = c;
+    return NUFHE_OK;
+}
+
+int nufhe_device_name(int device, char *buf, size_t buflen)
+{
+    if (!buf || !buflen) return fail(NUFHE_EINVAL, "null argument");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return NUFHE_OK;
+}
+
+int nufhe_ctx_create(int device, void *stream, nufhe_ctx **out)
+{
+    if (!out) return fail(NUFHE_EINVAL, "null argument");
+    int count = 0;
+    int rc = nufhe_device_count(&count);
+    if (rc) return rc;
+    if (count == 0) return fail(NUFHE_ENODEV, "no HIP device available");
+    if (device < 0 || device >= count) return fail(NUFHE_EINVAL, "device %d out of range [0, %d)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    nufhe_ctx *ctx = new nufhe_ctx();
+    ctx->device = device;
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete ctx; return fail(NUFHE_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        ctx->own_stream = true;
+    }
+    std::vector<u64> f(1024), i(1024);
+    ntt_make_tables(f.data(), i.data());
+    hipError_t e = hipMalloc((void **)&ctx->d_tw1f, 1024 * sizeof(u64));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_tw1i, 1024 * sizeof(u64));
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_tw1f, f.data(), 1024 * sizeof(u64), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_tw1i, i.data(), 1024 * sizeof(u64), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = kernels_init_device();
+    for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipEventCreate(&ctx->ev[k]);
+    if (e != hipSuccess) {
+        nufhe_ctx_destroy(ctx);
+        return fail(NUFHE_EHIP, "context setup: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return NUFHE_OK;
+}
+
+int nufhe_ctx_destroy(nufhe_ctx *ctx)
+{
+    if (!ctx) return NUFHE_OK;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->d_tw1f) hipFree(ctx->d_tw1f);
+    if (ctx->d_tw1i) hipFree(ctx->d_tw1i);
+    if (ctx->ext_a.ptr) hipFree(ctx->ext_a.ptr);
+    if (ctx->ext_b.ptr) hipFree(ctx->ext_b.ptr);
+    if (ctx->ks_acc.ptr) hipFree(ctx->ks_acc.ptr);
+    for (int k = 0; k < 4; k++)
+        if (ctx->ev[k]) hipEventDestroy(ctx->ev[k]);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return NUFHE_OK;
+}
+
+int nufhe_ctx_synchronize(nufhe_ctx *ctx)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return NUFHE_OK;
+}
+
+int nufhe_ctx_device(nufhe_ctx *ctx, int *device)
+{
+    if (!ctx || !device) return fail(NUFHE_EINVAL, "null argument");
+    *device = ctx->device;
+    return NUFHE_OK;
+}
+
+void *nufhe_ctx_stream(nufhe_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int nufhe_alloc(nufhe_ctx *ctx, size_t bytes, void **d_ptr)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!d_ptr) return fail(NUFHE_EINVAL, "null argument");
+    HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return NUFHE_OK;
+}
+
+int nufhe_free(nufhe_ctx *ctx, void *d_ptr)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(d_ptr));
+    return NUFHE_OK;
+}
+
+int nufhe_h2d(nufhe_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return NUFHE_OK;
+}
+
+int nufhe_d2h(nufhe_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return NUFHE_OK;
+}
+
+// ---- cloud key ---------------------------------------------------------------------------
+
+int nufhe_cloudkey_create(nufhe_ctx *ctx, int lwe_size, nufhe_cloudkey **key)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!key) return fail(NUFHE_EINVAL, "null argument");
+    if (lwe_size < 1 || lwe_size > BR_MAX_LWE)
+        return fail(NUFHE_EINVAL, "lwe_size %d out of range [1, %d]", lwe_size, BR_MAX_LWE);
+    nufhe_cloudkey *k = new nufhe_cloudkey();
+    k->ctx = ctx;
+    k->n = lwe_size;
+    *key = k;
+    return NUFHE_OK;
+}
+
+int nufhe_cloudkey_destroy(nufhe_cloudkey *key)
+{
+    if (!key) return NUFHE_OK;
+    hipSetDevice(key->ctx->device);
+    hipStreamSynchronize(key->ctx->stream);
+    if (key->d_bk) hipFree(key->d_bk);
+    if (key->d_ks_a3) hipFree(key->d_ks_a3);
+    if (key->d_ks_b) hipFree(key->d_ks_b);
+    if (key->d_ks_cv) hipFree(key->d_ks_cv);
+    delete key;
+    return NUFHE_OK;
+}
+
+static int alloc_bk(nufhe_cloudkey *key)
+{
+    if (!key->d_bk) HIP_TRY(hipMalloc((void **)&key->d_bk, (size_t)key->n * BK_ROW_ELEMS * sizeof(u64)));
+    return NUFHE_OK;
+}
+
+int nufhe_bk_upload_reference(nufhe_cloudkey *key, const uint64_t *h_bk)
+{
+    if (!key || !h_bk) return fail(NUFHE_EINVAL, "null argument");
+    nufhe_ctx *ctx = key->ctx;
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    rc = alloc_bk(key);
+    if (rc) return rc;
+    const size_t bytes = (size_t)key->n * BK_ROW_ELEMS * sizeof(u64);
+    u64 *tmp = nullptr;
+    HIP_TRY(hipMalloc((void **)&tmp, bytes));
+    hipError_t e = hipMemcpyAsync(tmp, h_bk, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = launch_bk_from_reference(key->d_bk, tmp, (long)key->n * 8, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(tmp);
+    if (e != hipSuccess) return fail(NUFHE_EHIP, "bk upload: %s", hipGetErrorString(e));
+    return NUFHE_OK;
+}
+
+int nufhe_bk_download_reference(nufhe_cloudkey *key, uint64_t *h_bk)
+{
+    if (!key || !h_bk) return fail(NUFHE_EINVAL, "null argument");
+    nufhe_ctx *ctx = key->ctx;
+    int rc = check_key(ctx, key, true, false);
+    if (rc) return rc;
+    const size_t bytes = (size_t)key->n * BK_ROW_ELEMS * sizeof(u64);
+    u64 *tmp = nullptr;
+    HIP_TRY(hipMalloc((void **)&tmp, bytes));
+    hipError_t e = launch_bk_to_reference(tmp, key->d_bk, (long)key->n * 8, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_bk, tmp, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(tmp);
+    if (e != hipSuccess) return fail(NUFHE_EHIP, "bk download: %s", hipGetErrorString(e));
+    return NUFHE_OK;
+}
+
+int nufhe_bk_from_coeffs(nufhe_cloudkey *key, const int32_t *d_tgsw)
+{
+    if (!key || !d_tgsw) return fail(NUFHE_EINVAL, "null argument");
+    nufhe_ctx *ctx = key->ctx;
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    rc = alloc_bk(key);
+    if (rc) return rc;
+    HIP_TRY(launch_bk_from_coeffs(key->d_bk, d_tgsw, (long)key->n * 8, ctx->d_tw1f, ctx->d_tw1i, ctx->stream));
+    return NUFHE_OK;
+}
+
+int nufhe_ks_upload(nufhe_cloudkey *key, const int32_t *h_ks_a, const int32_t *h_ks_b, const float *h_ks_cv)
+{
+    if (!key || !h_ks_a || !h_ks_b || !h_ks_cv) return fail(NUFHE_EINVAL, "null argument");
+    nufhe_ctx *ctx = key->ctx;
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    const int n = key->n;
+    const long rows = 1024L * NUFHE_KS_T;
+    // base-0 slice must be zero (lwe_cpu.py:30-33): the kernels never read it
+    for (long r = 0; r < rows; r++) {
+        const int32_t *row0 = h_ks_a + (r * 4) * n;
+        for (int i = 0; i < n; i++)
+            if (row0[i] != 0) return fail(NUFHE_EINVAL, "keyswitch key: base-0 slice of ks_a is not zero (row %ld)", r);
+        if (h_ks_b[r * 4] != 0 || h_ks_cv[r * 4] != 0.0f)
+            return fail(NUFHE_EINVAL, "keyswitch key: base-0 slice of ks_b/ks_cv is not zero (row %ld)", r);
+    }
+    std::vector<int32_t> packed((size_t)rows * 3 * n);
+    for (long r = 0; r < rows; r++)
+        memcpy(packed.data() + (size_t)r * 3 * n, h_ks_a + ((size_t)r * 4 + 1) * n, sizeof(int32_t) * 3 * n);
+    if (!key->d_ks_a3) HIP_TRY(hipMalloc((void **)&key->d_ks_a3, packed.size() * sizeof(int32_t)));
+    if (!key->d_ks_b) HIP_TRY(hipMalloc((void **)&key->d_ks_b, rows * 4 * sizeof(int32_t)));
+    if (!key->d_ks_cv) HIP_TRY(hipMalloc((void **)&key->d_ks_cv, rows * 4 * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(key->d_ks_a3, packed.data(), packed.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(key->d_ks_b, h_ks_b, rows * 4 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(key->d_ks_cv, h_ks_cv, rows * 4 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return NUFHE_OK;
+}
+
+// ---- hot path ----------------------------------------------------------------------------
+
+int nufhe_lwe_linear(nufhe_ctx *ctx, nufhe_lwe res, nufhe_lwe src, int32_t p, int add_result, long nbits, int size)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (nbits < 0 || size < 1) return fail(NUFHE_EINVAL, "bad sizes");
+    HIP_TRY(launch_lwe_linear(view(res), view(src), p, add_result, nbits, size, ctx->stream));
+    return NUFHE_OK;
+}
+
+int nufhe_lwe_trivial_const(nufhe_ctx *ctx, nufhe_lwe res, int32_t mu, long nbits, int size)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (nbits < 0 || size < 1) return fail(NUFHE_EINVAL, "bad sizes");
+    HIP_TRY(launch_lwe_trivial_const(view(res), mu, nbits, size, ctx->stream));
+    return NUFHE_OK;
+}
+
+// shared by bootstrap / gate_binary / gate_mux: jobs -> (optional keyswitch) -> result
+static int run_gate(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result, const BrJob *jobs, int njobs,
+                    i32 mu, long nbits, bool keyswitch, i32 ks_c0)
+{
+    if (nbits < 0) return fail(NUFHE_EINVAL, "negative batch size");
+    if (nbits == 0) return NUFHE_OK;
+    const long total = nbits * njobs;
+    BrLaunch P;
+    memset(&P, 0, sizeof(P));
+    for (int j = 0; j < njobs; j++) P.job[j] = jobs[j];
+    P.bits_per_job = nbits;
+    P.nbits_total = total;
+    P.bk = key->d_bk;
+    P.n = key->n;
+    P.mu = mu;
+    P.tw1f = ctx->d_tw1f;
+    P.tw1i = ctx->d_tw1i;
+    if (keyswitch) {
+        int rc = ensure(ctx, ctx->ext_a, (size_t)total * 1024 * sizeof(i32));
+        if (rc) return rc;
+        rc = ensure(ctx, ctx->ext_b, (size_t)total * sizeof(i32));
+        if (rc) return rc;
+        P.out_a = (i32 *)ctx->ext_a.ptr; P.out_a_stride = 1024;
+        P.out_b = (i32 *)ctx->ext_b.ptr; P.out_b_stride = 1;
+    } else {
+        P.out_a = result.a; P.out_a_stride = result.a_stride;
+        P.out_b = result.b; P.out_b_stride = result.b_stride;
+    }
+    if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+    HIP_TRY(launch_bootstrap(P, ctx->stream));
+    if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+    if (keyswitch) {
+        const i32 *ea = (const i32 *)ctx->ext_a.ptr, *eb = (const i32 *)ctx->ext_b.ptr;
+        int rc = run_keyswitch(ctx, key, result, ea, 1024, eb, 1, njobs == 2 ? ea + nbits * 1024 : nullptr, 1024,
+                               njobs == 2 ? eb + nbits : nullptr, 1, ks_c0, nbits);
+        if (rc) return rc;
+    }
+    if (ctx->profile) {
+        HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+        ctx->ev_valid = true;
+    }
+    return NUFHE_OK;
+}
+
+int nufhe_bootstrap(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe_lwe x, int32_t mu, long nbits,
+                    int no_keyswitch)
+{
+    int rc = check_key(ctx, key, true, !no_keyswitch);
+    if (rc) return rc;
+    BrJob job;
+    memset(&job, 0, sizeof(job));
+    job.s0 = source(x, 1);
+    job.c0 = 0;
+    return run_gate(ctx, key, result, &job, 1, mu, nbits, !no_keyswitch, 0);
+}
+
+int nufhe_keyswitch(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe_lwe src, long nbits)
+{
+    int rc = check_key(ctx, key, false, true);
+    if (rc) return rc;
+    if (nbits < 0) return fail(NUFHE_EINVAL, "negative batch size");
+    if (nbits == 0) return NUFHE_OK;
+    if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+    if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+    rc = run_keyswitch(ctx, key, result, src.a, src.a_stride, src.b, src.b_stride, nullptr, 0, nullptr, 0, 0, nbits);
+    if (rc) return rc;
+    if (ctx->profile) {
+        HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+        ctx->ev_valid = true;
+    }
+    return NUFHE_OK;
+}
+
+int nufhe_gate_binary(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe_lwe a, nufhe_lwe b, int32_t c,
+                      int32_t pa, int32_t pb, int32_t mu, long nbits)
+{
+    int rc = check_key(ctx, key, true, true);
+    if (rc) return rc;
+    BrJob job;
+    memset(&job, 0, sizeof(job));
+    job.s0 = source(a, pa);
+    job.s1 = source(b, pb);
+    job.c0 = c;
+    return run_gate(ctx, key, result, &job, 1, mu, nbits, true, 0);
+}
+
+int nufhe_gate_mux(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe_lwe a, nufhe_lwe b, nufhe_lwe c,
+                   long nbits)
+{
+    int rc = check_key(ctx, key, true, true);
+    if (rc) return rc;
+    const i32 MU = (i32)(1u << 29);
+    BrJob jobs[2];
+    memset(jobs, 0, sizeof(jobs));
+    jobs[0].s0 = source(a, 1);  jobs[0].s1 = source(b, 1);  jobs[0].c0 = -MU;   // (0,-1/8) + a + b, gates.py:639-641
+    jobs[1].s0 = source(a, -1); jobs[1].s1 = source(c, 1);  jobs[1].c0 = -MU;   // (0,-1/8) - a + c, gates.py:648-650
+    return run_gate(ctx, key, result, jobs, 2, MU, nbits, true, MU);             // (0,1/8) + u1 + u2 -> KS, :657-664
+}
+
+// ---- per-kernel entry points -------------------------------------------------------------
+
+int nufhe_t32_to_phase(nufhe_ctx *ctx, int32_t *d_result, const int32_t *d_phase, long count, uint32_t mspace_size)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (mspace_size == 0) return fail(NUFHE_EINVAL, "mspace_size must be positive");
+    HIP_TRY(launch_t32_to_phase(d_result, d_phase, count, mspace_size, ctx->stream));
+    return NUFHE_OK;
+}
+
+int nufhe_shift_torus_polynomial(nufhe_ctx *ctx, int32_t *d_result, const int32_t *d_source, const int32_t *d_powers,
+                                 long powers_stride, long powers_idx, long batch, int polys, int minus_one,
+                                 int invert_powers)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(launch_shift_tp(d_result, d_source, d_powers, powers_stride, powers_idx, batch, polys, minus_one,
+                            invert_powers, ctx->stream));
+    return NUFHE_OK;
+}
+
+int nufhe_tlwe_extract(nufhe_ctx *ctx, int32_t *d_result_a, int32_t *d_result_b, const int32_t *d_tlwe, long batch)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(launch_tlwe_extract(d_result_a, d_result_b, d_tlwe, batch, ctx->stream));
+    return NUFHE_OK;
+}
+
+int nufhe_ntt_forward_i32(nufhe_ctx *ctx, uint64_t *d_out, const int32_t *d_in, long batch)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(launch_ntt_forward(d_out, d_in, 0, batch, ctx->d_tw1f, ctx->d_tw1i, ctx->stream));
+    return NUFHE_OK;
+}
+
+int nufhe_ntt_forward_u64(nufhe_ctx *ctx, uint64_t *d_out, const uint64_t *d_in, long batch)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(launch_ntt_forward(d_out, d_in, 1, batch, ctx->d_tw1f, ctx->d_tw1i, ctx->stream));
+    return NUFHE_OK;
+}
+
+int nufhe_ntt_inverse_i32(nufhe_ctx *ctx, int32_t *d_out, const uint64_t *d_in, long batch)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(launch_ntt_inverse(d_out, d_in, 0, batch, ctx->d_tw1f, ctx->d_tw1i, ctx->stream));
+    return NUFHE_OK;
+}
+
+int nufhe_ntt_inverse_u64(nufhe_ctx *ctx, uint64_t *d_out, const uint64_t *d_in, long batch)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(launch_ntt_inverse(d_out, d_in, 1, batch, ctx->d_tw1f, ctx->d_tw1i, ctx->stream));
+    return NUFHE_OK;
+}
+
+int nufhe_poly_mul_i32(nufhe_ctx *ctx, int32_t *d_out, const int32_t *d_x, const int32_t *d_y, long batch, long y_batch)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (y_batch < 1) return fail(NUFHE_EINVAL, "y_batch must be positive");
+    HIP_TRY(launch_poly_mul(d_out, d_x, d_y, nullptr, 1024, batch, y_batch, ctx->d_tw1f, ctx->d_tw1i, ctx->stream));
+    return NUFHE_OK;
+}
+
+int nufhe_external_mul(nufhe_ctx *ctx, nufhe_cloudkey *key, int32_t *d_accum, int bk_row, long batch)
+{
+    int rc = check_key(ctx, key, true, false);
+    if (rc) return rc;
+    if (bk_row < 0 || bk_row >= key->n) return fail(NUFHE_EINVAL, "bk_row %d out of range", bk_row);
+    HIP_TRY(launch_blind_rotate_accum(d_accum, key->d_bk, nullptr, 0, bk_row, 1, 1, batch, ctx->d_tw1f, ctx->d_tw1i,
+                                      ctx->stream));
+    return NUFHE_OK;
+}
+
+int nufhe_blind_rotate(nufhe_ctx *ctx, nufhe_cloudkey *key, int32_t *d_accum, const int32_t *d_bara, long bara_stride,
+                       int n_rows, long batch)
+{
+    int rc = check_key(ctx, key, true, false);
+    if (rc) return rc;
+    if (n_rows < 0 || n_rows > key->n) return fail(NUFHE_EINVAL, "n_rows %d out of range", n_rows);
+    HIP_TRY(launch_blind_rotate_accum(d_accum, key->d_bk, d_bara, bara_stride, 0, n_rows, 0, batch, ctx->d_tw1f,
+                                      ctx->d_tw1i, ctx->stream));
+    return NUFHE_OK;
+}
+
+int nufhe_tlwe_encrypt_zero(nufhe_ctx *ctx, int32_t *d_result_a, const int32_t *d_key, const int32_t *d_noises1,
+                            const int32_t *d_noises2, long batch)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    // mask polynomial: result[:, 0, :] = noises1 (tlwe_cpu.py:81)
+    HIP_TRY(hipMemcpy2DAsync(d_result_a, 2048 * sizeof(i32), d_noises1, 1024 * sizeof(i32), 1024 * sizeof(i32),
+                             (size_t)batch, hipMemcpyDeviceToDevice, ctx->stream));
+    // body: result[:, 1, :] = noises2 + noises1 * key (tlwe_cpu.py:76-84)
+    HIP_TRY(launch_poly_mul(d_result_a + 1024, d_noises1, d_key, d_noises2, 2048, batch, 1, ctx->d_tw1f, ctx->d_tw1i,
+                            ctx->stream));
+    return NUFHE_OK;
+}
+
+int nufhe_profile_enable(nufhe_ctx *ctx, int enable)
+{
+    if (!ctx) return fail(NUFHE_EINVAL, "null context");
+    ctx->profile = enable != 0;
+    ctx->ev_valid = false;
+    return NUFHE_OK;
+}
+
+int nufhe_profile_last(nufhe_ctx *ctx, float *blind_rotate_ms, float *keyswitch_ms)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!ctx->ev_valid) return fail(NUFHE_EINVAL, "no profiled launch recorded");
+    HIP_TRY(hipEventSynchronize(ctx->ev[2]));
+    float br = 0, ks = 0;
+    HIP_TRY(hipEventElapsedTime(&br, ctx->ev[0], ctx->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ks, ctx->ev[1], ctx->ev[2]));
+    if (blind_rotate_ms) *blind_rotate_ms = br;
+    if (keyswitch_ms) *keyswitch_ms = ks;
+    return NUFHE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,190 @@
+// blind_rotate.h -- fused bootstrap body: mod-switch + test-vector init + 500 x (rotate, gadget
+// decomposition, 4 forward NTTs, multiply-accumulate against one bootstrapping-key row, 2 inverse
+// NTTs) + sample extraction, for ONE ciphertext bit executed by ONE wavefront.
+//
+// Replaces the reference's fused kernel (nufhe/blind_rotate.mako:18-226, launched from
+// nufhe/blind_rotate.py:156-180: one 512+-thread work-group per bit with 3 barriers per transform)
+// and the driver logic around it (nufhe/bootstrap.py:154-229).  Behaviour (bit-exact):
+//   bara_i = round(a_i * 2N / 2^32), barb likewise          (numeric_functions_cpu.py:23-37)
+//   ACC = (0, X^(2N - barb) * [mu, ..., mu])                (bootstrap.py:176-182)
+//   for i < n: ACC += BK_i (.) ((X^bara_i - 1) * ACC)       (bootstrap.py:96-109, tgsw_cpu.py:82-106)
+//   extract: a'_0 = A_0, a'_j = -A_(N-j), b' = B_0          (tlwe_cpu.py:41-60)
+//
+// CDNA4 mapping: a wave owns its bit completely -- the accumulator lives in 32 VGPRs per lane
+// (coefficient j = lane + 64 r) with an LDS mirror that is only used for the data-dependent
+// rotation; the four digit polynomials are transformed one after the other by the same wave and
+// multiplied straight out of registers against the key row (stored in the wave layout, read with
+// 16-byte loads, 1 KiB per wave instruction); no s_barrier anywhere in the loop.
+#pragma once
+#include "ff.h"
+#include "ntt1024.h"
+
+#define BR_N 1024
+#define BR_MAX_LWE 512                    /* capacity of the per-wave bara buffer (u16 each) */
+#define BK_POLY_ELEMS 1024
+#define BK_ROW_ELEMS (8 * BK_POLY_ELEMS)  /* one TGSW row: (k+1) l (k+1) = 8 polynomials */
+
+#define TGSW_OFFSET 0x80200000u           /* 2^31 + 2^21: tgsw.py:49-52 with l=2, Bg=2^10 */
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#else
+#define WAVE_UNIFORM(x) (x)
+#endif
+
+// element offset of (lane, reg) inside one key polynomial in the wave layout:
+// [reg/2][lane][reg%2] so that a wave reads 8 x (64 lanes x 16 bytes)
+FF_FN constexpr int bk_elem_offset(int lane, int reg) { return (reg >> 1) * 128 + lane * 2 + (reg & 1); }
+
+// One source term of the linear combination that feeds the bootstrap (gates.py:110-114):
+// tmp = (0, c0) + sum_s p_s * src_s
+struct BrSource {
+    const i32 *a;      // [bit * a_stride + i]
+    const i32 *b;      // [bit * b_stride]
+    long a_stride;
+    long b_stride;
+    i32 p;             // 0 => term absent
+};
+
+struct BrLds {
+    u64 *xbuf;         // NTT exchange buffer, NTT_XBUF_ELEMS u64
+    i32 *acc;          // [2][1024] accumulator mirror for rotated reads
+    uint16_t *bara;    // [BR_MAX_LWE]
+    const u64 *tw1f;   // [1024]
+    const u64 *tw1i;   // [1024]
+};
+
+// mod-switch, Torus32ToPhase with mspace 2N = 2048 (numeric_functions_cpu.py:23-37)
+FF_FN u32 br_modswitch(u32 x) { return (x + (1u << 20)) >> 21; }
+
+// Prologue: linear combination + mod-switch of the n mask coefficients into LDS, returns barb
+FF_FN u32 br_prologue(const BrSource &s0, const BrSource &s1, i32 c0, long bit, int n, const BrLds &lds,
+                      int lane)
+{
+    for (int i = lane; i < n; i += 64) {
+        u32 v = 0;
+        if (s0.p) v += (u32)s0.p * (u32)s0.a[bit * s0.a_stride + i];
+        if (s1.p) v += (u32)s1.p * (u32)s1.a[bit * s1.a_stride + i];
+        lds.bara[i] = (uint16_t)br_modswitch(v);
+    }
+    u32 vb = (u32)c0;
+    if (s0.p) vb += (u32)s0.p * (u32)s0.b[bit * s0.b_stride];
+    if (s1.p) vb += (u32)s1.p * (u32)s1.b[bit * s1.b_stride];
+    return br_modswitch(vb);
+}
+
+// gadget decomposition digit p (1-based) of a torus coefficient: tgsw_cpu.py:41-47
+template <int DIGIT>
+FF_FN i32 br_digit(u32 t)
+{
+    const i32 x = (i32)(t + TGSW_OFFSET);
+    return ((x >> (32 - 10 * (DIGIT + 1))) & 1023) - 512;
+}
+
+// External product of one TGSW row with a TLWE sample given coefficient-wise by `tsrc`:
+//   sum[mo] (canonical field elements of the coefficient-domain result, coefficient lane + 64 r)
+//     = sum_{m, d} digit_d(T_m) (*) BK_row[m][d][mo]                      (tgsw_cpu.py:82-106)
+// tsrc(m, T) must fill T[r] = coefficient lane + 64 r of polynomial m (as uint32 torus values).
+template <class TSource>
+FF_FN void br_external_product(u64 (&sum)[2][16], TSource &&tsrc, const u64 *row, const BrLds &lds,
+                               const NttLane &L)
+{
+    const int lane = L.lane;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { sum[0][r] = 0; sum[1][r] = 0; }
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        u32 T[16];
+        tsrc(m, T);
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            u64 x[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                x[r] = ff_from_i32(d == 0 ? br_digit<0>(T[r]) : br_digit<1>(T[r]));
+            ntt_forward(x, lds.xbuf, lds.tw1f, L);
+            // multiply-accumulate against BK[i][m][d][mo] (tgsw_cpu.py:63-77)
+            const u64 *poly = row + (m * 2 + d) * 2 * BK_POLY_ELEMS;
+#pragma unroll
+            for (int mo = 0; mo < 2; mo++) {
+                const u64 *p = poly + mo * BK_POLY_ELEMS + lane * 2;
+#pragma unroll
+                for (int h = 0; h < 8; h++) {
+                    const u64 k0 = p[h * 128], k1 = p[h * 128 + 1];
+                    sum[mo][2 * h] = ff_add(sum[mo][2 * h], ff_mul(x[2 * h], k0));
+                    sum[mo][2 * h + 1] = ff_add(sum[mo][2 * h + 1], ff_mul(x[2 * h + 1], k1));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int mo = 0; mo < 2; mo++) ntt_inverse(sum[mo], lds.xbuf, lds.tw1i, L);
+}
+
+// ACC = (0, X^(2N - barb) * mu) (bootstrap.py:176-182): body coefficient j is +mu if
+// (j + barb) mod 2N < N, else -mu.  Fills the registers and the LDS mirror.
+FF_FN void br_init_acc(u32 (&acc)[2][16], u32 barb, i32 mu, const BrLds &lds, int lane)
+{
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const u32 j = (u32)(lane + 64 * r);
+        const u32 t = (j + barb) & 2047u;
+        acc[0][r] = 0;
+        acc[1][r] = (t < 1024u) ? (u32)mu : 0u - (u32)mu;
+        lds.acc[j] = 0;
+        lds.acc[1024 + j] = (i32)acc[1][r];
+    }
+    WAVE_SYNC();
+}
+
+// One blind-rotate step with rotation amount a in [0, 2N) (bootstrap.py:96-109):
+// ACC += BK_row (.) ((X^a - 1) ACC).  acc registers and the LDS mirror are both updated.
+FF_FN void br_step(u32 (&acc)[2][16], u32 a, const u64 *row, const BrLds &lds, const NttLane &L)
+{
+    const int lane = L.lane;
+    u64 sum[2][16];
+    br_external_product(
+        sum,
+        [&](int m, u32 (&T)[16]) {
+            // T = (X^a - 1) ACC_m  (polynomials_cpu.py:46-58 with minus_one)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const u32 j = (u32)(lane + 64 * r);
+                const u32 t = (j - a) & 2047u;
+                const u32 v = (u32)lds.acc[m * 1024 + (t & 1023u)];
+                T[r] = ((t & 1024u) ? 0u - v : v) - acc[m][r];
+            }
+        },
+        row, lds, L);
+#pragma unroll
+    for (int mo = 0; mo < 2; mo++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            acc[mo][r] += (u32)ff_to_i32(sum[mo][r]);
+            lds.acc[mo * 1024 + lane + 64 * r] = (i32)acc[mo][r];
+        }
+    WAVE_SYNC();
+}
+
+// The whole blind rotation for one bit; bara comes from the per-wave LDS buffer.
+FF_FN void br_blind_rotate(u32 (&acc)[2][16], const u64 *bk, int n, u32 barb, i32 mu, const BrLds &lds,
+                           const NttLane &L)
+{
+    br_init_acc(acc, barb, mu, lds, L.lane);
+    for (int i = 0; i < n; i++) {
+        const u32 a = WAVE_UNIFORM((u32)lds.bara[i]);
+        if (a == 0) continue;   // (X^0 - 1) ACC = 0: the external product adds nothing
+        br_step(acc, a, bk + (long)i * BK_ROW_ELEMS, lds, L);
+    }
+}
+
+// Sample extraction straight from registers (tlwe_cpu.py:55-58); out_a has 1024 entries
+FF_FN void br_extract(i32 *out_a, i32 *out_b, const u32 (&acc)[2][16], int lane)
+{
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int j = lane + 64 * r;
+        out_a[(1024 - j) & 1023] = (i32)(j == 0 ? acc[0][r] : 0u - acc[0][r]);
+    }
+    if (lane == 0) *out_b = (i32)acc[1][0];
+}

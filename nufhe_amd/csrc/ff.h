@@ -1,0 +1,137 @@
+// ff.h -- arithmetic in GF(P), P = 2^64 - 2^32 + 1, for CDNA4 32-bit integer VALUs.
+//
+// Replaces the reference's finite-field Mako modules (nufhe/transform/arithmetic.mako:42-1045:
+// add :78-119, sub :122-161, mul :197-333, lsh :465-1045).  Written from the behavioural spec
+// (canonical representatives in [0, P); 2^64 = 2^32 - 1, 2^96 = -1, 2^192 = 1 mod P); there is
+// no PTX/OpenCL flavour matrix here, only one formulation for the gfx950 integer ALU.
+//
+// The header also compiles with a host C++ compiler: tests/emu/ runs the wave-level kernel
+// bodies lane by lane on the CPU to check them against the oracle without a GPU.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define FF_FN __host__ __device__ __forceinline__
+#else
+#define FF_FN static inline __attribute__((always_inline))
+#endif
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef int32_t i32;
+
+#define FF_P 0xFFFFFFFF00000001ULL
+#define FF_EPS 0xFFFFFFFFULL /* 2^64 mod P */
+
+// a, b canonical (< P) -> canonical
+FF_FN u64 ff_sub(u64 a, u64 b)
+{
+    u64 d = a - b;
+    return (a < b) ? d - FF_EPS : d;   // borrow: + P == - EPS (mod 2^64)
+}
+
+// a, b canonical -> canonical.  a + b - P is computed as a - (P - b): one borrow decides,
+// no 64-bit compare against P is needed.
+FF_FN u64 ff_add(u64 a, u64 b) { return ff_sub(a, FF_P - b); }
+
+FF_FN u64 ff_neg(u64 a) { return ff_sub(0, a); }
+
+// any 64-bit value -> canonical
+FF_FN u64 ff_canon(u64 x) { return x >= FF_P ? x - FF_P : x; }
+
+// w * (2^32 - 1), canonical for any 32-bit w
+FF_FN u64 ff_times_eps(u32 w) { return ((u64)w << 32) - w; }
+
+// lo + 2^64 * (h0 + 2^32 h1) -> canonical    (2^64 = 2^32 - 1, 2^96 = -1)
+FF_FN u64 ff_reduce128(u64 lo, u32 h0, u32 h1)
+{
+    u64 t = lo - h1;
+    if (lo < h1) t -= FF_EPS;              // borrow: + P; cannot underflow again
+    u64 m = ff_times_eps(h0);
+    u64 r = t + m;
+    if (r < m) r += FF_EPS;                // carry: + 2^64 = + EPS; cannot overflow again
+    return ff_canon(r);
+}
+
+FF_FN void ff_mul_wide(u64 a, u64 b, u64 &lo, u64 &hi)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    lo = a * b;
+    hi = __umul64hi(a, b);
+#else
+    unsigned __int128 p = (unsigned __int128)a * b;
+    lo = (u64)p;
+    hi = (u64)(p >> 64);
+#endif
+}
+
+// canonical * canonical -> canonical
+FF_FN u64 ff_mul(u64 a, u64 b)
+{
+    u64 lo, hi;
+    ff_mul_wide(a, b, lo, hi);
+    return ff_reduce128(lo, (u32)hi, (u32)(hi >> 32));
+}
+
+// signed 32-bit integer -> canonical field element (ntt.mako:395-399)
+FF_FN u64 ff_from_i32(i32 x)
+{
+    u64 v = (u64)(int64_t)x;
+    return x < 0 ? v + FF_P : v;
+}
+
+// canonical field element -> i32: values above P/2 are negative, truncated to 32 bits
+// (ntt.mako:402-408, ntt_cpu.py:74-80)
+FF_FN i32 ff_to_i32(u64 v) { return (i32)((u32)v - (u32)(v > FF_P / 2)); }
+
+// (w0 + w1 2^32 + w2 2^64) * 2^(32 Q), Q in {0,1,2}; w2 < 2^31.  -> canonical
+template <int Q>
+FF_FN u64 ff_place96(u32 w0, u32 w1, u32 w2)
+{
+    if constexpr (Q == 0) {          // (w1:w0) + w2 * eps
+        return ff_reduce128(((u64)w1 << 32) | w0, w2, 0);
+    } else if constexpr (Q == 1) {   // w0 2^32 + w1 eps - w2
+        return ff_add(ff_sub((u64)w0 << 32, (u64)w2), ff_times_eps(w1));
+    } else {               // w0 eps - (w2:w1)
+        return ff_sub(ff_times_eps(w0), ((u64)w2 << 32) | w1);
+    }
+}
+
+// canonical x times 2^S, S compile-time in [0, 96)
+template <int S>
+FF_FN u64 ff_mul_pow2_lt96(u64 x)
+{
+    static_assert(S >= 0 && S < 96, "shift out of range");
+    if constexpr (S == 0) return x;
+    constexpr int R = S % 32, Q = S / 32;
+    const u32 lo = (u32)x, hi = (u32)(x >> 32);
+    u32 w0, w1, w2;
+    if constexpr (R == 0) {
+        w0 = lo; w1 = hi; w2 = 0;
+    } else {
+        w0 = lo << R;
+        w1 = (hi << R) | (lo >> ((32 - R) & 31));
+        w2 = hi >> ((32 - R) & 31);
+    }
+    return ff_place96<Q>(w0, w1, w2);
+}
+
+// canonical x times 2^S mod P, S compile-time, any integer (reduced mod 192; 2^96 = -1)
+// (the reference's "lsh" family, arithmetic.mako:465-1045)
+template <int S>
+FF_FN u64 ff_mul_pow2(u64 x)
+{
+    constexpr int T = ((S % 192) + 192) % 192;
+    if constexpr (T >= 96) return ff_neg(ff_mul_pow2_lt96<T - 96>(x));
+    else return ff_mul_pow2_lt96<T>(x);
+}
+
+// canonical x times 2^r, r a run-time (per-lane) amount in [0, 31]
+FF_FN u64 ff_mul_pow2_var(u64 x, u32 r)
+{
+    const u32 hi = (u32)(x >> 32);
+    const u64 sh = x << r;                      // low 64 bits of x * 2^r
+    const u32 w2 = (hi >> 1) >> (31 - r);       // bits shifted out (r = 0 safe)
+    return ff_reduce128(sh, w2, 0);
+}

@@ -1,0 +1,87 @@
+// kernels.h -- launch descriptors and host launchers of kernels.hip (internal to libnufhe_hip.so)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "blind_rotate.h"
+
+#define BR_BLOCK_THREADS 512
+#define BR_WAVES_PER_BLOCK 8
+#define KS_BLOCK_THREADS 256
+#define KS_TILE_BITS 32
+
+struct BrJob {
+    BrSource s0, s1;
+    i32 c0;
+};
+
+// Fused bootstrap launch: global bit g in [0, nbits_total); job = g / bits_per_job (at most 2 jobs:
+// MUX runs its two blind rotations in one launch), bit = g % bits_per_job.
+struct BrLaunch {
+    BrJob job[2];
+    long bits_per_job;
+    long nbits_total;
+    const u64 *bk;        // wave layout, [n][8][1024]
+    int n;
+    i32 mu;
+    i32 *out_a;           // extracted LWE(1024): out_a[g * out_a_stride + j]
+    i32 *out_b;           // out_b[g * out_b_stride]
+    long out_a_stride;
+    long out_b_stride;
+    const u64 *tw1f;
+    const u64 *tw1i;
+};
+
+struct KsLaunch {
+    u32 *acc;             // [nbits][n] zero-initialised accumulator
+    const i32 *ks_a3;     // [1024][8][3][n] (digits 1..3)
+    const i32 *src1_a;    // LWE(1024) source, plus optional second source added on the fly (MUX)
+    const i32 *src2_a;
+    long src1_stride, src2_stride;
+    long nbits;
+    int n;
+    int j_per_block;
+};
+
+struct KsFinal {
+    const u32 *acc;
+    const i32 *ks_b;      // [1024][8][4]
+    const float *ks_cv;   // [1024][8][4]
+    const i32 *src1_a, *src2_a, *src1_b, *src2_b;
+    long src1_stride, src2_stride, src1_bstride, src2_bstride;
+    i32 c0;               // constant added to b (MUX: +1/8)
+    i32 *out_a, *out_b;
+    float *out_cv;
+    long out_a_stride, out_b_stride;
+    int n;
+};
+
+struct LweView {
+    i32 *a;
+    i32 *b;
+    float *cv;
+    long a_stride, b_stride;
+};
+
+hipError_t kernels_init_device();
+hipError_t launch_bootstrap(const BrLaunch &P, hipStream_t stream);
+hipError_t launch_blind_rotate_accum(i32 *accum, const u64 *bk, const i32 *bara, long bara_stride, int row0,
+                                     int n_rows, int external_mul_only, long batch, const u64 *tw1f,
+                                     const u64 *tw1i, hipStream_t stream);
+hipError_t launch_ntt_forward(u64 *out, const void *in, int mode, long batch, const u64 *tw1f, const u64 *tw1i,
+                              hipStream_t stream);
+hipError_t launch_ntt_inverse(void *out, const u64 *in, int mode, long batch, const u64 *tw1f, const u64 *tw1i,
+                              hipStream_t stream);
+hipError_t launch_poly_mul(i32 *out, const i32 *x, const i32 *y, const i32 *base, long out_stride, long batch,
+                           long y_batch, const u64 *tw1f, const u64 *tw1i, hipStream_t stream);
+hipError_t launch_bk_from_reference(u64 *out, const u64 *in, long polys, hipStream_t stream);
+hipError_t launch_bk_to_reference(u64 *out, const u64 *in, long polys, hipStream_t stream);
+hipError_t launch_bk_from_coeffs(u64 *out, const i32 *in, long polys, const u64 *tw1f, const u64 *tw1i,
+                                 hipStream_t stream);
+hipError_t launch_keyswitch(const KsLaunch &P, const KsFinal &F, hipStream_t stream);
+hipError_t launch_lwe_linear(const LweView &res, const LweView &src, i32 p, int add_result, long nbits, int size,
+                             hipStream_t stream);
+hipError_t launch_lwe_trivial_const(const LweView &res, i32 mu, long nbits, int size, hipStream_t stream);
+hipError_t launch_t32_to_phase(i32 *result, const i32 *phase, long count, u32 mspace, hipStream_t stream);
+hipError_t launch_shift_tp(i32 *result, const i32 *source, const i32 *powers, long powers_stride, long powers_idx,
+                           long batch, int polys, int minus_one, int invert_powers, hipStream_t stream);
+hipError_t launch_tlwe_extract(i32 *ra, i32 *rb, const i32 *tlwe, long batch, hipStream_t stream);

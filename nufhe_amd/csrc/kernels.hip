@@ -1,0 +1,547 @@
+// kernels.hip -- gfx950 kernels of the bootstrapped-gate hot path and their host launchers.
+// Device-side bodies live in ff.h / ntt1024.h / blind_rotate.h / keyswitch.h; this file adds the
+// __global__ wrappers (LDS carving, wave -> bit mapping) and the launch geometry.
+#include <hip/hip_runtime.h>
+
+#include "blind_rotate.h"
+#include "ff.h"
+#include "kernels.h"
+#include "ntt1024.h"
+
+// ------------------------------------------------------------------------------------------
+// LDS carving
+// ------------------------------------------------------------------------------------------
+// [0, 8 KiB)   tw1f     [8 KiB, 16 KiB)  tw1i      then one region per wave:
+//   xbuf (8704 B) | acc mirror (8192 B) | bara (1024 B)            = 17920 B
+#define TABLE_LDS_BYTES (2 * 1024 * 8)
+#define WAVE_XBUF_BYTES (NTT_XBUF_ELEMS * 8)
+#define WAVE_ACC_BYTES (2 * 1024 * 4)
+#define WAVE_BARA_BYTES (BR_MAX_LWE * 2)
+#define WAVE_BR_LDS_BYTES (WAVE_XBUF_BYTES + WAVE_ACC_BYTES + WAVE_BARA_BYTES)
+
+extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
+
+__device__ __forceinline__ void load_tables(const u64 *__restrict__ g_tw1f, const u64 *__restrict__ g_tw1i)
+{
+    u64 *t = (u64 *)g_smem;
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) {
+        t[i] = g_tw1f[i];
+        t[1024 + i] = g_tw1i[i];
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ BrLds carve_br_lds(int wave)
+{
+    unsigned char *base = g_smem + TABLE_LDS_BYTES + wave * WAVE_BR_LDS_BYTES;
+    BrLds lds;
+    lds.xbuf = (u64 *)base;
+    lds.acc = (i32 *)(base + WAVE_XBUF_BYTES);
+    lds.bara = (uint16_t *)(base + WAVE_XBUF_BYTES + WAVE_ACC_BYTES);
+    lds.tw1f = (const u64 *)g_smem;
+    lds.tw1i = (const u64 *)g_smem + 1024;
+    return lds;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: fused bootstrap (prologue + blind rotate + extract), one wave per bit
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_bootstrap(BrLaunch P)
+{
+    load_tables(P.tw1f, P.tw1i);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long gbit = (long)blockIdx.x * BR_WAVES_PER_BLOCK + wave;
+    if (gbit >= P.nbits_total) return;
+    const int job = gbit >= P.bits_per_job ? 1 : 0;
+    const long bit = gbit - (job ? P.bits_per_job : 0);
+
+    const BrLds lds = carve_br_lds(wave);
+    const NttLane L = ntt_lane_init(lane);
+    const u32 barb = br_prologue(P.job[job].s0, P.job[job].s1, P.job[job].c0, bit, P.n, lds, lane);
+    WAVE_SYNC();
+    u32 acc[2][16];
+    br_blind_rotate(acc, P.bk, P.n, barb, P.mu, lds, L);
+    br_extract(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, acc, lane);
+}
+
+// Test hook / multi-kernel-style entry: blind rotate (or a single external product) on
+// accumulators held in global memory: accum int32 [batch][2][1024]
+__global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_blind_rotate_accum(
+    i32 *__restrict__ accum, const u64 *__restrict__ bk, const i32 *__restrict__ bara, long bara_stride,
+    int row0, int n_rows, int external_mul_only, long batch, const u64 *__restrict__ tw1f,
+    const u64 *__restrict__ tw1i)
+{
+    load_tables(tw1f, tw1i);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long bit = (long)blockIdx.x * BR_WAVES_PER_BLOCK + wave;
+    if (bit >= batch) return;
+    const BrLds lds = carve_br_lds(wave);
+    const NttLane L = ntt_lane_init(lane);
+    i32 *my = accum + bit * 2048;
+    u32 acc[2][16];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            acc[m][r] = (u32)my[m * 1024 + lane + 64 * r];
+            lds.acc[m * 1024 + lane + 64 * r] = (i32)acc[m][r];
+        }
+    WAVE_SYNC();
+    if (external_mul_only) {
+        u64 sum[2][16];
+        br_external_product(
+            sum,
+            [&](int m, u32(&T)[16]) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) T[r] = acc[m][r];
+            },
+            bk + (long)row0 * BK_ROW_ELEMS, lds, L);
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][r] = (u32)ff_to_i32(sum[m][r]);
+    } else {
+        for (int i = 0; i < n_rows; i++) {
+            const u32 a = WAVE_UNIFORM((u32)bara[bit * bara_stride + i]) & 2047u;
+            if (a == 0) continue;
+            br_step(acc, a, bk + (long)(row0 + i) * BK_ROW_ELEMS, lds, L);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) my[m * 1024 + lane + 64 * r] = (i32)acc[m][r];
+}
+
+// ------------------------------------------------------------------------------------------
+// K3/K4: standalone batched transforms, natural order, one wave per polynomial
+// ------------------------------------------------------------------------------------------
+#define NTT_BLOCK_THREADS 256
+#define NTT_WAVES_PER_BLOCK 4
+
+__device__ __forceinline__ u64 *carve_ntt_xbuf(int wave)
+{
+    return (u64 *)(g_smem + TABLE_LDS_BYTES + wave * WAVE_XBUF_BYTES);
+}
+
+// mode: 0 = i32 in (forward) / i32 out (inverse); 1 = u64 field elements
+template <int MODE>
+__global__ __launch_bounds__(NTT_BLOCK_THREADS) void k_ntt_forward(u64 *__restrict__ out, const void *__restrict__ in,
+                                                                   long batch, const u64 *__restrict__ tw1f,
+                                                                   const u64 *__restrict__ tw1i)
+{
+    load_tables(tw1f, tw1i);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long p = (long)blockIdx.x * NTT_WAVES_PER_BLOCK + wave;
+    if (p >= batch) return;
+    const NttLane L = ntt_lane_init(lane);
+    u64 x[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const long idx = p * 1024 + ntt_coef_index(lane, r);
+        x[r] = MODE == 0 ? ff_from_i32(((const i32 *)in)[idx]) : ff_canon(((const u64 *)in)[idx]);
+    }
+    ntt_forward(x, carve_ntt_xbuf(wave), (const u64 *)g_smem, L);
+#pragma unroll
+    for (int r = 0; r < 16; r++) out[p * 1024 + ntt_freq_index(lane, r)] = x[r];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(NTT_BLOCK_THREADS) void k_ntt_inverse(void *__restrict__ out, const u64 *__restrict__ in,
+                                                                   long batch, const u64 *__restrict__ tw1f,
+                                                                   const u64 *__restrict__ tw1i)
+{
+    load_tables(tw1f, tw1i);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long p = (long)blockIdx.x * NTT_WAVES_PER_BLOCK + wave;
+    if (p >= batch) return;
+    const NttLane L = ntt_lane_init(lane);
+    u64 x[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[r] = ff_canon(in[p * 1024 + ntt_freq_index(lane, r)]);
+    ntt_inverse(x, carve_ntt_xbuf(wave), (const u64 *)g_smem + 1024, L);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const long idx = p * 1024 + ntt_coef_index(lane, r);
+        if (MODE == 0) ((i32 *)out)[idx] = ff_to_i32(x[r]);
+        else ((u64 *)out)[idx] = x[r];
+    }
+}
+
+// Negacyclic product of int32 polynomials mod 2^32: out[b] = x[b] * y[b % y_batch]
+// ADD_TO: out = base + product (used by TLweEncryptZero: b = noise + a * s, tlwe_cpu.py:76-84)
+__global__ __launch_bounds__(NTT_BLOCK_THREADS) void k_poly_mul(i32 *__restrict__ out, const i32 *__restrict__ x,
+                                                                const i32 *__restrict__ y, const i32 *__restrict__ base,
+                                                                long out_stride, long batch, long y_batch,
+                                                                const u64 *__restrict__ tw1f,
+                                                                const u64 *__restrict__ tw1i)
+{
+    load_tables(tw1f, tw1i);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long p = (long)blockIdx.x * NTT_WAVES_PER_BLOCK + wave;
+    if (p >= batch) return;
+    const NttLane L = ntt_lane_init(lane);
+    u64 *xbuf = carve_ntt_xbuf(wave);
+    u64 fx[16], fy[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        fx[r] = ff_from_i32(x[p * 1024 + ntt_coef_index(lane, r)]);
+        fy[r] = ff_from_i32(y[(p % y_batch) * 1024 + ntt_coef_index(lane, r)]);
+    }
+    ntt_forward(fx, xbuf, (const u64 *)g_smem, L);
+    ntt_forward(fy, xbuf, (const u64 *)g_smem, L);
+#pragma unroll
+    for (int r = 0; r < 16; r++) fx[r] = ff_mul(fx[r], fy[r]);
+    ntt_inverse(fx, xbuf, (const u64 *)g_smem + 1024, L);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int j = ntt_coef_index(lane, r);
+        u32 v = (u32)ff_to_i32(fx[r]);
+        if (base) v += (u32)base[p * 1024 + j];
+        out[p * out_stride + j] = (i32)v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Bootstrapping-key format conversion
+// ------------------------------------------------------------------------------------------
+// reference format (natural-order NTT, Montgomery: x * 2^64) -> wave layout, plain residues
+__global__ void k_bk_from_reference(u64 *__restrict__ out, const u64 *__restrict__ in, long polys)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= polys * 1024) return;
+    const long p = t >> 10;
+    const int e = (int)(t & 1023), lane = e & 63, reg = e >> 6;
+    out[p * 1024 + bk_elem_offset(lane, reg)] = ff_mul_pow2<128>(ff_canon(in[p * 1024 + ntt_freq_index(lane, reg)]));
+}
+
+__global__ void k_bk_to_reference(u64 *__restrict__ out, const u64 *__restrict__ in, long polys)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= polys * 1024) return;
+    const long p = t >> 10;
+    const int e = (int)(t & 1023), lane = e & 63, reg = e >> 6;
+    out[p * 1024 + ntt_freq_index(lane, reg)] = ff_mul_pow2<64>(in[p * 1024 + bk_elem_offset(lane, reg)]);
+}
+
+// coefficient-domain TGSW polynomials (int32) -> wave layout (forward NTT only; no Montgomery)
+__global__ __launch_bounds__(NTT_BLOCK_THREADS) void k_bk_from_coeffs(u64 *__restrict__ out, const i32 *__restrict__ in,
+                                                                      long polys, const u64 *__restrict__ tw1f,
+                                                                      const u64 *__restrict__ tw1i)
+{
+    load_tables(tw1f, tw1i);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long p = (long)blockIdx.x * NTT_WAVES_PER_BLOCK + wave;
+    if (p >= polys) return;
+    const NttLane L = ntt_lane_init(lane);
+    u64 x[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[r] = ff_from_i32(in[p * 1024 + ntt_coef_index(lane, r)]);
+    ntt_forward(x, carve_ntt_xbuf(wave), (const u64 *)g_smem, L);
+#pragma unroll
+    for (int r = 0; r < 16; r++) out[p * 1024 + bk_elem_offset(lane, r)] = x[r];
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: LWE keyswitch (lwe_gpu.mako:59-120, lwe_cpu.py:62-93)
+//   out_a[bit][c] = - sum_{j < 1024, k < 8} KS_a[j][k][digit_jk(src_a[bit][j])][c]
+// A block owns KS_TILE_BITS bits x all columns for one slice of j: the three non-zero key rows of
+// every (j, k) are loaded ONCE per block (coalesced over columns) and each bit picks its row by its
+// wave-uniform digit; per-thread accumulators stay in registers.  j-slices combine with integer
+// atomics (order independent => bit-exact).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(KS_BLOCK_THREADS) void k_keyswitch_a(KsLaunch P)
+{
+    const int tid = threadIdx.x;
+    const long bit0 = (long)blockIdx.x * KS_TILE_BITS;
+    const int j0 = blockIdx.y * P.j_per_block;
+    const int c0 = tid, c1 = tid + KS_BLOCK_THREADS;
+    const bool v0 = c0 < P.n, v1 = c1 < P.n;
+    const int nb = (int)((P.nbits - bit0) < KS_TILE_BITS ? (P.nbits - bit0) : KS_TILE_BITS);
+
+    u32 acc0[KS_TILE_BITS], acc1[KS_TILE_BITS];
+#pragma unroll
+    for (int t = 0; t < KS_TILE_BITS; t++) { acc0[t] = 0; acc1[t] = 0; }
+
+    for (int j = j0; j < j0 + P.j_per_block; j++) {
+        // source coefficients of this tile's bits: wave-uniform values
+        u32 aj[KS_TILE_BITS];
+#pragma unroll
+        for (int t = 0; t < KS_TILE_BITS; t++) {
+            u32 v = 0;
+            if (t < nb) {
+                v = (u32)P.src1_a[(bit0 + t) * P.src1_stride + j];
+                if (P.src2_a) v += (u32)P.src2_a[(bit0 + t) * P.src2_stride + j];
+            }
+            aj[t] = WAVE_UNIFORM(v) + (1u << 15);   // + prec_offset, lwe_cpu.py:70
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const i32 *rows = P.ks_a3 + ((long)(j * 8 + k) * 3) * P.n;
+            const u32 r10 = v0 ? (u32)rows[c0] : 0, r20 = v0 ? (u32)rows[P.n + c0] : 0,
+                      r30 = v0 ? (u32)rows[2 * P.n + c0] : 0;
+            const u32 r11 = v1 ? (u32)rows[c1] : 0, r21 = v1 ? (u32)rows[P.n + c1] : 0,
+                      r31 = v1 ? (u32)rows[2 * P.n + c1] : 0;
+#pragma unroll
+            for (int t = 0; t < KS_TILE_BITS; t++) {
+                const u32 dg = (aj[t] >> (30 - 2 * k)) & 3u;   // lwe_cpu.py:76 (arithmetic == logical after & 3)
+                const u32 m1 = dg == 1u ? ~0u : 0u, m2 = dg == 2u ? ~0u : 0u, m3 = dg == 3u ? ~0u : 0u;
+                acc0[t] -= (r10 & m1) | (r20 & m2) | (r30 & m3);
+                acc1[t] -= (r11 & m1) | (r21 & m2) | (r31 & m3);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < KS_TILE_BITS; t++) {
+        if (t < nb) {
+            if (v0) atomicAdd(&P.acc[(bit0 + t) * P.n + c0], acc0[t]);
+            if (v1) atomicAdd(&P.acc[(bit0 + t) * P.n + c1], acc1[t]);
+        }
+    }
+}
+
+// finalize: copy the accumulated mask into the result view, and compute b and the variance with
+// the reference's sequential (j, k) order (float sum order matters): lwe_cpu.py:80-92
+__global__ __launch_bounds__(256) void k_keyswitch_finalize(KsFinal P)
+{
+    const long bit = blockIdx.x;
+    for (int c = threadIdx.x; c < P.n; c += blockDim.x)
+        P.out_a[bit * P.out_a_stride + c] = (i32)P.acc[bit * P.n + c];
+    if (threadIdx.x == 0) {
+        u32 b = (u32)P.c0 + (u32)P.src1_b[bit * P.src1_bstride];
+        if (P.src2_b) b += (u32)P.src2_b[bit * P.src2_bstride];
+        float cv = 0.0f;
+        for (int j = 0; j < 1024; j++) {
+            u32 a = (u32)P.src1_a[bit * P.src1_stride + j];
+            if (P.src2_a) a += (u32)P.src2_a[bit * P.src2_stride + j];
+            a += 1u << 15;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const u32 dg = (a >> (30 - 2 * k)) & 3u;
+                const int idx = (j * 8 + k) * 4 + (int)dg;
+                b -= (u32)P.ks_b[idx];
+                cv += P.ks_cv[idx];
+            }
+        }
+        P.out_b[bit * P.out_b_stride] = (i32)b;
+        if (P.out_cv) P.out_cv[bit * P.out_b_stride] = cv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Small element-wise kernels
+// ------------------------------------------------------------------------------------------
+// LweLinear, lwe_gpu.mako:123-169 / lwe_cpu.py:115-123
+__global__ void k_lwe_linear(LweView res, LweView src, i32 p, int add_result, long nbits, int size)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nbits * (size + 1)) return;
+    const long bit = t / (size + 1);
+    const int i = (int)(t - bit * (size + 1));
+    if (i < size) {
+        const u32 v = (u32)p * (u32)src.a[bit * src.a_stride + i];
+        i32 *r = &res.a[bit * res.a_stride + i];
+        *r = (i32)((add_result ? (u32)*r : 0u) + v);
+    } else {
+        const u32 v = (u32)p * (u32)src.b[bit * src.b_stride];
+        i32 *r = &res.b[bit * res.b_stride];
+        *r = (i32)((add_result ? (u32)*r : 0u) + v);
+        if (res.cv) {
+            const float sv = src.cv ? src.cv[bit * src.b_stride] : 0.0f;
+            float *c = &res.cv[bit * res.b_stride];
+            *c = (add_result ? *c : 0.0f) + (float)((long)p * p) * sv;
+        }
+    }
+}
+
+// LweNoiselessTrivialConstant, lwe_cpu.py:136-143
+__global__ void k_lwe_trivial_const(LweView res, i32 mu, long nbits, int size)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nbits * (size + 1)) return;
+    const long bit = t / (size + 1);
+    const int i = (int)(t - bit * (size + 1));
+    if (i < size) res.a[bit * res.a_stride + i] = 0;
+    else {
+        res.b[bit * res.b_stride] = mu;
+        if (res.cv) res.cv[bit * res.b_stride] = 0.0f;
+    }
+}
+
+// Torus32ToPhase, numeric_functions_cpu.py:23-37
+__global__ void k_t32_to_phase(i32 *__restrict__ result, const i32 *__restrict__ phase, long count, u32 interv)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    result[t] = (i32)(((u32)phase[t] + interv / 2) / interv);
+}
+
+// ShiftTorusPolynomial, polynomials_cpu.py:25-59 (N = 1024)
+__global__ void k_shift_tp(i32 *__restrict__ result, const i32 *__restrict__ source, const i32 *__restrict__ powers,
+                           long powers_stride, long powers_idx, long batch, int polys, int minus_one,
+                           int invert_powers)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch * polys * 1024) return;
+    const long b = t / ((long)polys * 1024);
+    const u32 j = (u32)(t & 1023);
+    u32 pw = (u32)powers[b * powers_stride + powers_idx];
+    if (invert_powers) pw = 2048u - pw;
+    const u32 s = (j - pw) & 2047u;
+    const long base = t - j;
+    const u32 v = (u32)source[base + (s & 1023u)];
+    u32 r = (s & 1024u) ? 0u - v : v;
+    if (minus_one) r -= (u32)source[t];
+    result[t] = (i32)r;
+}
+
+// tlwe_extract_lwe_samples (k = 1), tlwe_cpu.py:41-60
+__global__ void k_tlwe_extract(i32 *__restrict__ ra, i32 *__restrict__ rb, const i32 *__restrict__ tlwe, long batch)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch * 1024) return;
+    const long b = t >> 10;
+    const int j = (int)(t & 1023);
+    const i32 *A = tlwe + b * 2048;
+    ra[t] = j == 0 ? A[0] : (i32)(0u - (u32)A[1024 - j]);
+    if (j == 0) rb[b] = A[1024];
+}
+
+// ------------------------------------------------------------------------------------------
+// Host launchers
+// ------------------------------------------------------------------------------------------
+static inline unsigned blocks_for(long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+static const size_t kBrLds = TABLE_LDS_BYTES + (size_t)BR_WAVES_PER_BLOCK * WAVE_BR_LDS_BYTES;
+
+// per-device one-time setup: the fused kernels use 156 KiB of dynamic LDS (> the 64 KiB default cap)
+hipError_t kernels_init_device()
+{
+    hipError_t e = hipFuncSetAttribute((const void *)k_bootstrap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrLds);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void *)k_blind_rotate_accum, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrLds);
+}
+
+hipError_t launch_bootstrap(const BrLaunch &P, hipStream_t stream)
+{
+    if (P.nbits_total == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_bootstrap, dim3(blocks_for(P.nbits_total, BR_WAVES_PER_BLOCK)), dim3(BR_BLOCK_THREADS),
+                       kBrLds, stream, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_blind_rotate_accum(i32 *accum, const u64 *bk, const i32 *bara, long bara_stride, int row0,
+                                     int n_rows, int external_mul_only, long batch, const u64 *tw1f,
+                                     const u64 *tw1i, hipStream_t stream)
+{
+    if (batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_blind_rotate_accum, dim3(blocks_for(batch, BR_WAVES_PER_BLOCK)), dim3(BR_BLOCK_THREADS),
+                       kBrLds, stream, accum, bk, bara, bara_stride, row0, n_rows, external_mul_only, batch, tw1f,
+                       tw1i);
+    return hipGetLastError();
+}
+
+static const size_t kNttLds = TABLE_LDS_BYTES + (size_t)NTT_WAVES_PER_BLOCK * WAVE_XBUF_BYTES;
+
+hipError_t launch_ntt_forward(u64 *out, const void *in, int mode, long batch, const u64 *tw1f, const u64 *tw1i,
+                              hipStream_t stream)
+{
+    if (batch == 0) return hipSuccess;
+    const dim3 grid(blocks_for(batch, NTT_WAVES_PER_BLOCK)), block(NTT_BLOCK_THREADS);
+    if (mode == 0) hipLaunchKernelGGL(k_ntt_forward<0>, grid, block, kNttLds, stream, out, in, batch, tw1f, tw1i);
+    else hipLaunchKernelGGL(k_ntt_forward<1>, grid, block, kNttLds, stream, out, in, batch, tw1f, tw1i);
+    return hipGetLastError();
+}
+
+hipError_t launch_ntt_inverse(void *out, const u64 *in, int mode, long batch, const u64 *tw1f, const u64 *tw1i,
+                              hipStream_t stream)
+{
+    if (batch == 0) return hipSuccess;
+    const dim3 grid(blocks_for(batch, NTT_WAVES_PER_BLOCK)), block(NTT_BLOCK_THREADS);
+    if (mode == 0) hipLaunchKernelGGL(k_ntt_inverse<0>, grid, block, kNttLds, stream, out, in, batch, tw1f, tw1i);
+    else hipLaunchKernelGGL(k_ntt_inverse<1>, grid, block, kNttLds, stream, out, in, batch, tw1f, tw1i);
+    return hipGetLastError();
+}
+
+hipError_t launch_poly_mul(i32 *out, const i32 *x, const i32 *y, const i32 *base, long out_stride, long batch,
+                           long y_batch, const u64 *tw1f, const u64 *tw1i, hipStream_t stream)
+{
+    if (batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_poly_mul, dim3(blocks_for(batch, NTT_WAVES_PER_BLOCK)), dim3(NTT_BLOCK_THREADS), kNttLds,
+                       stream, out, x, y, base, out_stride, batch, y_batch, tw1f, tw1i);
+    return hipGetLastError();
+}
+
+hipError_t launch_bk_from_reference(u64 *out, const u64 *in, long polys, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_bk_from_reference, dim3(blocks_for(polys * 1024, 256)), dim3(256), 0, stream, out, in, polys);
+    return hipGetLastError();
+}
+
+hipError_t launch_bk_to_reference(u64 *out, const u64 *in, long polys, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_bk_to_reference, dim3(blocks_for(polys * 1024, 256)), dim3(256), 0, stream, out, in, polys);
+    return hipGetLastError();
+}
+
+hipError_t launch_bk_from_coeffs(u64 *out, const i32 *in, long polys, const u64 *tw1f, const u64 *tw1i,
+                                 hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_bk_from_coeffs, dim3(blocks_for(polys, NTT_WAVES_PER_BLOCK)), dim3(NTT_BLOCK_THREADS),
+                       kNttLds, stream, out, in, polys, tw1f, tw1i);
+    return hipGetLastError();
+}
+
+hipError_t launch_keyswitch(const KsLaunch &P, const KsFinal &F, hipStream_t stream)
+{
+    if (P.nbits == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(P.acc, 0, (size_t)P.nbits * P.n * sizeof(u32), stream);
+    if (e != hipSuccess) return e;
+    const dim3 grid(blocks_for(P.nbits, KS_TILE_BITS), 1024 / P.j_per_block);
+    hipLaunchKernelGGL(k_keyswitch_a, grid, dim3(KS_BLOCK_THREADS), 0, stream, P);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_keyswitch_finalize, dim3((unsigned)P.nbits), dim3(256), 0, stream, F);
+    return hipGetLastError();
+}
+
+hipError_t launch_lwe_linear(const LweView &res, const LweView &src, i32 p, int add_result, long nbits, int size,
+                             hipStream_t stream)
+{
+    if (nbits == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_lwe_linear, dim3(blocks_for(nbits * (size + 1), 256)), dim3(256), 0, stream, res, src, p,
+                       add_result, nbits, size);
+    return hipGetLastError();
+}
+
+hipError_t launch_lwe_trivial_const(const LweView &res, i32 mu, long nbits, int size, hipStream_t stream)
+{
+    if (nbits == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_lwe_trivial_const, dim3(blocks_for(nbits * (size + 1), 256)), dim3(256), 0, stream, res, mu,
+                       nbits, size);
+    return hipGetLastError();
+}
+
+hipError_t launch_t32_to_phase(i32 *result, const i32 *phase, long count, u32 mspace, hipStream_t stream)
+{
+    if (count == 0) return hipSuccess;
+    const u32 interv = (u32)((1ULL << 32) / mspace);
+    hipLaunchKernelGGL(k_t32_to_phase, dim3(blocks_for(count, 256)), dim3(256), 0, stream, result, phase, count, interv);
+    return hipGetLastError();
+}
+
+hipError_t launch_shift_tp(i32 *result, const i32 *source, const i32 *powers, long powers_stride, long powers_idx,
+                           long batch, int polys, int minus_one, int invert_powers, hipStream_t stream)
+{
+    if (batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_shift_tp, dim3(blocks_for(batch * polys * 1024, 256)), dim3(256), 0, stream, result, source,
+                       powers, powers_stride, powers_idx, batch, polys, minus_one, invert_powers);
+    return hipGetLastError();
+}
+
+hipError_t launch_tlwe_extract(i32 *ra, i32 *rb, const i32 *tlwe, long batch, hipStream_t stream)
+{
+    if (batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tlwe_extract, dim3(blocks_for(batch * 1024, 256)), dim3(256), 0, stream, ra, rb, tlwe, batch);
+    return hipGetLastError();
+}

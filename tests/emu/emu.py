@@ -1,0 +1,79 @@
+"""ctypes loader of the CPU emulation of the wave-level device code (tests only)."""
+import ctypes
+import os
+import subprocess
+
+import numpy
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+c_u64p = ctypes.POINTER(ctypes.c_uint64)
+c_u32p = ctypes.POINTER(ctypes.c_uint32)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "libnufhe_emu.so"])
+        _lib = ctypes.CDLL(os.path.join(_HERE, "libnufhe_emu.so"))
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def ff_binary(name, a, b):
+    a = numpy.ascontiguousarray(a, numpy.uint64); b = numpy.ascontiguousarray(b, numpy.uint64)
+    r = numpy.empty_like(a)
+    getattr(lib(), name)(_p(r, c_u64p), _p(a, c_u64p), _p(b, c_u64p), ctypes.c_long(a.size))
+    return r
+
+
+def ff_lsh_const(a, s):
+    a = numpy.ascontiguousarray(a, numpy.uint64)
+    r = numpy.empty_like(a)
+    lib().emu_ff_lsh_const(_p(r, c_u64p), _p(a, c_u64p), ctypes.c_int(s), ctypes.c_long(a.size))
+    return r
+
+
+def ff_lsh_var(a, s):
+    a = numpy.ascontiguousarray(a, numpy.uint64); s = numpy.ascontiguousarray(s, numpy.uint32)
+    r = numpy.empty_like(a)
+    lib().emu_ff_lsh_var(_p(r, c_u64p), _p(a, c_u64p), _p(s, c_u32p), ctypes.c_long(a.size))
+    return r
+
+
+def ntt_forward(x):
+    x = numpy.ascontiguousarray(x, numpy.uint64)
+    r = numpy.empty_like(x)
+    lib().emu_ntt_forward(_p(r, c_u64p), _p(x, c_u64p))
+    return r
+
+
+def ntt_inverse(x):
+    x = numpy.ascontiguousarray(x, numpy.uint64)
+    r = numpy.empty_like(x)
+    lib().emu_ntt_inverse(_p(r, c_u64p), _p(x, c_u64p))
+    return r
+
+
+def bk_from_reference(bk):
+    bk = numpy.ascontiguousarray(bk, numpy.uint64)
+    out = numpy.empty_like(bk)
+    lib().emu_bk_from_reference(_p(out, c_u64p), _p(bk, c_u64p), ctypes.c_long(bk.size // 1024))
+    return out
+
+
+def bootstrap_bit(bk_internal, n, src0, p0, src1, p1, c0, mu):
+    """src = (a [n], b scalar array [1]); returns (ext_a [1024], ext_b)."""
+    a0 = numpy.ascontiguousarray(src0[0], numpy.int32); b0 = numpy.ascontiguousarray(src0[1], numpy.int32).reshape(1)
+    a1 = numpy.ascontiguousarray(src1[0], numpy.int32); b1 = numpy.ascontiguousarray(src1[1], numpy.int32).reshape(1)
+    out_a = numpy.empty(1024, numpy.int32); out_b = numpy.empty(1, numpy.int32)
+    lib().emu_bootstrap_bit(_p(out_a, c_i32p), _p(out_b, c_i32p), _p(bk_internal, c_u64p), ctypes.c_int(n),
+                            _p(a0, c_i32p), _p(b0, c_i32p), ctypes.c_int32(p0),
+                            _p(a1, c_i32p), _p(b1, c_i32p), ctypes.c_int32(p1),
+                            ctypes.c_int32(c0), ctypes.c_int32(mu))
+    return out_a, out_b[0]

@@ -1,0 +1,102 @@
+// emu_kernels.cpp -- TEST INFRASTRUCTURE: C entry points that run the wave-level device code of
+// nufhe_amd/csrc/*.h on the CPU through the fibre emulator (tests/emu/emu_wave.*), so that the
+// index math / arithmetic of the HIP kernels can be checked against the oracle without a GPU.
+#include <cstring>
+#include <vector>
+
+#define NUFHE_EMU 1
+#include "../../nufhe_amd/csrc/ff.h"
+#include "../../nufhe_amd/csrc/ntt1024.h"
+#include "../../nufhe_amd/csrc/ntt_tables.h"
+#include "../../nufhe_amd/csrc/blind_rotate.h"
+#include "emu_wave.h"
+
+static u64 g_tw1f[1024], g_tw1i[1024];
+static bool g_tables = false;
+static void tables()
+{
+    if (!g_tables) { ntt_make_tables(g_tw1f, g_tw1i); g_tables = true; }
+}
+
+template <int S> static void lsh_all(u64 *r, const u64 *a, long n) { for (long i = 0; i < n; i++) r[i] = ff_mul_pow2<S>(a[i]); }
+template <int S> struct LshTable {
+    static void fill(void (**t)(u64 *, const u64 *, long)) { t[S] = lsh_all<S>; LshTable<S - 1>::fill(t); }
+};
+template <> struct LshTable<-1> { static void fill(void (**)(u64 *, const u64 *, long)) {} };
+
+extern "C" {
+
+// ff primitives (host build of the same inline functions the GPU uses)
+void emu_ff_add(u64 *r, const u64 *a, const u64 *b, long n) { for (long i = 0; i < n; i++) r[i] = ff_add(a[i], b[i]); }
+void emu_ff_sub(u64 *r, const u64 *a, const u64 *b, long n) { for (long i = 0; i < n; i++) r[i] = ff_sub(a[i], b[i]); }
+void emu_ff_mul(u64 *r, const u64 *a, const u64 *b, long n) { for (long i = 0; i < n; i++) r[i] = ff_mul(a[i], b[i]); }
+void emu_ff_lsh_var(u64 *r, const u64 *a, const u32 *s, long n) { for (long i = 0; i < n; i++) r[i] = ff_mul_pow2_var(a[i], s[i]); }
+
+// r = a * 2^s for every compile-time instantiation s in [0,192)
+void emu_ff_lsh_const(u64 *r, const u64 *a, int s, long n)
+{
+    static void (*table[192])(u64 *, const u64 *, long);
+    static bool init = false;
+    if (!init) { LshTable<191>::fill(table); init = true; }
+    table[s](r, a, n);
+}
+
+// forward NTT of one polynomial of canonical field elements; out in natural frequency order
+void emu_ntt_forward(u64 *out, const u64 *in)
+{
+    tables();
+    std::vector<u64> xbuf(NTT_XBUF_ELEMS);
+    emu_run_wave([&](int lane) {
+        NttLane L = ntt_lane_init(lane);
+        u64 x[16];
+        for (int r = 0; r < 16; r++) x[r] = in[ntt_coef_index(lane, r)];
+        ntt_forward(x, xbuf.data(), g_tw1f, L);
+        for (int r = 0; r < 16; r++) out[ntt_freq_index(lane, r)] = x[r];
+    });
+}
+
+void emu_ntt_inverse(u64 *out, const u64 *in)
+{
+    tables();
+    std::vector<u64> xbuf(NTT_XBUF_ELEMS);
+    emu_run_wave([&](int lane) {
+        NttLane L = ntt_lane_init(lane);
+        u64 x[16];
+        for (int r = 0; r < 16; r++) x[r] = in[ntt_freq_index(lane, r)];
+        ntt_inverse(x, xbuf.data(), g_tw1i, L);
+        for (int r = 0; r < 16; r++) out[ntt_coef_index(lane, r)] = x[r];
+    });
+}
+
+
+// reference-format key polynomials (natural-order NTT, Montgomery) -> wave layout, plain
+void emu_bk_from_reference(u64 *out, const u64 *in, long polys)
+{
+    for (long p = 0; p < polys; p++)
+        for (int lane = 0; lane < 64; lane++)
+            for (int r = 0; r < 16; r++)
+                out[p * 1024 + bk_elem_offset(lane, r)] = ff_mul_pow2<128>(in[p * 1024 + ntt_freq_index(lane, r)]);
+}
+
+// one bit: tmp = (0, c0) + p0 * src0 + p1 * src1 -> bootstrap without keyswitch
+void emu_bootstrap_bit(i32 *out_a, i32 *out_b, const u64 *bk_internal, int n,
+                       const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,
+                       i32 c0, i32 mu)
+{
+    tables();
+    std::vector<u64> xbuf(NTT_XBUF_ELEMS);
+    std::vector<i32> accbuf(2048);
+    std::vector<uint16_t> bara(BR_MAX_LWE);
+    BrLds lds{xbuf.data(), accbuf.data(), bara.data(), g_tw1f, g_tw1i};
+    BrSource s0{a0, b0, 0, 0, p0}, s1{a1, b1, 0, 0, p1};
+    emu_run_wave([&](int lane) {
+        NttLane L = ntt_lane_init(lane);
+        u32 barb = br_prologue(s0, s1, c0, 0, n, lds, lane);
+        WAVE_SYNC();
+        u32 acc[2][16];
+        br_blind_rotate(acc, bk_internal, n, barb, mu, lds, L);
+        br_extract(out_a, out_b, acc, lane);
+    });
+}
+
+}  // extern "C"

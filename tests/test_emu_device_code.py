@@ -1,0 +1,102 @@
+"""
+CPU checks of the DEVICE code (nufhe_amd/csrc/ff.h, ntt1024.h, ...) compiled for the host and
+run lane-by-lane through the fibre emulator in tests/emu/ -- compared with the oracle.  These
+tests validate the arithmetic formulations and the index math of the HIP kernels without a GPU;
+the GPU parity tests proper are in tests/test_gpu_*.py.
+"""
+
+import numpy
+import pytest
+
+from tests.emu import emu
+
+P = 2**64 - 2**32 + 1
+
+
+def _edge_values():
+    return [0, 1, 2, 2**31, 2**32 - 1, 2**32, 2**32 + 1, 2**63, P - 1, P - 2, P - 2**32, P - 2**32 - 1,
+            2**64 - 2**33, 0xFFFFFFFE00000000, 0xFFFFFFFEFFFFFFFF, 0x00000000FFFFFFFF, 0xFFFFFFFF00000000]
+
+
+def _ff_inputs(n=4000, seed=11):
+    rs = numpy.random.RandomState(seed)
+    a = rs.randint(0, P, size=n, dtype=numpy.uint64)
+    b = rs.randint(0, P, size=n, dtype=numpy.uint64)
+    ev = _edge_values()
+    k = 0
+    for x in ev:
+        for y in ev:
+            a[k] = x; b[k] = y; k += 1
+    return a, b
+
+
+def test_ff_add_sub_mul(orc):
+    a, b = _ff_inputs()
+    assert (emu.ff_binary('emu_ff_add', a, b) == orc.ff_add(a, b)).all()
+    assert (emu.ff_binary('emu_ff_sub', a, b) == orc.ff_sub(a, b)).all()
+    assert (emu.ff_binary('emu_ff_mul', a, b) == orc.ff_mul(a, b)).all()
+
+
+def test_ff_shifts(orc):
+    a, _ = _ff_inputs(1000, seed=12)
+    for s in range(192):
+        exp = orc.ff_lsh(a, numpy.full(a.shape, s, numpy.uint32))
+        assert (emu.ff_lsh_const(a, s) == exp).all(), s
+    rs = numpy.random.RandomState(13)
+    s = rs.randint(0, 32, size=a.size).astype(numpy.uint32)
+    s[:4] = [0, 31, 1, 30]
+    assert (emu.ff_lsh_var(a, s) == orc.ff_lsh(a, s)).all()
+
+
+def test_ntt_forward_inverse(orc):
+    rs = numpy.random.RandomState(14)
+    for case in range(3):
+        if case == 0:
+            x = rs.randint(0, P, size=1024, dtype=numpy.uint64)
+        elif case == 1:
+            x = numpy.zeros(1024, numpy.uint64); x[1] = 1
+        else:
+            x = orc.ff_from_i32(rs.randint(-512, 512, size=1024).astype(numpy.int32))
+        f = emu.ntt_forward(x)
+        assert (f == orc.ntt_forward(x[None, :], i32_conversion=False)[0]).all()
+        assert (emu.ntt_inverse(f) == x).all()
+        y = rs.randint(0, P, size=1024, dtype=numpy.uint64)
+        assert (emu.ntt_inverse(y) == orc.ntt_inverse(y[None, :], i32_conversion=False)[0]).all()
+
+
+def test_bootstrap_wave_body_reduced(orc):
+    """The fused blind-rotate body (device code, emulated) == oracle bootstrap_extract, on a
+    random transformed-domain key with a few rows (incl. bara = 0 and bara >= N cases)."""
+    rs = numpy.random.RandomState(21)
+    n = 6
+    bk = rs.randint(0, P, size=(n, 2, 2, 2, 1024), dtype=numpy.uint64)
+    bki = emu.bk_from_reference(bk)
+    MU = 2**29
+    for trial in range(2):
+        a0 = rs.randint(-2**31, 2**31, size=n, dtype=numpy.int32)
+        a1 = rs.randint(-2**31, 2**31, size=n, dtype=numpy.int32)
+        b0 = rs.randint(-2**31, 2**31, size=1, dtype=numpy.int32)
+        b1 = rs.randint(-2**31, 2**31, size=1, dtype=numpy.int32)
+        if trial == 1:
+            a0[2] = 0; a1[2] = 0          # bara = 0 -> skipped iteration
+        ta = (-a0 - a1).astype(numpy.int32)
+        tb = (numpy.int32(MU) - b0 - b1).astype(numpy.int32)
+        ea, eb = orc.bootstrap_extract(bk, ta[None, :], tb, MU)
+        ga, gb = emu.bootstrap_bit(bki, n, (a0, b0), -1, (a1, b1), -1, MU, MU)
+        assert (ga == ea[0]).all()
+        assert gb == eb[0]
+
+
+@pytest.mark.slow
+def test_bootstrap_wave_body_full_key(orc, oracle_keys):
+    """Full-size key (n = 500), one bit, NAND pre-combination: device code == oracle."""
+    lwe_key, tlwe_key, ck = oracle_keys
+    rng = orc.DeterministicRNG(456)
+    m1 = numpy.array([True]); m2 = numpy.array([True])
+    c1 = orc.encrypt(rng, lwe_key, m1); c2 = orc.encrypt(rng, lwe_key, m2)
+    MU = 2**29
+    ta = (-c1[0] - c2[0]).astype(numpy.int32); tb = (numpy.int32(MU) - c1[1] - c2[1]).astype(numpy.int32)
+    ea, eb = orc.bootstrap_extract(ck.bk, ta, tb, MU)
+    bki = emu.bk_from_reference(ck.bk)
+    ga, gb = emu.bootstrap_bit(bki, 500, (c1[0][0], c1[1]), -1, (c2[0][0], c2[1]), -1, MU, MU)
+    assert (ga == ea[0]).all() and gb == eb[0]
