@@ -1,0 +1,112 @@
+"""
+ctypes binding of libnufhe_hip.so (the C ABI of include/nufhe_hip.h).
+
+There is NO fallback: if the shared library is missing or fails to load, importing this module's
+``lib()`` raises -- the product path never routes through a CPU implementation.
+"""
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnufhe_hip.so")
+
+
+class NufheError(RuntimeError):
+    pass
+
+
+class NufheLwe(ctypes.Structure):
+    """nufhe_lwe of include/nufhe_hip.h"""
+    _fields_ = [
+        ("a", ctypes.c_void_p),
+        ("b", ctypes.c_void_p),
+        ("cv", ctypes.c_void_p),
+        ("a_stride", ctypes.c_long),
+        ("b_stride", ctypes.c_long),
+    ]
+
+
+_vp = ctypes.c_void_p
+_i32 = ctypes.c_int32
+_int = ctypes.c_int
+_long = ctypes.c_long
+_pp = ctypes.POINTER(ctypes.c_void_p)
+
+# name -> argtypes (every entry point returns int, except the three string/pointer getters)
+PROTOTYPES = {
+    "nufhe_device_count": [ctypes.POINTER(_int)],
+    "nufhe_device_name": [_int, ctypes.c_char_p, ctypes.c_size_t],
+    "nufhe_ctx_create": [_int, _vp, _pp],
+    "nufhe_ctx_destroy": [_vp],
+    "nufhe_ctx_synchronize": [_vp],
+    "nufhe_ctx_device": [_vp, ctypes.POINTER(_int)],
+    "nufhe_alloc": [_vp, ctypes.c_size_t, _pp],
+    "nufhe_free": [_vp, _vp],
+    "nufhe_h2d": [_vp, _vp, _vp, ctypes.c_size_t],
+    "nufhe_d2h": [_vp, _vp, _vp, ctypes.c_size_t],
+    "nufhe_cloudkey_create": [_vp, _int, _pp],
+    "nufhe_cloudkey_destroy": [_vp],
+    "nufhe_bk_upload_reference": [_vp, _vp],
+    "nufhe_bk_download_reference": [_vp, _vp],
+    "nufhe_bk_from_coeffs": [_vp, _vp],
+    "nufhe_ks_upload": [_vp, _vp, _vp, _vp],
+    "nufhe_lwe_linear": [_vp, NufheLwe, NufheLwe, _i32, _int, _long, _int],
+    "nufhe_lwe_trivial_const": [_vp, NufheLwe, _i32, _long, _int],
+    "nufhe_bootstrap": [_vp, _vp, NufheLwe, NufheLwe, _i32, _long, _int],
+    "nufhe_keyswitch": [_vp, _vp, NufheLwe, NufheLwe, _long],
+    "nufhe_gate_binary": [_vp, _vp, NufheLwe, NufheLwe, NufheLwe, _i32, _i32, _i32, _i32, _long],
+    "nufhe_gate_mux": [_vp, _vp, NufheLwe, NufheLwe, NufheLwe, NufheLwe, _long],
+    "nufhe_t32_to_phase": [_vp, _vp, _vp, _long, ctypes.c_uint32],
+    "nufhe_shift_torus_polynomial": [_vp, _vp, _vp, _vp, _long, _long, _long, _int, _int, _int],
+    "nufhe_tlwe_extract": [_vp, _vp, _vp, _vp, _long],
+    "nufhe_ntt_forward_i32": [_vp, _vp, _vp, _long],
+    "nufhe_ntt_forward_u64": [_vp, _vp, _vp, _long],
+    "nufhe_ntt_inverse_i32": [_vp, _vp, _vp, _long],
+    "nufhe_ntt_inverse_u64": [_vp, _vp, _vp, _long],
+    "nufhe_poly_mul_i32": [_vp, _vp, _vp, _vp, _long, _long],
+    "nufhe_external_mul": [_vp, _vp, _vp, _int, _long],
+    "nufhe_blind_rotate": [_vp, _vp, _vp, _vp, _long, _int, _long],
+    "nufhe_tlwe_encrypt_zero": [_vp, _vp, _vp, _vp, _vp, _long],
+    "nufhe_profile_enable": [_vp, _int],
+    "nufhe_profile_last": [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)],
+}
+
+_lib = None
+
+
+def lib():
+    """Loads libnufhe_hip.so (built by __graft_entry__.build() / nufhe_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NufheError(
+                "libnufhe_hip.so not found at %s: build it with `make -C nufhe_amd/csrc` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        handle.nufhe_last_error.restype = ctypes.c_char_p
+        handle.nufhe_last_error.argtypes = []
+        handle.nufhe_version.restype = ctypes.c_char_p
+        handle.nufhe_version.argtypes = []
+        handle.nufhe_ctx_stream.restype = ctypes.c_void_p
+        handle.nufhe_ctx_stream.argtypes = [_vp]
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    """Maps a C status code to the Python exception types the reference raises."""
+    if rc == 0:
+        return
+    msg = lib().nufhe_last_error().decode("utf-8", "replace")
+    if rc == -1:
+        raise ValueError(msg)
+    raise NufheError("nufhe_hip error %d: %s" % (rc, msg))
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args))

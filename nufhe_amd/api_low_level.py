@@ -1,0 +1,208 @@
+"""
+Low-level API: scheme parameters, keys, encrypt/decrypt (reference: nufhe/api_low_level.py:31-302).
+"""
+
+import io
+import pickle
+
+import numpy
+
+from .bootstrap import BootstrapKey, NativeCloudKey
+from .lwe import LweParams, LweKey, LweSampleArray, lwe_encrypt, lwe_decrypt, LweKeyswitchKey
+from .numeric_functions import phase_to_t32
+from .performance import PerformanceParameters
+from .tgsw import TGswParams, TGswKey
+from .tlwe import TLweParams
+
+
+class NuFHEParameters:
+    """
+    Parameters of the FHE scheme (nufhe/api_low_level.py:31-87); the defaults correspond to about
+    128 bits of security.
+
+    :param transform_type: ``'NTT'`` (64-bit-prime number-theoretic transform).  ``'FFT'`` is
+        accepted by the reference; this build implements the NTT path only (BASELINE config 5 is
+        scheduled after the NTT path meets its bar) and raises NotImplementedError for 'FFT'.
+    """
+
+    def __init__(self, transform_type='NTT', tlwe_mask_size=1):
+        assert transform_type in ('FFT', 'NTT')
+        assert tlwe_mask_size >= 1
+        if transform_type != 'NTT':
+            raise NotImplementedError("only transform_type='NTT' is implemented on gfx950 so far")
+        if tlwe_mask_size != 1:
+            raise NotImplementedError("only tlwe_mask_size=1 is implemented on gfx950 so far")
+
+        tlwe_polynomial_degree = 1024
+        lwe_size = 500
+        bs_decomp_length = 2
+        bs_log2_base = 10
+        ks_decomp_length = 8
+        ks_log2_base = 2
+
+        coeff = (2 / numpy.pi)**0.5
+        ks_stdev = 1/2**15 * coeff
+        bs_stdev = 9e-9 * coeff
+        max_stdev = 1/2**4 / 4 * coeff
+
+        params_in = LweParams(lwe_size, ks_stdev, max_stdev)
+        params_accum = TLweParams(
+            tlwe_polynomial_degree, tlwe_mask_size, bs_stdev, max_stdev, transform_type)
+        params_bs = TGswParams(params_accum, bs_decomp_length, bs_log2_base)
+
+        self.ks_decomp_length = ks_decomp_length
+        self.ks_log2_base = ks_log2_base
+        self.in_out_params = params_in
+        self.tgsw_params = params_bs
+        self._transform_type = transform_type
+        self._tlwe_mask_size = tlwe_mask_size
+
+    def __hash__(self):
+        return hash((self.__class__, self._transform_type, self._tlwe_mask_size))
+
+    def __eq__(self, other):
+        return (
+            self.__class__ == other.__class__
+            and self._transform_type == other._transform_type
+            and self._tlwe_mask_size == other._tlwe_mask_size)
+
+
+class NuFHESecretKey:
+    """A secret key (nufhe/api_low_level.py:90-148)."""
+
+    def __init__(self, params: NuFHEParameters, lwe_key: LweKey):
+        self.params = params
+        self.lwe_key = lwe_key
+
+    @classmethod
+    def from_rng(cls, thr, params: NuFHEParameters, rng):
+        return cls(params, LweKey.from_rng(thr, params.in_out_params, rng))
+
+    def dump(self, file_obj):
+        pickle.dump(self.params, file_obj)
+        self.lwe_key.dump(file_obj)
+
+    def dumps(self):
+        file_obj = io.BytesIO()
+        self.dump(file_obj)
+        return file_obj.getvalue()
+
+    @classmethod
+    def load(cls, file_obj, thr):
+        params = pickle.load(file_obj)
+        lwe_key = LweKey.load(file_obj, thr)
+        return cls(params, lwe_key)
+
+    @classmethod
+    def loads(cls, s: bytes, thr):
+        return cls.load(io.BytesIO(s), thr)
+
+    def __eq__(self, other):
+        return (
+            self.__class__ == other.__class__
+            and self.params == other.params
+            and self.lwe_key == other.lwe_key)
+
+
+class NuFHECloudKey:
+    """A cloud key: bootstrapping key + keyswitch key (nufhe/api_low_level.py:151-239)."""
+
+    def __init__(self, params: NuFHEParameters, bootstrap_key: BootstrapKey,
+                 keyswitch_key: LweKeyswitchKey, native: NativeCloudKey):
+        self.params = params
+        self.bootstrap_key = bootstrap_key
+        self.keyswitch_key = keyswitch_key
+        self._native = native
+
+    @staticmethod
+    def _attach_keyswitch(native, ks: LweKeyswitchKey):
+        import ctypes
+        from . import _lib
+        lwe = ks.lwe
+        _lib.call("nufhe_ks_upload", native.handle,
+                  lwe.a.ctypes.data_as(ctypes.c_void_p), lwe.b.ctypes.data_as(ctypes.c_void_p),
+                  lwe.current_variances.ctypes.data_as(ctypes.c_void_p))
+        ks._native = native
+
+    @classmethod
+    def from_rng(cls, thr, params: NuFHEParameters, rng, secret_key: NuFHESecretKey, perf_params=None):
+        """Generates a cloud key in the reference's RNG order (api_low_level.py:174-196):
+        TGSW key, bootstrapping key, keyswitch key."""
+        native = NativeCloudKey(thr, params.in_out_params.size)
+        tgsw_key = TGswKey.from_rng(thr, params.tgsw_params, rng)
+        bk = BootstrapKey.from_rng(thr, rng, secret_key.lwe_key, tgsw_key, native, perf_params)
+        ks = LweKeyswitchKey.from_tgsw_key(
+            thr, rng, params.ks_decomp_length, params.ks_log2_base, secret_key.lwe_key, tgsw_key)
+        cls._attach_keyswitch(native, ks)
+        return cls(params, bk, ks, native)
+
+    def dump(self, file_obj):
+        pickle.dump(self.params, file_obj)
+        self.bootstrap_key.dump(file_obj)
+        self.keyswitch_key.dump(file_obj)
+
+    def dumps(self):
+        file_obj = io.BytesIO()
+        self.dump(file_obj)
+        return file_obj.getvalue()
+
+    @classmethod
+    def load(cls, file_obj, thr):
+        params = pickle.load(file_obj)
+        native = NativeCloudKey(thr, params.in_out_params.size)
+        bootstrap_key = BootstrapKey.load(file_obj, thr, native)
+        keyswitch_key = LweKeyswitchKey.load(file_obj, thr)
+        cls._attach_keyswitch(native, keyswitch_key)
+        return cls(params, bootstrap_key, keyswitch_key, native)
+
+    @classmethod
+    def loads(cls, s: bytes, thr):
+        return cls.load(io.BytesIO(s), thr)
+
+    def __eq__(self, other):
+        return (
+            self.__class__ == other.__class__
+            and self.params == other.params
+            and self.bootstrap_key == other.bootstrap_key
+            and self.keyswitch_key == other.keyswitch_key)
+
+
+def make_key_pair(thr, rng, **params):
+    """nufhe/api_low_level.py:242-250"""
+    nufhe_params = NuFHEParameters(**params)
+    secret_key = NuFHESecretKey.from_rng(thr, nufhe_params, rng)
+    cloud_key = NuFHECloudKey.from_rng(thr, nufhe_params, rng, secret_key)
+    return secret_key, cloud_key
+
+
+_1s8 = phase_to_t32(1, 8)
+
+
+def bool_to_t32(bits):
+    bits = numpy.asarray(bits).astype(bool)
+    return numpy.where(bits, _1s8, -_1s8).astype(numpy.int32)
+
+
+def t32_to_bool(mus):
+    return numpy.asarray(mus) > 0
+
+
+def encrypt(thr, rng, key: NuFHESecretKey, message):
+    """Encrypts an array of bits (nufhe/api_low_level.py:266-281)."""
+    message = numpy.asarray(message)
+    result = empty_ciphertext(thr, key.params, message.shape)
+    mus = bool_to_t32(message)
+    noise = key.params.in_out_params.min_noise
+    lwe_encrypt(thr, rng, result, mus, noise, key.lwe_key)
+    return result
+
+
+def decrypt(thr, key: NuFHESecretKey, ciphertext: LweSampleArray):
+    """Decrypts to a numpy bool array of the ciphertext's shape (nufhe/api_low_level.py:284-295)."""
+    mus = lwe_decrypt(thr, ciphertext, key.lwe_key)
+    return t32_to_bool(mus)
+
+
+def empty_ciphertext(thr, params: NuFHEParameters, shape):
+    """nufhe/api_low_level.py:298-302"""
+    return LweSampleArray.empty(thr, params.in_out_params, tuple(shape))

@@ -1,0 +1,107 @@
+"""
+Bootstrap key and the bootstrap driver (reference: nufhe/bootstrap.py:44-229,
+nufhe/blind_rotate.py:262-281).
+
+The reference's driver issues ~10 kernel launches per gate (mod-switch x2, fill, shift, trivial,
+fused blind-rotate, keyswitch, ...); here `bootstrap()` is ONE C-ABI call that enqueues the fused
+gfx950 bootstrap kernel (+ the keyswitch kernels).
+"""
+
+import ctypes
+import pickle
+
+import numpy
+
+from . import _lib
+from .device import ptr
+from .lwe import LweParams, LweKey, LweSampleArray, LweKeyswitchKey, _Flat
+from .tgsw import TGswKey, TGswParams, tgsw_encrypt_int
+from .utils import arrays_equal
+
+
+class NativeCloudKey:
+    """Owner of the device copies of the bootstrapping key (wave layout) and the keyswitch key."""
+
+    def __init__(self, thr, lwe_size):
+        self.thr = thr
+        handle = ctypes.c_void_p()
+        _lib.call("nufhe_cloudkey_create", thr.handle, int(lwe_size), ctypes.byref(handle))
+        self.handle = handle
+
+    def __del__(self):
+        try:
+            if self.handle and not self.thr._released:
+                _lib.lib().nufhe_cloudkey_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class BootstrapKey:
+    """
+    nufhe/bootstrap.py:44-92.  The transformed TGSW samples live on the device in the library's
+    own layout; ``dump``/``load`` convert from/to the reference's storage format (natural-order
+    NTT, Montgomery-prepared uint64 [n, k+1, l, k+1, N]).
+    """
+
+    def __init__(self, in_out_params: LweParams, bk_params: TGswParams, native: NativeCloudKey):
+        accum_params = bk_params.tlwe_params
+        self.in_out_params = in_out_params
+        self.bk_params = bk_params
+        self.accum_params = accum_params
+        self.extract_params = accum_params.extracted_lweparams
+        self._native = native
+
+    @classmethod
+    def from_rng(cls, thr, rng, lwe_key: LweKey, tgsw_key: TGswKey, native: NativeCloudKey,
+                 perf_params=None):
+        in_out_params = lwe_key.params
+        bk_params = tgsw_key.params
+        accum_params = bk_params.tlwe_params
+        # non-transformed key: TGSW encryptions of the LWE key bits (bootstrap.py:67-69)
+        bk = tgsw_encrypt_int(thr, rng, lwe_key.key, accum_params.min_noise, tgsw_key)
+        # to the transformed domain, where it is used (bootstrap.py:72-74)
+        _lib.call("nufhe_bk_from_coeffs", native.handle, ptr(bk.contiguous()))
+        thr.synchronize()
+        return cls(in_out_params, bk_params, native)
+
+    def transformed_reference_format(self):
+        """Host uint64 array [n, k+1, l, k+1, N]: the reference's storage format."""
+        k1 = self.bk_params.tlwe_params.mask_size + 1
+        shape = (self.in_out_params.size, k1, self.bk_params.decomp_length, k1,
+                 self.bk_params.tlwe_params.polynomial_degree)
+        out = numpy.empty(shape, numpy.uint64)
+        _lib.call("nufhe_bk_download_reference", self._native.handle, out.ctypes.data_as(ctypes.c_void_p))
+        return out
+
+    def dump(self, file_obj):
+        pickle.dump(self.in_out_params, file_obj)
+        pickle.dump(self.bk_params, file_obj)
+        pickle.dump(self.transformed_reference_format(), file_obj)
+
+    @classmethod
+    def load(cls, file_obj, thr, native: NativeCloudKey):
+        in_out_params = pickle.load(file_obj)
+        bk_params = pickle.load(file_obj)
+        arr = numpy.ascontiguousarray(pickle.load(file_obj), numpy.uint64)
+        _lib.call("nufhe_bk_upload_reference", native.handle, arr.ctypes.data_as(ctypes.c_void_p))
+        return cls(in_out_params, bk_params, native)
+
+    def __eq__(self, other):
+        return (
+            self.__class__ == other.__class__
+            and self.in_out_params == other.in_out_params
+            and self.bk_params == other.bk_params
+            and arrays_equal(self.transformed_reference_format(), other.transformed_reference_format()))
+
+
+def bootstrap(thr, result: LweSampleArray, bk: BootstrapKey, ks: LweKeyswitchKey, mu, x: LweSampleArray,
+              perf_params=None, no_keyswitch=False):
+    """
+    result = LWE(mu) iff phase(x) > 0, LWE(-mu) iff phase(x) < 0  (nufhe/bootstrap.py:206-229).
+    With ``no_keyswitch`` the result is an LWE sample under the extracted key (size N*k).
+    """
+    res = _Flat(result, result.shape, output=True)
+    src = _Flat(x, result.shape)
+    _lib.call("nufhe_bootstrap", thr.handle, bk._native.handle, res.desc, src.desc,
+              int(numpy.int32(mu)), res.nbits, int(bool(no_keyswitch)))
+    res.writeback()

@@ -1,0 +1,106 @@
+"""
+DeviceThread: the object passed wherever the reference takes a Reikna ``Thread`` (``thr``).
+One GPU + one in-order HIP stream (reference: reikna.cluda Thread, used all over
+nufhe/api_high_level.py:130-181).  Device memory is held in torch tensors (plumbing only: an
+allocator and a stream); every computation of the hot path goes to libnufhe_hip.so through the
+C ABI with raw pointers.
+"""
+
+import ctypes
+
+import numpy
+import torch
+
+from . import _lib
+from ._lib import NufheLwe
+
+
+class DeviceParams:
+    """Stand-in for Reikna's device_params (only consumed by PerformanceParameters.for_device)."""
+
+    def __init__(self, name, compute_units):
+        self.name = name
+        self.compute_units = compute_units
+        self.max_work_group_size = 1024
+        self.local_mem_size = 160 * 1024
+
+
+_NP_TO_TORCH = {
+    numpy.dtype('int32'): torch.int32,
+    numpy.dtype('float32'): torch.float32,
+    numpy.dtype('uint64'): torch.uint64 if hasattr(torch, 'uint64') else torch.int64,
+    numpy.dtype('int64'): torch.int64,
+    numpy.dtype('bool'): torch.bool,
+}
+
+
+class DeviceThread:
+
+    def __init__(self, device_index=0):
+        lib = _lib.lib()   # raises if the HIP library is missing: no CPU fallback
+        count = ctypes.c_int(0)
+        _lib.check(lib.nufhe_device_count(ctypes.byref(count)))
+        if count.value == 0 or not torch.cuda.is_available():
+            raise _lib.NufheError("no MI355X / HIP device available (nufhe_amd has no CPU fallback)")
+        self.device_index = int(device_index)
+        self.device = torch.device('cuda', self.device_index)
+        torch.cuda.set_device(self.device)
+        self._torch_stream = torch.cuda.current_stream(self.device)
+        handle = ctypes.c_void_p()
+        _lib.check(lib.nufhe_ctx_create(
+            self.device_index, ctypes.c_void_p(self._torch_stream.cuda_stream), ctypes.byref(handle)))
+        self.handle = handle
+        props = torch.cuda.get_device_properties(self.device)
+        self.device_params = DeviceParams(props.name, props.multi_processor_count)
+        self._released = False
+
+    # ---- memory -------------------------------------------------------------------------
+    def array(self, shape, dtype):
+        return torch.empty(tuple(shape), dtype=_NP_TO_TORCH[numpy.dtype(dtype)], device=self.device)
+
+    def zeros(self, shape, dtype):
+        return torch.zeros(tuple(shape), dtype=_NP_TO_TORCH[numpy.dtype(dtype)], device=self.device)
+
+    def empty_like(self, arr):
+        return torch.empty_like(arr)
+
+    def to_device(self, arr):
+        arr = numpy.ascontiguousarray(arr)
+        if arr.dtype == numpy.uint64 and not hasattr(torch, 'uint64'):
+            arr = arr.view(numpy.int64)
+        return torch.from_numpy(arr).to(self.device)
+
+    def from_device(self, arr):
+        return arr.detach().cpu().numpy()
+
+    def synchronize(self):
+        _lib.call("nufhe_ctx_synchronize", self.handle)
+
+    def release(self):
+        if not self._released and self.handle:
+            _lib.lib().nufhe_ctx_destroy(self.handle)
+            self._released = True
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+def ptr(tensor):
+    return ctypes.c_void_p(tensor.data_ptr() if tensor is not None else 0)
+
+
+def lwe_desc(a, b, cv, size):
+    """Builds the C descriptor of an LWE sample batch from (a [B, size], b [B], cv [B]) device
+    tensors that are 2D/1D views with a contiguous last axis (stride-0 batch axes broadcast)."""
+    assert a.dim() == 2 and b.dim() == 1
+    if a.shape[1] != size or (a.shape[1] > 1 and a.stride(1) != 1):
+        raise ValueError("LWE mask array must have a contiguous last axis of length %d" % size)
+    if cv is not None:
+        assert cv.dim() == 1 and (cv.stride(0) == b.stride(0) or cv.shape[0] <= 1)
+    return NufheLwe(
+        a=a.data_ptr(), b=b.data_ptr(), cv=(cv.data_ptr() if cv is not None else None),
+        a_stride=a.stride(0) if a.shape[0] > 1 else (a.stride(0) if a.shape[0] == 1 else 0),
+        b_stride=b.stride(0) if b.shape[0] > 1 else (b.stride(0) if b.shape[0] == 1 else 0))

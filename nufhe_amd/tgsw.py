@@ -1,0 +1,63 @@
+"""
+TGSW parameter / key records (reference: nufhe/tgsw.py:43-78) and the gadget-message step of
+bootstrap-key generation (tgsw_add_message, tgsw.py:142-161 / tgsw_cpu.py:109-126).
+"""
+
+import numpy
+
+from .numeric_functions import Torus32
+from .tlwe import TLweParams, TLweKey, tlwe_encrypt_zero
+
+
+class TGswParams:
+    """nufhe/tgsw.py:43-67"""
+
+    def __init__(self, tlwe_params: TLweParams, decomp_length: int, bs_log2_base: int):
+        decomp_range = numpy.arange(1, decomp_length + 1)
+        self.base_powers = (2**(32 - decomp_range * bs_log2_base)).astype(Torus32)
+        self.offset = (
+            self.base_powers.astype(numpy.int64).sum() * (2**bs_log2_base // 2)).astype(Torus32)
+        self.decomp_length = decomp_length
+        self.bs_log2_base = bs_log2_base
+        self.tlwe_params = tlwe_params
+
+    def __eq__(self, other):
+        return (
+            self.__class__ == other.__class__
+            and self.decomp_length == other.decomp_length
+            and self.bs_log2_base == other.bs_log2_base
+            and self.tlwe_params == other.tlwe_params)
+
+    def __hash__(self):
+        return hash((self.__class__, self.decomp_length, self.bs_log2_base, self.tlwe_params))
+
+
+class TGswKey:
+    """nufhe/tgsw.py:70-78"""
+
+    def __init__(self, params: TGswParams, tlwe_key: TLweKey):
+        self.params = params
+        self.tlwe_key = tlwe_key
+
+    @classmethod
+    def from_rng(cls, thr, params: TGswParams, rng):
+        return cls(params, TLweKey.from_rng(thr, params.tlwe_params, rng))
+
+
+def tgsw_encrypt_int(thr, rng, messages, noise: float, key: TGswKey):
+    """
+    TGSW encryptions of the integer ``messages`` (one per entry): int32 device array
+    ``messages.shape + (k+1, l, k+1, N)`` (nufhe/tgsw.py:155-161).
+    result = TGSW(0) + message * H, H = gadget: adds message * 2^(32 - Bgbit (d+1)) to
+    coefficient 0 of polynomial m of row (m, d)  (tgsw_cpu.py:121-124).
+    """
+    params = key.params
+    k1 = params.tlwe_params.mask_size + 1
+    l = params.decomp_length
+    shape = tuple(messages.shape)
+    result = tlwe_encrypt_zero(thr, rng, shape + (k1, l), noise, key.tlwe_key)
+    base_powers = thr.to_device(params.base_powers)                  # [l]
+    inc = messages.reshape(shape + (1,)).to(base_powers.dtype) * base_powers   # int32 wraparound
+    for m in range(k1):
+        result[..., m, :, m, 0] += inc
+    return result

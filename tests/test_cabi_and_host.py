@@ -1,0 +1,127 @@
+"""
+CPU-only checks of the product's host side: the C-ABI shared library loads and exports every
+symbol include/nufhe_hip.h declares (no compute calls without a GPU), the product fails loudly
+without a GPU, and the host logic (shapes, parameters, RNG, torus helpers) behaves like the
+reference's.
+"""
+
+import ctypes
+import os
+import re
+
+import numpy
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def built_lib():
+    import __graft_entry__
+    if not os.path.exists(os.path.join(ROOT, 'nufhe_amd', 'libnufhe_hip.so')):
+        __graft_entry__.build()
+    from nufhe_amd import _lib
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    header = open(os.path.join(ROOT, 'include', 'nufhe_hip.h')).read()
+    declared = set(re.findall(r'\b(nufhe_[a-z0-9_]+)\s*\(', header))
+    declared -= {'nufhe_ctx', 'nufhe_cloudkey', 'nufhe_lwe'}
+    assert len(declared) >= 35
+    lib = ctypes.CDLL(built_lib.LIB_PATH)
+    missing = [name for name in sorted(declared) if not hasattr(lib, name)]
+    assert not missing, missing
+    # the ctypes prototypes cover the header
+    proto = set(built_lib.PROTOTYPES) | {'nufhe_last_error', 'nufhe_version', 'nufhe_ctx_stream'}
+    assert declared <= proto, sorted(declared - proto)
+
+
+def test_no_cpu_fallback(built_lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import nufhe_amd
+    lib = built_lib.lib()
+    assert lib.nufhe_version().startswith(b'nufhe_hip')
+    count = ctypes.c_int(-1)
+    rc = lib.nufhe_device_count(ctypes.byref(count))
+    assert rc != 0 and count.value == 0
+    with pytest.raises((built_lib.NufheError, ValueError)):
+        nufhe_amd.Context()
+
+
+def test_product_does_not_import_oracle():
+    """The product package never imports, includes or loads anything under oracle/ or tests/."""
+    pkg = os.path.join(ROOT, 'nufhe_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith(('.py', '.hip', '.h', '.cpp')):
+                continue
+            for line in open(os.path.join(dirpath, f)).read().splitlines():
+                low = line.lower()
+                if 'oracle' in low or 'emu' in low.split('//')[0]:
+                    assert not re.search(r'^\s*(from|import|#\s*include)\b', line), (f, line)
+                    assert 'cdll' not in low and 'dlopen' not in low, (f, line)
+
+
+def test_phase_to_t32_wraps():
+    from nufhe_amd.numeric_functions import phase_to_t32, double_to_t32
+    # intended values (NumPy 1.x wrapped silently)
+    assert phase_to_t32(1, 8) == 2**29
+    assert phase_to_t32(-1, 8) == -2**29
+    assert phase_to_t32(-1, 4) == -2**30
+    assert phase_to_t32(1, 4) == 2**30
+    assert double_to_t32(numpy.array([0.0, 2.0**-15]))[1] == 2**17
+
+
+def test_result_shape_rules():
+    # nufhe/gates.py:51-78 / test_api_high_level.py:135-172
+    from nufhe_amd.gates import result_shape, check_shape
+
+    class S:
+        def __init__(self, shape): self.shape = shape
+    assert result_shape((3, 4), (4,)) == (3, 4)
+    assert result_shape((1, 4), (3, 1)) == (3, 4)
+    assert result_shape((2, 3, 4), (4,), (3, 1)) == (2, 3, 4)
+    with pytest.raises(ValueError):
+        result_shape((3, 4), (5,))
+    check_shape(S((2, 3, 4)), S((3, 4)), S((4,)))
+    with pytest.raises(ValueError):
+        check_shape(S((3, 4)), S((2, 3, 4)))
+
+
+def test_parameters_match_reference_defaults():
+    # nufhe/api_low_level.py:49-61
+    from nufhe_amd import NuFHEParameters
+    p = NuFHEParameters()
+    assert p.in_out_params.size == 500
+    assert p.tgsw_params.tlwe_params.polynomial_degree == 1024
+    assert p.tgsw_params.tlwe_params.mask_size == 1
+    assert p.tgsw_params.decomp_length == 2 and p.tgsw_params.bs_log2_base == 10
+    assert p.ks_decomp_length == 8 and p.ks_log2_base == 2
+    assert int(p.tgsw_params.offset) == -2145386496   # (int32)(2^31 + 2^21), tgsw.py:49-52
+    assert p.tgsw_params.tlwe_params.extracted_lweparams.size == 1024
+    assert p == NuFHEParameters() and hash(p) == hash(NuFHEParameters())
+    with pytest.raises(NotImplementedError):
+        NuFHEParameters(transform_type='FFT')
+
+
+def test_rng_order_matches_oracle(orc):
+    """DeterministicRNG draws (random_numbers.py:46-62) are the oracle's / the reference's."""
+    from nufhe_amd.random_numbers import DeterministicRNG, rand_gaussian_torus32_host
+    r1 = DeterministicRNG(9); r2 = orc.DeterministicRNG(9)
+    assert (r1.uniform_bool((7,)) == r2.uniform_bool((7,))).all()
+    assert (r1.uniform_torus32((3, 5)) == r2.uniform_torus32((3, 5))).all()
+    a = rand_gaussian_torus32_host(r1, 0, 1e-4, (4, 6), centered=True)
+    b = orc.rand_gaussian_torus32(r2, 0, 1e-4, (4, 6), centered=True)
+    assert (a == b).all()
+
+
+def test_secure_rng_shapes():
+    from nufhe_amd import SecureRNG
+    r = SecureRNG()
+    assert r.uniform_bool((3, 5)).shape == (3, 5) and set(numpy.unique(r.uniform_bool((64,)))) <= {0, 1}
+    assert r.uniform_torus32((4,)).dtype == numpy.int32
+    g = r.gauss((1001,), 2.0)
+    assert g.shape == (1001,) and 1.0 < g.std() < 3.0

@@ -1,0 +1,174 @@
+"""
+GPU parity tests, whole-gate granularity (BASELINE configs 1-3), through the nufhe-style API:
+ * ciphertext-level equality (a, b, current_variances) with golden outputs of the REFERENCE's own
+   CPU functions at full size (B=2 NAND/MUX) and with the oracle on larger batches,
+ * decrypt == truth table for all 14 gates (test/test_gates.py:178-245 of the reference),
+ * GPU key generation == oracle key generation from the same seed (RNG order),
+ * the 4096-bit configurations through size-independent properties.
+"""
+
+import os
+
+import numpy
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import make_golden_gate
+
+
+@pytest.fixture(scope='module')
+def env(orc, oracle_keys):
+    import gpu_helpers as H
+    from nufhe_amd.device import DeviceThread
+    import nufhe_amd
+    thr = DeviceThread(0)
+    lwe_key, tlwe_key, ck = oracle_keys
+    cloud_key = H.cloud_key_from_arrays(thr, ck)
+    secret_key = H.secret_key_from_array(thr, lwe_key)
+    ctx = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(456), thread=thr)
+    vm = ctx.make_virtual_machine(cloud_key)
+    return dict(H=H, thr=thr, ctx=ctx, vm=vm, ck=ck, lwe_key=lwe_key, cloud_key=cloud_key, secret_key=secret_key)
+
+
+def test_nand_mux_vs_reference_full_size_golden(env, orc):
+    H = env['H']; thr = env['thr']; vm = env['vm']
+    g = numpy.load(os.path.join(os.path.dirname(make_golden_gate.__file__), 'reference_gate_outputs.npz'))
+    lwe_key, tlwe_key, ck, cts, ms = make_golden_gate.gate_inputs()
+    d = [H.ciphertext_from_arrays(thr, ct) for ct in cts]
+    ra, rb, rcv = H.ct_arrays(vm.gate_nand(d[0], d[1]))
+    assert (ra == g['nand_a']).all() and (rb == g['nand_b']).all() and (rcv == g['nand_cv']).all()
+    ra, rb, rcv = H.ct_arrays(vm.gate_mux(d[0], d[1], d[2]))
+    assert (ra == g['mux_a']).all() and (rb == g['mux_b']).all() and (rcv == g['mux_cv']).all()
+    # bootstrap without keyswitch -> extracted sample (gates.py:633-655 building block)
+    from nufhe_amd.bootstrap import bootstrap
+    from nufhe_amd import lwe as L
+    params = env['cloud_key'].params
+    MU = 2**29
+    tmp = L.LweSampleArray.empty(thr, params.in_out_params, (2,))
+    L.lwe_noiseless_trivial_constant(thr, tmp, MU)
+    L.lwe_sub_to(thr, tmp, d[0]); L.lwe_sub_to(thr, tmp, d[1])
+    ext = L.LweSampleArray.empty(thr, params.tgsw_params.tlwe_params.extracted_lweparams, (2,))
+    bootstrap(thr, ext, env['cloud_key'].bootstrap_key, env['cloud_key'].keyswitch_key, MU, tmp, no_keyswitch=True)
+    assert (H.host(ext.a) == g['nand_ext_a']).all() and (H.host(ext.b) == g['nand_ext_b']).all()
+
+
+def test_config1_nand_32_bits_vs_oracle(env, orc):
+    """BASELINE config 1/2 shape at 32 bits: every output word equals the CPU path."""
+    H = env['H']; thr = env['thr']; vm = env['vm']; ck = env['ck']; lwe_key = env['lwe_key']
+    rng = orc.DeterministicRNG(456)
+    m1 = rng.uniform_bool((32,)).astype(bool); m2 = rng.uniform_bool((32,)).astype(bool)
+    c1 = orc.encrypt(rng, lwe_key, m1); c2 = orc.encrypt(rng, lwe_key, m2)
+    exp = orc.gate('gate_nand', ck, c1, c2)
+    r = vm.gate_nand(H.ciphertext_from_arrays(thr, c1), H.ciphertext_from_arrays(thr, c2))
+    ra, rb, rcv = H.ct_arrays(r)
+    assert (ra == exp[0]).all() and (rb == exp[1]).all() and (rcv == exp[2]).all()
+    assert (env['ctx'].decrypt(env['secret_key'], r) == ~(m1 & m2)).all()
+
+
+def test_mux_vs_oracle_odd_batch(env, orc):
+    H = env['H']; thr = env['thr']; vm = env['vm']; ck = env['ck']; lwe_key = env['lwe_key']
+    rng = orc.DeterministicRNG(789)
+    B = 19
+    ms = [rng.uniform_bool((B,)).astype(bool) for _ in range(3)]
+    cs = [orc.encrypt(rng, lwe_key, m) for m in ms]
+    exp = orc.gate_mux(ck, *cs)
+    r = vm.gate_mux(*[H.ciphertext_from_arrays(thr, c) for c in cs])
+    ra, rb, rcv = H.ct_arrays(r)
+    assert (ra == exp[0]).all() and (rb == exp[1]).all() and (rcv == exp[2]).all()
+    assert (env['ctx'].decrypt(env['secret_key'], r) == numpy.where(ms[0], ms[1], ms[2])).all()
+
+
+TRUTH = {
+    'gate_nand': lambda a, b: ~(a & b), 'gate_or': lambda a, b: a | b, 'gate_and': lambda a, b: a & b,
+    'gate_nor': lambda a, b: ~(a | b), 'gate_xor': lambda a, b: a ^ b, 'gate_xnor': lambda a, b: ~(a ^ b),
+    'gate_andny': lambda a, b: ~a & b, 'gate_andyn': lambda a, b: a & ~b,
+    'gate_orny': lambda a, b: ~a | b, 'gate_oryn': lambda a, b: a | ~b,
+}
+
+
+def test_all_gates_truth_tables_and_parity(env, orc):
+    """test_gates.py:178-245 of the reference (32 bits), plus ciphertext equality with the oracle."""
+    H = env['H']; thr = env['thr']; vm = env['vm']; ctx = env['ctx']; sk = env['secret_key']
+    ck = env['ck']
+    rng = numpy.random.RandomState(5)
+    m1 = rng.randint(0, 2, size=(4, 8)).astype(bool); m2 = rng.randint(0, 2, size=(4, 8)).astype(bool)
+    c1 = ctx.encrypt(sk, m1); c2 = ctx.encrypt(sk, m2)
+    for name, fn in TRUTH.items():
+        r = getattr(vm, name)(c1, c2)
+        assert r.shape == (4, 8)
+        assert (ctx.decrypt(sk, r) == fn(m1, m2)).all(), name
+        exp = orc.gate(name, ck, H.ct_arrays(c1)[:2], H.ct_arrays(c2)[:2])
+        ra, rb, rcv = H.ct_arrays(r)
+        assert (ra == exp[0]).all() and (rb == exp[1]).all(), name
+    assert (ctx.decrypt(sk, vm.gate_not(c1)) == ~m1).all()
+    assert (ctx.decrypt(sk, vm.gate_copy(c1)) == m1).all()
+    assert (ctx.decrypt(sk, vm.gate_constant(m2)) == m2).all()
+
+
+def test_broadcast_and_views(env, orc):
+    """Shape derivation / broadcasting (test_api_high_level.py:135-172) and strided views as
+    inputs and output (test_gates.py:514-559)."""
+    vm = env['vm']; ctx = env['ctx']; sk = env['secret_key']
+    rng = numpy.random.RandomState(6)
+    m1 = rng.randint(0, 2, size=(3, 4)).astype(bool); m2 = rng.randint(0, 2, size=(4,)).astype(bool)
+    c1 = ctx.encrypt(sk, m1); c2 = ctx.encrypt(sk, m2)
+    r = vm.gate_and(c1, c2)
+    assert r.shape == (3, 4) and (ctx.decrypt(sk, r) == (m1 & m2)).all()
+    big = ctx.encrypt(sk, numpy.zeros((6, 4), bool))
+    vm.gate_or(c1[:, ::2], c2[::2], dest=big[1::2, 1:3])
+    dec = ctx.decrypt(sk, big)
+    assert (dec[1::2, 1:3] == (m1[:, ::2] | m2[::2])).all()
+    mask = numpy.ones((6, 4), bool); mask[1::2, 1:3] = False
+    assert (dec[mask] == False).all()
+    with pytest.raises(ValueError):
+        vm.gate_and(c1, ctx.encrypt(sk, numpy.zeros((5,), bool)))
+
+
+def test_gpu_keygen_matches_oracle_keygen(env, orc, oracle_keys):
+    """Context.make_key_pair on the GPU == oracle.make_key_pair from the same seed: same RNG
+    consumption order, same TLWE-encrypt-zero products, same transformed key (reference format)."""
+    import nufhe_amd
+    thr = env['thr']; H = env['H']
+    lwe_key, tlwe_key, ck = oracle_keys
+    ctx = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(123), thread=thr)
+    sk, cloud = ctx.make_key_pair()
+    assert (H.host(sk.lwe_key.key) == lwe_key).all()
+    assert (cloud.bootstrap_key.transformed_reference_format() == ck.bk).all()
+    assert (cloud.keyswitch_key.lwe.a == ck.ks_a).all()
+    assert (cloud.keyswitch_key.lwe.b == ck.ks_b).all()
+    assert (cloud.keyswitch_key.lwe.current_variances == ck.ks_cv).all()
+    # serialization round trip (test_api_high_level.py:58-110)
+    cloud2 = ctx.load_cloud_key(cloud.dumps())
+    assert cloud2 == cloud
+    sk2 = ctx.load_secret_key(sk.dumps())
+    assert sk2 == sk
+    ct = ctx.encrypt(sk, [True, False, True])
+    ct2 = ctx.load_ciphertext(ct.dumps())
+    assert ct2 == ct
+    vm = ctx.make_virtual_machine(cloud2)
+    assert (ctx.decrypt(sk2, vm.gate_nand(ct2, ct2)) == [False, True, False]).all()
+
+
+def test_config2_config3_full_size_properties(env, orc):
+    """BASELINE configs 2 and 3 (4096 bits): decrypted outputs equal the truth tables for every bit;
+    the first 32 ciphertexts equal the CPU path word for word; re-running gives identical output
+    (determinism of the atomics-based keyswitch)."""
+    H = env['H']; thr = env['thr']; vm = env['vm']; ctx = env['ctx']; sk = env['secret_key']; ck = env['ck']
+    rng = numpy.random.RandomState(7)
+    B = 4096
+    ms = [rng.randint(0, 2, size=(B,)).astype(bool) for _ in range(3)]
+    cs = [ctx.encrypt(sk, m) for m in ms]
+    r = vm.gate_nand(cs[0], cs[1])
+    assert (ctx.decrypt(sk, r) == ~(ms[0] & ms[1])).all()
+    exp = orc.gate('gate_nand', ck, tuple(x[:32] for x in H.ct_arrays(cs[0])[:2]),
+                   tuple(x[:32] for x in H.ct_arrays(cs[1])[:2]))
+    ra, rb, rcv = H.ct_arrays(r)
+    assert (ra[:32] == exp[0]).all() and (rb[:32] == exp[1]).all() and (rcv[:32] == exp[2]).all()
+    r2 = vm.gate_nand(cs[0], cs[1])
+    assert r2 == r
+    rm = vm.gate_mux(cs[0], cs[1], cs[2])
+    assert (ctx.decrypt(sk, rm) == numpy.where(ms[0], ms[1], ms[2])).all()
+    expm = orc.gate_mux(ck, *[tuple(x[:16] for x in H.ct_arrays(c)[:2]) for c in cs])
+    ma, mb, mcv = H.ct_arrays(rm)
+    assert (ma[:16] == expm[0]).all() and (mb[:16] == expm[1]).all()

@@ -1,0 +1,209 @@
+"""
+GPU parity tests, kernel granularity (the reference's differential-test structure: every kernel
+against its CPU reference function, exact equality for integers): HIP library through the C ABI
+vs (a) golden outputs of the REFERENCE's own CPU functions and (b) the oracle.
+"""
+
+import ctypes
+
+import numpy
+import pytest
+
+import golden_inputs as gi
+
+pytestmark = pytest.mark.gpu
+
+P = 2**64 - 2**32 + 1
+
+
+@pytest.fixture(scope='module')
+def thr():
+    from nufhe_amd.device import DeviceThread
+    t = DeviceThread(0)
+    yield t
+
+
+@pytest.fixture(scope='module')
+def H():
+    import gpu_helpers
+    return gpu_helpers
+
+
+def call(name, *args):
+    from nufhe_amd import _lib
+    _lib.call(name, *args)
+
+
+def ptr(t):
+    from nufhe_amd.device import ptr as p
+    return p(t)
+
+
+def _ntt(thr, H, fn, data, out_dtype):
+    d = H.dev(thr, data)
+    out = thr.array(data.shape, out_dtype)
+    call(fn, thr.handle, ptr(out), ptr(d), data.size // 1024)
+    thr.synchronize()
+    return H.host_u64(out) if out_dtype == numpy.uint64 else H.host(out)
+
+
+def test_ntt_vs_reference_golden(thr, H, golden, orc):
+    polys_i32, polys_ff = gi.ntt_inputs()
+    assert (_ntt(thr, H, "nufhe_ntt_forward_i32", polys_i32, numpy.uint64) == golden['ntt_forward_i32']).all()
+    assert (_ntt(thr, H, "nufhe_ntt_forward_u64", polys_ff, numpy.uint64) == golden['ntt_forward_u64']).all()
+    assert (_ntt(thr, H, "nufhe_ntt_inverse_i32", polys_ff, numpy.int32) == golden['ntt_inverse_i32']).all()
+    assert (_ntt(thr, H, "nufhe_ntt_inverse_u64", polys_ff, numpy.uint64) == golden['ntt_inverse_u64']).all()
+
+
+def test_ntt_batch_vs_oracle_and_product(thr, H, orc):
+    # test_computation.py:33-124 of the reference: exact transform, and transform-based negacyclic
+    # product == schoolbook, on a batch that spans many blocks (odd size: ragged last block)
+    rs = numpy.random.RandomState(31)
+    a = rs.randint(-2**31, 2**31, size=(1037, 1024), dtype=numpy.int32)
+    f = _ntt(thr, H, "nufhe_ntt_forward_i32", a, numpy.uint64)
+    assert (f == orc.ntt_forward(a)).all()
+    assert (_ntt(thr, H, "nufhe_ntt_inverse_i32", f, numpy.int32) == a).all()
+    b = rs.randint(-1000, 1000, size=(5, 1024)).astype(numpy.int32)
+    x = H.dev(thr, a[:35]); y = H.dev(thr, b)
+    out = thr.array((35, 1024), numpy.int32)
+    call("nufhe_poly_mul_i32", thr.handle, ptr(out), ptr(x), ptr(y), 35, 5)
+    exp = orc.poly_mul_schoolbook(a[:35], b[numpy.arange(35) % 5])
+    assert (H.host(out) == exp).all()
+
+
+def test_t32_to_phase(thr, H, golden):
+    x = gi.modswitch_inputs()
+    out = thr.array(x.shape, numpy.int32)
+    call("nufhe_t32_to_phase", thr.handle, ptr(out), ptr(H.dev(thr, x)), x.size, 2048)
+    assert (H.host(out) == golden['t32_to_phase']).all()
+
+
+def test_shift(thr, H, golden):
+    src, powers, N = gi.shift_inputs()['n1024']
+    for minus_one in (False, True):
+        for invert in (False, True):
+            out = thr.array(src.shape, numpy.int32)
+            call("nufhe_shift_torus_polynomial", thr.handle, ptr(out), ptr(H.dev(thr, src)),
+                 ptr(H.dev(thr, powers)), 1, 0, powers.size, 2, int(minus_one), int(invert))
+            assert (H.host(out) == golden['shift_n1024_m%d_i%d' % (minus_one, invert)]).all()
+    src, powers_arr, idx, N = gi.shift_view_inputs()
+    out = thr.array(src.shape, numpy.int32)
+    call("nufhe_shift_torus_polynomial", thr.handle, ptr(out), ptr(H.dev(thr, src)),
+         ptr(H.dev(thr, powers_arr)), powers_arr.shape[1], idx, powers_arr.shape[0], 2, 1, 0)
+    assert (H.host(out) == golden['shift_view']).all()
+
+
+def test_extract(thr, H, golden):
+    tl = gi.tlwe_extract_inputs()
+    ra = thr.array((2, 3, 1024), numpy.int32); rb = thr.array((2, 3), numpy.int32)
+    call("nufhe_tlwe_extract", thr.handle, ptr(ra), ptr(rb), ptr(H.dev(thr, tl)), 6)
+    assert (H.host(ra) == golden['tlwe_extract_a']).all() and (H.host(rb) == golden['tlwe_extract_b']).all()
+
+
+def test_lwe_linear_and_trivial(thr, H, golden):
+    from nufhe_amd import lwe as L
+    from nufhe_amd.api_low_level import NuFHEParameters
+    params = NuFHEParameters()
+    res, src = gi.linear_inputs()
+    for p, add in ((1, False), (-1, True), (2, True), (-2, True)):
+        r = H.ciphertext_from_arrays(thr, res); s = H.ciphertext_from_arrays(thr, src)
+        L._linear(thr, r, s, p, add)
+        ra, rb, rcv = H.ct_arrays(r)
+        assert (ra == golden['linear_p%d_add%d_a' % (p, add)]).all()
+        assert (rb == golden['linear_p%d_add%d_b' % (p, add)]).all()
+        assert (rcv == golden['linear_p%d_add%d_cv' % (p, add)]).all()
+    # broadcast of the source over a leading axis + strided destination view (test_lwe.py:216-294)
+    r = H.ciphertext_from_arrays(thr, res)
+    s1 = H.ciphertext_from_arrays(thr, tuple(x[0] for x in src))
+    L.lwe_add_to(thr, r[::2], s1)
+    ra, rb, rcv = H.ct_arrays(r)
+    exp_a = res[0].copy(); exp_a[::2] += src[0][0]
+    assert (ra == exp_a).all()
+    t = L.LweSampleArray.empty(thr, params.in_out_params, (5, 3))
+    L.lwe_noiseless_trivial_constant(thr, t, -123)
+    ta, tb, tcv = H.ct_arrays(t)
+    assert (ta == 0).all() and (tb == -123).all() and (tcv == 0).all()
+
+
+def _key_with_bk(thr, bk):
+    from nufhe_amd.bootstrap import NativeCloudKey
+    native = NativeCloudKey(thr, bk.shape[0])
+    bk = numpy.ascontiguousarray(bk, numpy.uint64)
+    call("nufhe_bk_upload_reference", native.handle, bk.ctypes.data_as(ctypes.c_void_p))
+    return native
+
+
+def test_bk_roundtrip_reference_format(thr, H):
+    rs = numpy.random.RandomState(33)
+    bk = rs.randint(0, P, size=(7, 2, 2, 2, 1024), dtype=numpy.uint64)
+    native = _key_with_bk(thr, bk)
+    back = numpy.empty_like(bk)
+    call("nufhe_bk_download_reference", native.handle, back.ctypes.data_as(ctypes.c_void_p))
+    assert (back == bk).all()
+
+
+def test_external_mul_vs_reference_golden(thr, H, golden):
+    # test_tgsw.py:118-154 of the reference
+    for full in (False, True):
+        accum, bk, row = gi.extmul_inputs(full_range=full)
+        native = _key_with_bk(thr, bk)
+        acc = H.dev(thr, accum)
+        call("nufhe_external_mul", thr.handle, native.handle, ptr(acc), row, 6)
+        assert (H.host(acc) == golden['tgsw_extmul_full' if full else 'tgsw_extmul']).all()
+
+
+def test_blind_rotate_vs_reference_golden(thr, H, golden):
+    acc0, bk, bara = gi.blind_rotate_inputs()
+    native = _key_with_bk(thr, bk)
+    acc = H.dev(thr, acc0)
+    call("nufhe_blind_rotate", thr.handle, native.handle, ptr(acc), ptr(H.dev(thr, bara)), bara.shape[1],
+         bk.shape[0], acc0.shape[0])
+    assert (H.host(acc) == golden['blind_rotate_acc']).all()
+    ra = thr.array((2, 1024), numpy.int32); rb = thr.array((2,), numpy.int32)
+    call("nufhe_tlwe_extract", thr.handle, ptr(ra), ptr(rb), ptr(acc), 2)
+    assert (H.host(ra) == golden['blind_rotate_ext_a']).all() and (H.host(rb) == golden['blind_rotate_ext_b']).all()
+
+
+def test_blind_rotate_batch_vs_oracle(thr, H, orc):
+    # odd batch (ragged last work-group), more rows
+    rs = numpy.random.RandomState(34)
+    B, n = 21, 9
+    bk = rs.randint(0, P, size=(n, 2, 2, 2, 1024), dtype=numpy.uint64)
+    acc0 = rs.randint(-2**31, 2**31, size=(B, 2, 1024), dtype=numpy.int32)
+    bara = rs.randint(0, 2048, size=(B, n)).astype(numpy.int32)
+    native = _key_with_bk(thr, bk)
+    acc = H.dev(thr, acc0)
+    call("nufhe_blind_rotate", thr.handle, native.handle, ptr(acc), ptr(H.dev(thr, bara)), n, n, B)
+    assert (H.host(acc) == orc.blind_rotate(acc0, bk, bara)).all()
+
+
+def test_keyswitch_vs_reference_golden(thr, H, golden):
+    # test_lwe.py:47-101 of the reference
+    from nufhe_amd import lwe as L
+    from nufhe_amd.api_low_level import NuFHEParameters, NuFHECloudKey
+    from nufhe_amd.bootstrap import NativeCloudKey
+    params = NuFHEParameters()
+    ks_a, ks_b, ks_cv, src_a, src_b = gi.keyswitch_inputs()
+    native = NativeCloudKey(thr, 500)
+    ks = L.LweKeyswitchKey(L.HostLweSampleArray(params.in_out_params, ks_a, ks_b, ks_cv))
+    NuFHECloudKey._attach_keyswitch(native, ks)
+    src = L.LweSampleArray(params.tgsw_params.tlwe_params.extracted_lweparams, H.dev(thr, src_a),
+                           H.dev(thr, src_b), thr.zeros(src_b.shape, numpy.float32))
+    res = L.LweSampleArray.empty(thr, params.in_out_params, src_b.shape)
+    L.lwe_keyswitch(thr, res, ks, src)
+    ra, rb, rcv = H.ct_arrays(res)
+    assert (ra == golden['ks_a']).all()
+    assert (rb == golden['ks_b']).all()
+    assert (rcv == golden['ks_cv']).all()
+
+
+def test_keyswitch_rejects_nonzero_base0(thr):
+    from nufhe_amd import lwe as L
+    from nufhe_amd.api_low_level import NuFHEParameters, NuFHECloudKey
+    from nufhe_amd.bootstrap import NativeCloudKey
+    params = NuFHEParameters()
+    ks_a = numpy.zeros((1024, 8, 4, 500), numpy.int32); ks_a[3, 1, 0, 7] = 1
+    ks = L.LweKeyswitchKey(L.HostLweSampleArray(
+        params.in_out_params, ks_a, numpy.zeros((1024, 8, 4), numpy.int32), numpy.zeros((1024, 8, 4), numpy.float32)))
+    with pytest.raises(ValueError):
+        NuFHECloudKey._attach_keyswitch(NativeCloudKey(thr, 500), ks)
