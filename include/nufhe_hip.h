@@ -13,7 +13,7 @@
  *  - all work is enqueued on the context's HIP stream; nothing synchronises unless stated.
  *  - scheme parameters are the reference's defaults (nufhe/api_low_level.py:49-61):
  *    N = 1024, k = 1 (tlwe_mask_size), l = 2, Bg = 2^10, keyswitch t = 8, base 4; the LWE size n
- *    (500) is a run-time argument, n <= 1024.
+ *    (500) is a run-time argument, n <= 512.
  */
 #ifndef NUFHE_HIP_H
 #define NUFHE_HIP_H
@@ -44,8 +44,11 @@ const char *nufhe_version(void);
 /* ---- device / context (replaces reikna.cluda Thread creation, api_high_level.py:130-181) ---- */
 int nufhe_device_count(int *count);
 int nufhe_device_name(int device, char *buf, size_t buflen);
-/* stream: an existing hipStream_t (e.g. torch's current stream) or NULL to create a private one */
-int nufhe_ctx_create(int device, void *stream, nufhe_ctx **ctx);
+/* own_stream == 0: enqueue on `stream`, an existing hipStream_t (e.g. torch's current stream; NULL is
+ * the device's default stream, which is what torch uses unless told otherwise) so that the caller's
+ * copies and the library's kernels are ordered; own_stream != 0: `stream` is ignored and a private
+ * non-blocking stream is created (the caller must synchronise through nufhe_ctx_synchronize). */
+int nufhe_ctx_create(int device, void *stream, int own_stream, nufhe_ctx **ctx);
 int nufhe_ctx_destroy(nufhe_ctx *ctx);
 int nufhe_ctx_synchronize(nufhe_ctx *ctx);
 int nufhe_ctx_device(nufhe_ctx *ctx, int *device);

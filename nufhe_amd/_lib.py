@@ -37,7 +37,7 @@ _pp = ctypes.POINTER(ctypes.c_void_p)
 PROTOTYPES = {
     "nufhe_device_count": [ctypes.POINTER(_int)],
     "nufhe_device_name": [_int, ctypes.c_char_p, ctypes.c_size_t],
-    "nufhe_ctx_create": [_int, _vp, _pp],
+    "nufhe_ctx_create": [_int, _vp, _int, _pp],
     "nufhe_ctx_destroy": [_vp],
     "nufhe_ctx_synchronize": [_vp],
     "nufhe_ctx_device": [_vp, ctypes.POINTER(_int)],

@@ -168,7 +168,7 @@ int nufhe_device_name(int device, char *buf, size_t buflen)
     return NUFHE_OK;
 }
 
-int nufhe_ctx_create(int device, void *stream, nufhe_ctx **out)
+int nufhe_ctx_create(int device, void *stream, int own_stream, nufhe_ctx **out)
 {
     if (!out) return fail(NUFHE_EINVAL, "null argument");
     int count = 0;
@@ -179,8 +179,8 @@ int nufhe_ctx_create(int device, void *stream, nufhe_ctx **out)
     HIP_TRY(hipSetDevice(device));
     nufhe_ctx *ctx = new nufhe_ctx();
     ctx->device = device;
-    if (stream) {
-        ctx->stream = (hipStream_t)stream;
+    if (!own_stream) {
+        ctx->stream = (hipStream_t)stream;   // NULL = the device's default stream
     } else {
         hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { delete ctx; return fail(NUFHE_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
@@ -206,7 +206,7 @@ int nufhe_ctx_destroy(nufhe_ctx *ctx)
 {
     if (!ctx) return NUFHE_OK;
     hipSetDevice(ctx->device);
-    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    hipStreamSynchronize(ctx->stream);
     if (ctx->d_tw1f) hipFree(ctx->d_tw1f);
     if (ctx->d_tw1i) hipFree(ctx->d_tw1i);
     if (ctx->ext_a.ptr) hipFree(ctx->ext_a.ptr);

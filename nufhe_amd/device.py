@@ -47,8 +47,10 @@ class DeviceThread:
         torch.cuda.set_device(self.device)
         self._torch_stream = torch.cuda.current_stream(self.device)
         handle = ctypes.c_void_p()
+        # kernels are enqueued on torch's current stream (handle 0 = the default stream), so torch's
+        # copies/allocations and the library's launches are ordered without extra synchronisation
         _lib.check(lib.nufhe_ctx_create(
-            self.device_index, ctypes.c_void_p(self._torch_stream.cuda_stream), ctypes.byref(handle)))
+            self.device_index, ctypes.c_void_p(self._torch_stream.cuda_stream), 0, ctypes.byref(handle)))
         self.handle = handle
         props = torch.cuda.get_device_properties(self.device)
         self.device_params = DeviceParams(props.name, props.multi_processor_count)

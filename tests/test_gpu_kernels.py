@@ -74,29 +74,33 @@ def test_ntt_batch_vs_oracle_and_product(thr, H, orc):
 def test_t32_to_phase(thr, H, golden):
     x = gi.modswitch_inputs()
     out = thr.array(x.shape, numpy.int32)
-    call("nufhe_t32_to_phase", thr.handle, ptr(out), ptr(H.dev(thr, x)), x.size, 2048)
+    d_x = H.dev(thr, x)
+    call("nufhe_t32_to_phase", thr.handle, ptr(out), ptr(d_x), x.size, 2048)
     assert (H.host(out) == golden['t32_to_phase']).all()
 
 
 def test_shift(thr, H, golden):
     src, powers, N = gi.shift_inputs()['n1024']
+    d_src = H.dev(thr, src); d_pow = H.dev(thr, powers)     # keep the device buffers alive
     for minus_one in (False, True):
         for invert in (False, True):
             out = thr.array(src.shape, numpy.int32)
-            call("nufhe_shift_torus_polynomial", thr.handle, ptr(out), ptr(H.dev(thr, src)),
-                 ptr(H.dev(thr, powers)), 1, 0, powers.size, 2, int(minus_one), int(invert))
+            call("nufhe_shift_torus_polynomial", thr.handle, ptr(out), ptr(d_src),
+                 ptr(d_pow), 1, 0, powers.size, 2, int(minus_one), int(invert))
             assert (H.host(out) == golden['shift_n1024_m%d_i%d' % (minus_one, invert)]).all()
     src, powers_arr, idx, N = gi.shift_view_inputs()
+    d_src = H.dev(thr, src); d_pow = H.dev(thr, powers_arr)
     out = thr.array(src.shape, numpy.int32)
-    call("nufhe_shift_torus_polynomial", thr.handle, ptr(out), ptr(H.dev(thr, src)),
-         ptr(H.dev(thr, powers_arr)), powers_arr.shape[1], idx, powers_arr.shape[0], 2, 1, 0)
+    call("nufhe_shift_torus_polynomial", thr.handle, ptr(out), ptr(d_src),
+         ptr(d_pow), powers_arr.shape[1], idx, powers_arr.shape[0], 2, 1, 0)
     assert (H.host(out) == golden['shift_view']).all()
 
 
 def test_extract(thr, H, golden):
     tl = gi.tlwe_extract_inputs()
     ra = thr.array((2, 3, 1024), numpy.int32); rb = thr.array((2, 3), numpy.int32)
-    call("nufhe_tlwe_extract", thr.handle, ptr(ra), ptr(rb), ptr(H.dev(thr, tl)), 6)
+    d_tl = H.dev(thr, tl)
+    call("nufhe_tlwe_extract", thr.handle, ptr(ra), ptr(rb), ptr(d_tl), 6)
     assert (H.host(ra) == golden['tlwe_extract_a']).all() and (H.host(rb) == golden['tlwe_extract_b']).all()
 
 
@@ -155,8 +159,8 @@ def test_external_mul_vs_reference_golden(thr, H, golden):
 def test_blind_rotate_vs_reference_golden(thr, H, golden):
     acc0, bk, bara = gi.blind_rotate_inputs()
     native = _key_with_bk(thr, bk)
-    acc = H.dev(thr, acc0)
-    call("nufhe_blind_rotate", thr.handle, native.handle, ptr(acc), ptr(H.dev(thr, bara)), bara.shape[1],
+    acc = H.dev(thr, acc0); d_bara = H.dev(thr, bara)
+    call("nufhe_blind_rotate", thr.handle, native.handle, ptr(acc), ptr(d_bara), bara.shape[1],
          bk.shape[0], acc0.shape[0])
     assert (H.host(acc) == golden['blind_rotate_acc']).all()
     ra = thr.array((2, 1024), numpy.int32); rb = thr.array((2,), numpy.int32)
@@ -172,8 +176,8 @@ def test_blind_rotate_batch_vs_oracle(thr, H, orc):
     acc0 = rs.randint(-2**31, 2**31, size=(B, 2, 1024), dtype=numpy.int32)
     bara = rs.randint(0, 2048, size=(B, n)).astype(numpy.int32)
     native = _key_with_bk(thr, bk)
-    acc = H.dev(thr, acc0)
-    call("nufhe_blind_rotate", thr.handle, native.handle, ptr(acc), ptr(H.dev(thr, bara)), n, n, B)
+    acc = H.dev(thr, acc0); d_bara = H.dev(thr, bara)
+    call("nufhe_blind_rotate", thr.handle, native.handle, ptr(acc), ptr(d_bara), n, n, B)
     assert (H.host(acc) == orc.blind_rotate(acc0, bk, bara)).all()
 
 
