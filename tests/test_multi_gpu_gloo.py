@@ -1,0 +1,81 @@
+"""
+N > 1 path on CPU: world_size-2 gloo processes exercise the sharding / gather layer that
+bench.py --gpus N and the multi-GPU example use (nufhe_amd/multi_gpu.py).  The per-rank "gate" is
+a stand-in integer function of the inputs (the real gate needs a GPU); what is tested is that the
+shards partition the batch and that the gathered result equals the unsharded computation, for even
+and ragged batch sizes.
+"""
+
+import os
+import socket
+import sys
+
+import numpy
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _fake_gate(a, b):
+    # any deterministic int32 elementwise function of the two "ciphertexts"
+    return (a * 3 - b * 5 + 7).to(torch.int32)
+
+
+def _worker(rank, world, port, nbits, results):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from nufhe_amd import multi_gpu
+    g = torch.Generator().manual_seed(1234)     # same data on every rank (replicated inputs)
+    a = torch.randint(-2**31, 2**31 - 1, (nbits, 500), dtype=torch.int32, generator=g)
+    b = torch.randint(-2**31, 2**31 - 1, (nbits,), dtype=torch.int32, generator=g)
+    a2 = torch.randint(-2**31, 2**31 - 1, (nbits, 500), dtype=torch.int32, generator=g)
+    b2 = torch.randint(-2**31, 2**31 - 1, (nbits,), dtype=torch.int32, generator=g)
+    lo, hi = multi_gpu.shard_bounds(nbits, world, rank)
+    local = (_fake_gate(a[lo:hi], a2[lo:hi]), _fake_gate(b[lo:hi], b2[lo:hi]),
+             torch.full((hi - lo,), float(rank)))
+    full = multi_gpu.gather_arrays(local, nbits)
+    ok = bool((full[0] == _fake_gate(a, a2)).all() and (full[1] == _fake_gate(b, b2)).all())
+    owners = full[2].to(torch.int64)
+    expect_owner = torch.cat([torch.full((multi_gpu.shard_bounds(nbits, world, r)[1]
+                                          - multi_gpu.shard_bounds(nbits, world, r)[0],), r) for r in range(world)])
+    ok = ok and bool((owners == expect_owner).all())
+    results[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('nbits', [64, 37])
+def test_shard_and_gather_world2(nbits):
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_worker, args=(world, port, nbits, results), nprocs=world, join=True)
+    assert all(results.get(r) for r in range(world)), dict(results)
+
+
+def test_shard_bounds_partition():
+    sys.path.insert(0, ROOT)
+    from nufhe_amd.multi_gpu import shard_bounds
+    for nbits in (0, 1, 7, 32, 4096, 32768, 1001):
+        for world in (1, 2, 3, 8):
+            bounds = [shard_bounds(nbits, world, r) for r in range(world)]
+            assert bounds[0][0] == 0 and bounds[-1][1] == nbits
+            assert all(bounds[i][1] == bounds[i + 1][0] for i in range(world - 1))
+            sizes = [h - l for l, h in bounds]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(10, 2, 2)
