@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--gate", choices=["nand", "mux"], default="nand")
     ap.add_argument("--bits", type=int, default=4096, help="bits per GPU")
+    ap.add_argument("--transform", choices=["NTT", "FFT"], default="NTT",
+                    help="NTT = BASELINE configs 2-4 (bit-exact path); FFT = config 5 (fp64, tolerance path)")
     ap.add_argument("--cpu-sample-bits", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -83,7 +85,7 @@ def main():
 
     thr = DeviceThread(local_rank)
     ctx = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(123), thread=thr)
-    secret_key, cloud_key = ctx.make_key_pair()          # replicated on every rank (98.6 MB)
+    secret_key, cloud_key = ctx.make_key_pair(transform_type=args.transform)   # replicated on every rank (98.6 MB)
     vm = ctx.make_virtual_machine(cloud_key)
 
     B = args.bits
@@ -92,10 +94,7 @@ def main():
     ctx.rng = nufhe_amd.DeterministicRNG(1000 + rank)
     cs = [ctx.encrypt(secret_key, m) for m in ms]
     out = vm.empty_ciphertext((B,))
-    gathered = None
-    if world > 1:
-        gathered = [torch.empty((world * B, 500), dtype=torch.int32, device=thr.device),
-                    torch.empty((world * B,), dtype=torch.int32, device=thr.device)]
+    from nufhe_amd import multi_gpu
 
     def step():
         if args.gate == "mux":
@@ -103,8 +102,8 @@ def main():
         else:
             vm.gate_nand(cs[0], cs[1], dest=out)
         if world > 1:
-            dist.all_gather_into_tensor(gathered[0], out.a)
-            dist.all_gather_into_tensor(gathered[1], out.b)
+            # the result gather of examples/multi_gpu.py, here one RCCL all_gather per array
+            multi_gpu.gather_ciphertext(out, world * B)
 
     import ctypes
     lib = _lib.lib()
@@ -147,7 +146,8 @@ def main():
         achieved = a_kernel / (br_avg * 1e-3) / 1e9
         a_gate = (A_MUX if args.gate == "mux" else A_NAND) * B
         result = {
-            "metric": "bootstrapped gates/sec (%s), 4096-bit batch per GPU, NTT, n=500 N=1024 k=1 l=2" % args.gate.upper(),
+            "metric": "bootstrapped gates/sec (%s), 4096-bit batch per GPU, %s, n=500 N=1024 k=1 l=2" % (
+                args.gate.upper(), args.transform),
             "value": gates_per_s,
             "unit": "gates/s",
             "n_gpus": world,
@@ -158,14 +158,17 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u64 mod 2^64-2^32+1 (NTT) / int32 torus",
+            "dtype": ("u64 mod 2^64-2^32+1 (NTT) / int32 torus" if args.transform == "NTT"
+                      else "f64 complex (folded FFT-512) / int32 torus"),
             "data": "synthetic (seeded keys and ciphertexts, resident in HBM)",
             "correct": correct,
             "config": {"workload": "gate_%s, %d-bit batch per GPU (BASELINE config %s)" % (
-                args.gate, B, "3" if args.gate == "mux" else ("2" if world == 1 else "4")),
-                "bits_per_gpu": B, "transform": "NTT", "parallelism": "bits sharded over %d GPU(s), keys replicated" % world},
+                args.gate, B, "5" if args.transform == "FFT" else (
+                    "3" if args.gate == "mux" else ("2" if world == 1 else "4"))),
+                "bits_per_gpu": B, "transform": args.transform, "parallelism": "bits sharded over %d GPU(s), keys replicated" % world},
             "roofline": {
-                "bound": "hbm", "kernel": "k_bootstrap (fused mod-switch + blind rotate + extract)",
+                "bound": "hbm", "kernel": "k_bootstrap%s (fused mod-switch + blind rotate + extract)" % (
+                    "_fft" if args.transform == "FFT" else ""),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
                 "kernel_ms": br_avg, "keyswitch_ms": ks_avg,

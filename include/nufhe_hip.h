@@ -31,6 +31,9 @@ extern "C" {
 #define NUFHE_ENODEV (-3)   /* no usable GPU */
 #define NUFHE_ENOKEY (-4)   /* key part not uploaded */
 
+#define NUFHE_TRANSFORM_NTT 0   /* negacyclic NTT-1024 over 2^64 - 2^32 + 1 (bit-exact path) */
+#define NUFHE_TRANSFORM_FFT 1   /* fp64 folded FFT-512 (polynomial_transform_fft.py), tolerance path */
+
 #define NUFHE_N 1024        /* TLWE polynomial degree */
 #define NUFHE_KS_T 8        /* keyswitch decomposition length */
 #define NUFHE_KS_BASE 4     /* keyswitch base */
@@ -61,14 +64,17 @@ int nufhe_h2d(nufhe_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);   /
 int nufhe_d2h(nufhe_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);   /* synchronous */
 
 /* ---- cloud key (BootstrapKey bootstrap.py:44-92, LweKeyswitchKey lwe.py:254-308) ---- */
-int nufhe_cloudkey_create(nufhe_ctx *ctx, int lwe_size, nufhe_cloudkey **key);
+/* transform: NUFHE_TRANSFORM_NTT or NUFHE_TRANSFORM_FFT (NuFHEParameters(transform_type=...),
+ * api_low_level.py:44-47): fixes the domain the bootstrapping key is stored in. */
+int nufhe_cloudkey_create(nufhe_ctx *ctx, int lwe_size, int transform, nufhe_cloudkey **key);
 int nufhe_cloudkey_destroy(nufhe_cloudkey *key);
-/* Bootstrapping key in the REFERENCE's storage format: u64 [n][2][2][2][1024], natural-order NTT,
- * Montgomery-prepared (x * 2^64), as produced by TLweTransformSamples (tlwe_gpu.py:199-236) and
- * pickled by BootstrapKey.dump (bootstrap.py:78-80).  Host pointer. */
-int nufhe_bk_upload_reference(nufhe_cloudkey *key, const uint64_t *h_bk);
-/* Inverse of the above (for BootstrapKey.dump): writes u64 [n][2][2][2][1024] to the host. */
-int nufhe_bk_download_reference(nufhe_cloudkey *key, uint64_t *h_bk);
+/* Bootstrapping key in the REFERENCE's storage format, as produced by TLweTransformSamples
+ * (tlwe_gpu.py:199-236) and pickled by BootstrapKey.dump (bootstrap.py:78-80).  Host pointer.
+ *   NTT key: uint64 [n][2][2][2][1024], natural-order NTT, Montgomery-prepared (x * 2^64)
+ *   FFT key: complex128 [n][2][2][2][512], natural-order folded FFT (fft_transform_ref) */
+int nufhe_bk_upload_reference(nufhe_cloudkey *key, const void *h_bk);
+/* Inverse of the above (for BootstrapKey.dump): writes the same format to the host. */
+int nufhe_bk_download_reference(nufhe_cloudkey *key, void *h_bk);
 /* Bootstrapping key from coefficient-domain TGSW samples, int32 [n][2][2][2][1024] on the DEVICE
  * (replaces tgsw_transform_samples, tgsw.py:135-138). */
 int nufhe_bk_from_coeffs(nufhe_cloudkey *key, const int32_t *d_tgsw);
@@ -131,6 +137,10 @@ int nufhe_ntt_forward_i32(nufhe_ctx *ctx, uint64_t *d_out, const int32_t *d_in, 
 int nufhe_ntt_forward_u64(nufhe_ctx *ctx, uint64_t *d_out, const uint64_t *d_in, long batch);
 int nufhe_ntt_inverse_i32(nufhe_ctx *ctx, int32_t *d_out, const uint64_t *d_in, long batch);
 int nufhe_ntt_inverse_u64(nufhe_ctx *ctx, uint64_t *d_out, const uint64_t *d_in, long batch);
+/* Folded FFT-512 (transform/fft.py:27-51, i32_conversion=True): forward int32 [batch][1024] ->
+ * complex128 [batch][512] (re, im interleaved), natural order; inverse rounds to nearest. */
+int nufhe_fft_forward_i32(nufhe_ctx *ctx, double *d_out, const int32_t *d_in, long batch);
+int nufhe_fft_inverse_i32(nufhe_ctx *ctx, int32_t *d_out, const double *d_in, long batch);
 /* Negacyclic product mod 2^32 of int32 polynomials through the NTT: out[b] = x[b] * y[b % y_batch] */
 int nufhe_poly_mul_i32(nufhe_ctx *ctx, int32_t *d_out, const int32_t *d_x, const int32_t *d_y,
                        long batch, long y_batch);

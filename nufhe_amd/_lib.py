@@ -45,7 +45,7 @@ PROTOTYPES = {
     "nufhe_free": [_vp, _vp],
     "nufhe_h2d": [_vp, _vp, _vp, ctypes.c_size_t],
     "nufhe_d2h": [_vp, _vp, _vp, ctypes.c_size_t],
-    "nufhe_cloudkey_create": [_vp, _int, _pp],
+    "nufhe_cloudkey_create": [_vp, _int, _int, _pp],
     "nufhe_cloudkey_destroy": [_vp],
     "nufhe_bk_upload_reference": [_vp, _vp],
     "nufhe_bk_download_reference": [_vp, _vp],
@@ -65,6 +65,8 @@ PROTOTYPES = {
     "nufhe_ntt_inverse_i32": [_vp, _vp, _vp, _long],
     "nufhe_ntt_inverse_u64": [_vp, _vp, _vp, _long],
     "nufhe_poly_mul_i32": [_vp, _vp, _vp, _vp, _long, _long],
+    "nufhe_fft_forward_i32": [_vp, _vp, _vp, _long],
+    "nufhe_fft_inverse_i32": [_vp, _vp, _vp, _long],
     "nufhe_external_mul": [_vp, _vp, _vp, _int, _long],
     "nufhe_blind_rotate": [_vp, _vp, _vp, _vp, _long, _int, _long],
     "nufhe_tlwe_encrypt_zero": [_vp, _vp, _vp, _vp, _vp, _long],

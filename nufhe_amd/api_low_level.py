@@ -20,16 +20,14 @@ class NuFHEParameters:
     Parameters of the FHE scheme (nufhe/api_low_level.py:31-87); the defaults correspond to about
     128 bits of security.
 
-    :param transform_type: ``'NTT'`` (64-bit-prime number-theoretic transform).  ``'FFT'`` is
-        accepted by the reference; this build implements the NTT path only (BASELINE config 5 is
-        scheduled after the NTT path meets its bar) and raises NotImplementedError for 'FFT'.
+    :param transform_type: ``'NTT'`` (64-bit-prime number-theoretic transform, bit-exact) or
+        ``'FFT'`` (fp64 folded FFT, faster; results equal the exact ones unless an fp64 rounding
+        error reaches half a torus LSB -- see DESIGN.md for the stated tolerance).
     """
 
     def __init__(self, transform_type='NTT', tlwe_mask_size=1):
         assert transform_type in ('FFT', 'NTT')
         assert tlwe_mask_size >= 1
-        if transform_type != 'NTT':
-            raise NotImplementedError("only transform_type='NTT' is implemented on gfx950 so far")
         if tlwe_mask_size != 1:
             raise NotImplementedError("only tlwe_mask_size=1 is implemented on gfx950 so far")
 
@@ -128,7 +126,7 @@ class NuFHECloudKey:
     def from_rng(cls, thr, params: NuFHEParameters, rng, secret_key: NuFHESecretKey, perf_params=None):
         """Generates a cloud key in the reference's RNG order (api_low_level.py:174-196):
         TGSW key, bootstrapping key, keyswitch key."""
-        native = NativeCloudKey(thr, params.in_out_params.size)
+        native = NativeCloudKey(thr, params.in_out_params.size, params._transform_type)
         tgsw_key = TGswKey.from_rng(thr, params.tgsw_params, rng)
         bk = BootstrapKey.from_rng(thr, rng, secret_key.lwe_key, tgsw_key, native, perf_params)
         ks = LweKeyswitchKey.from_tgsw_key(
@@ -149,7 +147,7 @@ class NuFHECloudKey:
     @classmethod
     def load(cls, file_obj, thr):
         params = pickle.load(file_obj)
-        native = NativeCloudKey(thr, params.in_out_params.size)
+        native = NativeCloudKey(thr, params.in_out_params.size, params._transform_type)
         bootstrap_key = BootstrapKey.load(file_obj, thr, native)
         keyswitch_key = LweKeyswitchKey.load(file_obj, thr)
         cls._attach_keyswitch(native, keyswitch_key)

@@ -22,10 +22,14 @@ from .utils import arrays_equal
 class NativeCloudKey:
     """Owner of the device copies of the bootstrapping key (wave layout) and the keyswitch key."""
 
-    def __init__(self, thr, lwe_size):
+    TRANSFORMS = {'NTT': 0, 'FFT': 1}
+
+    def __init__(self, thr, lwe_size, transform_type='NTT'):
         self.thr = thr
+        self.transform_type = transform_type
         handle = ctypes.c_void_p()
-        _lib.call("nufhe_cloudkey_create", thr.handle, int(lwe_size), ctypes.byref(handle))
+        _lib.call("nufhe_cloudkey_create", thr.handle, int(lwe_size), self.TRANSFORMS[transform_type],
+                  ctypes.byref(handle))
         self.handle = handle
 
     def __del__(self):
@@ -65,11 +69,13 @@ class BootstrapKey:
         return cls(in_out_params, bk_params, native)
 
     def transformed_reference_format(self):
-        """Host uint64 array [n, k+1, l, k+1, N]: the reference's storage format."""
+        """Host array in the reference's storage format: uint64 [n, k+1, l, k+1, N] (NTT) or
+        complex128 [n, k+1, l, k+1, N/2] (FFT)."""
         k1 = self.bk_params.tlwe_params.mask_size + 1
-        shape = (self.in_out_params.size, k1, self.bk_params.decomp_length, k1,
-                 self.bk_params.tlwe_params.polynomial_degree)
-        out = numpy.empty(shape, numpy.uint64)
+        N = self.bk_params.tlwe_params.polynomial_degree
+        fft = self.bk_params.tlwe_params.transform_type == 'FFT'
+        shape = (self.in_out_params.size, k1, self.bk_params.decomp_length, k1, N // 2 if fft else N)
+        out = numpy.empty(shape, numpy.complex128 if fft else numpy.uint64)
         _lib.call("nufhe_bk_download_reference", self._native.handle, out.ctypes.data_as(ctypes.c_void_p))
         return out
 
@@ -82,7 +88,8 @@ class BootstrapKey:
     def load(cls, file_obj, thr, native: NativeCloudKey):
         in_out_params = pickle.load(file_obj)
         bk_params = pickle.load(file_obj)
-        arr = numpy.ascontiguousarray(pickle.load(file_obj), numpy.uint64)
+        fft = bk_params.tlwe_params.transform_type == 'FFT'
+        arr = numpy.ascontiguousarray(pickle.load(file_obj), numpy.complex128 if fft else numpy.uint64)
         _lib.call("nufhe_bk_upload_reference", native.handle, arr.ctypes.data_as(ctypes.c_void_p))
         return cls(in_out_params, bk_params, native)
 

@@ -49,6 +49,8 @@ struct nufhe_ctx {
     bool own_stream = false;
     u64 *d_tw1f = nullptr;
     u64 *d_tw1i = nullptr;
+    cplx *d_ftw1 = nullptr;
+    cplx *d_ftw2 = nullptr;
     Scratch ext_a, ext_b, ks_acc;
     bool profile = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -58,7 +60,8 @@ struct nufhe_ctx {
 struct nufhe_cloudkey {
     nufhe_ctx *ctx = nullptr;
     int n = 0;
-    u64 *d_bk = nullptr;      // wave layout [n][8][1024]
+    int transform = 0;        // 0 = NTT (u64 residues), 1 = FFT (complex128)
+    void *d_bk = nullptr;     // wave layout: u64 [n][8][1024] or complex128 [n][8][512] (same bytes)
     i32 *d_ks_a3 = nullptr;   // [1024][8][3][n]
     i32 *d_ks_b = nullptr;    // [1024][8][4]
     float *d_ks_cv = nullptr; // [1024][8][4]
@@ -192,6 +195,12 @@ int nufhe_ctx_create(int device, void *stream, int own_stream, nufhe_ctx **out)
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_tw1i, 1024 * sizeof(u64));
     if (e == hipSuccess) e = hipMemcpy(ctx->d_tw1f, f.data(), 1024 * sizeof(u64), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ctx->d_tw1i, i.data(), 1024 * sizeof(u64), hipMemcpyHostToDevice);
+    std::vector<cplx> g1(FFT_TW1_ELEMS), g2(FFT_TW2_ELEMS);
+    fft_make_tables(g1.data(), g2.data());
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_ftw1, FFT_TW1_ELEMS * sizeof(cplx));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_ftw2, FFT_TW2_ELEMS * sizeof(cplx));
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_ftw1, g1.data(), FFT_TW1_ELEMS * sizeof(cplx), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_ftw2, g2.data(), FFT_TW2_ELEMS * sizeof(cplx), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = kernels_init_device();
     for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipEventCreate(&ctx->ev[k]);
     if (e != hipSuccess) {
@@ -209,6 +218,8 @@ int nufhe_ctx_destroy(nufhe_ctx *ctx)
     hipStreamSynchronize(ctx->stream);
     if (ctx->d_tw1f) hipFree(ctx->d_tw1f);
     if (ctx->d_tw1i) hipFree(ctx->d_tw1i);
+    if (ctx->d_ftw1) hipFree(ctx->d_ftw1);
+    if (ctx->d_ftw2) hipFree(ctx->d_ftw2);
     if (ctx->ext_a.ptr) hipFree(ctx->ext_a.ptr);
     if (ctx->ext_b.ptr) hipFree(ctx->ext_b.ptr);
     if (ctx->ks_acc.ptr) hipFree(ctx->ks_acc.ptr);
@@ -274,16 +285,19 @@ int nufhe_d2h(nufhe_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
 
 // ---- cloud key ---------------------------------------------------------------------------
 
-int nufhe_cloudkey_create(nufhe_ctx *ctx, int lwe_size, nufhe_cloudkey **key)
+int nufhe_cloudkey_create(nufhe_ctx *ctx, int lwe_size, int transform, nufhe_cloudkey **key)
 {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (!key) return fail(NUFHE_EINVAL, "null argument");
+    if (transform != NUFHE_TRANSFORM_NTT && transform != NUFHE_TRANSFORM_FFT)
+        return fail(NUFHE_EINVAL, "unknown transform %d", transform);
     if (lwe_size < 1 || lwe_size > BR_MAX_LWE)
         return fail(NUFHE_EINVAL, "lwe_size %d out of range [1, %d]", lwe_size, BR_MAX_LWE);
     nufhe_cloudkey *k = new nufhe_cloudkey();
     k->ctx = ctx;
     k->n = lwe_size;
+    k->transform = transform;
     *key = k;
     return NUFHE_OK;
 }
@@ -307,7 +321,7 @@ static int alloc_bk(nufhe_cloudkey *key)
     return NUFHE_OK;
 }
 
-int nufhe_bk_upload_reference(nufhe_cloudkey *key, const uint64_t *h_bk)
+int nufhe_bk_upload_reference(nufhe_cloudkey *key, const void *h_bk)
 {
     if (!key || !h_bk) return fail(NUFHE_EINVAL, "null argument");
     nufhe_ctx *ctx = key->ctx;
@@ -319,14 +333,17 @@ int nufhe_bk_upload_reference(nufhe_cloudkey *key, const uint64_t *h_bk)
     u64 *tmp = nullptr;
     HIP_TRY(hipMalloc((void **)&tmp, bytes));
     hipError_t e = hipMemcpyAsync(tmp, h_bk, bytes, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = launch_bk_from_reference(key->d_bk, tmp, (long)key->n * 8, ctx->stream);
+    if (e == hipSuccess)
+        e = key->transform == NUFHE_TRANSFORM_NTT
+                ? launch_bk_from_reference((u64 *)key->d_bk, tmp, (long)key->n * 8, ctx->stream)
+                : launch_bkf_permute((cplx *)key->d_bk, (const cplx *)tmp, (long)key->n * 8, 0, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     hipFree(tmp);
     if (e != hipSuccess) return fail(NUFHE_EHIP, "bk upload: %s", hipGetErrorString(e));
     return NUFHE_OK;
 }
 
-int nufhe_bk_download_reference(nufhe_cloudkey *key, uint64_t *h_bk)
+int nufhe_bk_download_reference(nufhe_cloudkey *key, void *h_bk)
 {
     if (!key || !h_bk) return fail(NUFHE_EINVAL, "null argument");
     nufhe_ctx *ctx = key->ctx;
@@ -335,7 +352,9 @@ int nufhe_bk_download_reference(nufhe_cloudkey *key, uint64_t *h_bk)
     const size_t bytes = (size_t)key->n * BK_ROW_ELEMS * sizeof(u64);
     u64 *tmp = nullptr;
     HIP_TRY(hipMalloc((void **)&tmp, bytes));
-    hipError_t e = launch_bk_to_reference(tmp, key->d_bk, (long)key->n * 8, ctx->stream);
+    hipError_t e = key->transform == NUFHE_TRANSFORM_NTT
+                       ? launch_bk_to_reference(tmp, (const u64 *)key->d_bk, (long)key->n * 8, ctx->stream)
+                       : launch_bkf_permute((cplx *)tmp, (const cplx *)key->d_bk, (long)key->n * 8, 1, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(h_bk, tmp, bytes, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     hipFree(tmp);
@@ -351,7 +370,10 @@ int nufhe_bk_from_coeffs(nufhe_cloudkey *key, const int32_t *d_tgsw)
     if (rc) return rc;
     rc = alloc_bk(key);
     if (rc) return rc;
-    HIP_TRY(launch_bk_from_coeffs(key->d_bk, d_tgsw, (long)key->n * 8, ctx->d_tw1f, ctx->d_tw1i, ctx->stream));
+    if (key->transform == NUFHE_TRANSFORM_NTT)
+        HIP_TRY(launch_bk_from_coeffs((u64 *)key->d_bk, d_tgsw, (long)key->n * 8, ctx->d_tw1f, ctx->d_tw1i, ctx->stream));
+    else
+        HIP_TRY(launch_bkf_from_coeffs((cplx *)key->d_bk, d_tgsw, (long)key->n * 8, ctx->d_ftw1, ctx->d_ftw2, ctx->stream));
     return NUFHE_OK;
 }
 
@@ -419,8 +441,9 @@ static int run_gate(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result
     P.bk = key->d_bk;
     P.n = key->n;
     P.mu = mu;
-    P.tw1f = ctx->d_tw1f;
-    P.tw1i = ctx->d_tw1i;
+    const bool fft = key->transform == NUFHE_TRANSFORM_FFT;
+    P.tw_a = fft ? (const void *)ctx->d_ftw1 : (const void *)ctx->d_tw1f;
+    P.tw_b = fft ? (const void *)ctx->d_ftw2 : (const void *)ctx->d_tw1i;
     if (keyswitch) {
         int rc = ensure(ctx, ctx->ext_a, (size_t)total * 1024 * sizeof(i32));
         if (rc) return rc;
@@ -433,7 +456,7 @@ static int run_gate(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result
         P.out_b = result.b; P.out_b_stride = result.b_stride;
     }
     if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-    HIP_TRY(launch_bootstrap(P, ctx->stream));
+    HIP_TRY(launch_bootstrap(P, key->transform, ctx->stream));
     if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     if (keyswitch) {
         const i32 *ea = (const i32 *)ctx->ext_a.ptr, *eb = (const i32 *)ctx->ext_b.ptr;
@@ -565,6 +588,22 @@ int nufhe_ntt_inverse_u64(nufhe_ctx *ctx, uint64_t *d_out, const uint64_t *d_in,
     return NUFHE_OK;
 }
 
+int nufhe_fft_forward_i32(nufhe_ctx *ctx, double *d_out, const int32_t *d_in, long batch)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(launch_fft_forward((cplx *)d_out, d_in, batch, ctx->d_ftw1, ctx->d_ftw2, ctx->stream));
+    return NUFHE_OK;
+}
+
+int nufhe_fft_inverse_i32(nufhe_ctx *ctx, int32_t *d_out, const double *d_in, long batch)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(launch_fft_inverse(d_out, (const cplx *)d_in, batch, ctx->d_ftw1, ctx->d_ftw2, ctx->stream));
+    return NUFHE_OK;
+}
+
 int nufhe_poly_mul_i32(nufhe_ctx *ctx, int32_t *d_out, const int32_t *d_x, const int32_t *d_y, long batch, long y_batch)
 {
     int rc = check_ctx(ctx);
@@ -579,7 +618,10 @@ int nufhe_external_mul(nufhe_ctx *ctx, nufhe_cloudkey *key, int32_t *d_accum, in
     int rc = check_key(ctx, key, true, false);
     if (rc) return rc;
     if (bk_row < 0 || bk_row >= key->n) return fail(NUFHE_EINVAL, "bk_row %d out of range", bk_row);
-    HIP_TRY(launch_blind_rotate_accum(d_accum, key->d_bk, nullptr, 0, bk_row, 1, 1, batch, ctx->d_tw1f, ctx->d_tw1i,
+    const bool fft = key->transform == NUFHE_TRANSFORM_FFT;
+    HIP_TRY(launch_blind_rotate_accum(d_accum, key->d_bk, nullptr, 0, bk_row, 1, 1, batch,
+                                      fft ? (const void *)ctx->d_ftw1 : (const void *)ctx->d_tw1f,
+                                      fft ? (const void *)ctx->d_ftw2 : (const void *)ctx->d_tw1i, key->transform,
                                       ctx->stream));
     return NUFHE_OK;
 }
@@ -590,8 +632,11 @@ int nufhe_blind_rotate(nufhe_ctx *ctx, nufhe_cloudkey *key, int32_t *d_accum, co
     int rc = check_key(ctx, key, true, false);
     if (rc) return rc;
     if (n_rows < 0 || n_rows > key->n) return fail(NUFHE_EINVAL, "n_rows %d out of range", n_rows);
-    HIP_TRY(launch_blind_rotate_accum(d_accum, key->d_bk, d_bara, bara_stride, 0, n_rows, 0, batch, ctx->d_tw1f,
-                                      ctx->d_tw1i, ctx->stream));
+    const bool fft = key->transform == NUFHE_TRANSFORM_FFT;
+    HIP_TRY(launch_blind_rotate_accum(d_accum, key->d_bk, d_bara, bara_stride, 0, n_rows, 0, batch,
+                                      fft ? (const void *)ctx->d_ftw1 : (const void *)ctx->d_tw1f,
+                                      fft ? (const void *)ctx->d_ftw2 : (const void *)ctx->d_tw1i, key->transform,
+                                      ctx->stream));
     return NUFHE_OK;
 }
 

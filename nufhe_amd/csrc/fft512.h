@@ -1,0 +1,218 @@
+// fft512.h -- fp64 negacyclic "folded" FFT of a degree-1024 torus polynomial: 512 complex points,
+// one wavefront per polynomial, 8 complex values per lane.
+//
+// Replaces the reference's fft512 device module (nufhe/transform/fft.mako:18-355: 64 threads x 8
+// values, three radix-8 passes, 8 barriers per transform).  Same transform as fft_transform_ref
+// (nufhe/transform/fft.py:27-51, doc/source/implementation_details.rst:25-64):
+//
+//   forward: X_k = sum_{j<512} (a_j - i a_{j+512}) w^j W^(jk),  w = exp(-i pi/1024), W = w^4
+//   inverse: a_j = round Re(y_j), a_{j+512} = round -Im(y_j),  y_j = conj(w^j)/512 sum_k X_k conj(W)^(jk)
+//
+// Factorisation 512 = 8 x 8 x 8 with j = j1 + 64 j2 (lane j1, register j2), k = k2 + 8 (c + 8 d):
+//   pass 1 (in lane, j2 -> k2): inputs pre-multiplied by the compile-time constants w^(64 j2), 8-point DFT
+//   twiddle 1 (table, 512 entries): w^(j1 (1 + 4 k2))   -- carries the per-lane part w^j1 of the fold twist
+//   exchange 1 (LDS): lane (k2, a), register b, j1 = a + 8 b
+//   pass 2 (in lane, b -> c): 8-point DFT;  twiddle 2 (table, 64 entries): V^(a c), V = W^8
+//   exchange 2 (LDS): lane (k2, c), register a
+//   pass 3 (in lane, a -> d): 8-point DFT
+// The result stays in this wave layout (lane L = 8 k2 + c, register d); the FFT-domain bootstrapping
+// key is stored in the same layout.  The inverse runs the passes backwards with conjugated twiddles.
+// Coefficient ownership matches ntt1024.h: lane l holds coefficients l + 64 r, r = 0..15
+// (r < 8: real parts, r >= 8: imaginary parts), so the blind-rotate body is shared.
+//
+// Exchange buffer: 8 rows x 72 complex (16-byte slots); the 8-slot row padding and the (a + c) & 7
+// rotation make every ds_write_b128 / ds_read_b128 conflict-free.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include "ff.h"
+#include "ntt1024.h"   // WAVE_SYNC
+
+struct alignas(16) cplx {
+    double re, im;
+};
+
+#define FFT_ROW 72
+#define FFT_XBUF_ELEMS (8 * FFT_ROW)      /* 576 complex = 9216 bytes per wave */
+#define FFT_TW1_ELEMS 512                 /* [k2][j1] */
+#define FFT_TW2_ELEMS 64                  /* [c][a]   */
+
+FF_FN cplx c_add(cplx a, cplx b) { return cplx{a.re + b.re, a.im + b.im}; }
+FF_FN cplx c_sub(cplx a, cplx b) { return cplx{a.re - b.re, a.im - b.im}; }
+FF_FN cplx c_mul(cplx a, cplx b) { return cplx{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+FF_FN cplx c_mul_conj(cplx a, cplx b) { return cplx{a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im}; }  // a * conj(b)
+FF_FN cplx c_mul_mi(cplx a) { return cplx{a.im, -a.re}; }   // a * (-i)
+FF_FN cplx c_mul_pi(cplx a) { return cplx{-a.im, a.re}; }   // a * (+i)
+
+FF_FN constexpr int br3(int i) { return ((i & 1) << 2) | (i & 2) | ((i & 4) >> 2); }
+
+// natural-order frequency index held by (lane, reg) after fft_forward
+FF_FN constexpr int fft_freq_index(int lane, int reg) { return (lane >> 3) + 8 * ((lane & 7) + 8 * reg); }
+
+// element offset of (lane, reg) inside one FFT-domain key polynomial (wave layout): [reg][lane]
+FF_FN constexpr int bkf_elem_offset(int lane, int reg) { return reg * 64 + lane; }
+
+struct FftLane {
+    int lane;
+    int x1w;   // + k2 * ROW
+    int x1r;   // + 8 b
+    int x2a;   // lane viewed as (k2, a): k2 * ROW;  + 8 c + ((a + c) & 7)
+    int a;     // lane & 7
+};
+
+FF_FN FftLane fft_lane_init(int lane)
+{
+    FftLane L;
+    L.lane = lane;
+    L.a = lane & 7;
+    L.x1w = lane;
+    L.x1r = (lane >> 3) * FFT_ROW + (lane & 7);
+    L.x2a = (lane >> 3) * FFT_ROW;
+    return L;
+}
+
+// 8-point DFT, decimation in frequency, natural-order input, bit-reversed output (x[i] = X[br3(i)]).
+// INV = false: kernel exp(-2 pi i jk/8); INV = true: exp(+2 pi i jk/8) (unnormalised).
+template <bool INV>
+FF_FN void dft8(cplx (&x)[8])
+{
+    const double s = 0.70710678118654752440;
+    // stage 0
+    cplx u0 = c_add(x[0], x[4]), v0 = c_sub(x[0], x[4]);
+    cplx u1 = c_add(x[1], x[5]), v1 = c_sub(x[1], x[5]);
+    cplx u2 = c_add(x[2], x[6]), v2 = c_sub(x[2], x[6]);
+    cplx u3 = c_add(x[3], x[7]), v3 = c_sub(x[3], x[7]);
+    // twiddles E^j on v_j, E = exp(-+ 2 pi i/8)
+    if (!INV) {
+        v1 = cplx{(v1.re + v1.im) * s, (v1.im - v1.re) * s};     // * (1 - i)/sqrt2
+        v2 = c_mul_mi(v2);
+        v3 = cplx{(v3.im - v3.re) * s, -(v3.re + v3.im) * s};    // * (-1 - i)/sqrt2
+    } else {
+        v1 = cplx{(v1.re - v1.im) * s, (v1.re + v1.im) * s};     // * (1 + i)/sqrt2
+        v2 = c_mul_pi(v2);
+        v3 = cplx{-(v3.re + v3.im) * s, (v3.re - v3.im) * s};    // * (-1 + i)/sqrt2
+    }
+    // stage 1
+    cplx p0 = c_add(u0, u2), p2 = c_sub(u0, u2);
+    cplx p1 = c_add(u1, u3), p3 = INV ? c_mul_pi(c_sub(u1, u3)) : c_mul_mi(c_sub(u1, u3));
+    cplx q0 = c_add(v0, v2), q2 = c_sub(v0, v2);
+    cplx q1 = c_add(v1, v3), q3 = INV ? c_mul_pi(c_sub(v1, v3)) : c_mul_mi(c_sub(v1, v3));
+    // stage 2
+    x[0] = c_add(p0, p1); x[1] = c_sub(p0, p1);
+    x[2] = c_add(p2, p3); x[3] = c_sub(p2, p3);
+    x[4] = c_add(q0, q1); x[5] = c_sub(q0, q1);
+    x[6] = c_add(q2, q3); x[7] = c_sub(q2, q3);
+}
+
+// compile-time constants g^j2 = exp(-i pi j2/16), j2 = 0..7
+#define FFT_G_RE(j) ((j) == 0 ? 1.0 : (j) == 1 ? 0.98078528040323044913 : (j) == 2 ? 0.92387953251128675613 : \
+                     (j) == 3 ? 0.83146961230254523708 : (j) == 4 ? 0.70710678118654752440 :                  \
+                     (j) == 5 ? 0.55557023301960222474 : (j) == 6 ? 0.38268343236508977173 : 0.19509032201612826785)
+#define FFT_G_IM(j) ((j) == 0 ? -0.0 : (j) == 1 ? -0.19509032201612826785 : (j) == 2 ? -0.38268343236508977173 : \
+                     (j) == 3 ? -0.55557023301960222474 : (j) == 4 ? -0.70710678118654752440 :                  \
+                     (j) == 5 ? -0.83146961230254523708 : (j) == 6 ? -0.92387953251128675613 : -0.98078528040323044913)
+
+// Forward transform.
+//   in : x[j2] = (a_j, -a_{j+512}) for j = lane + 64 j2   (i.e. a_j - i a_{j+512})
+//   out: x[d]  = X_k, k = fft_freq_index(lane, d)
+FF_FN void fft_forward(cplx (&x)[8], cplx *xbuf, const cplx *tw1, const cplx *tw2, const FftLane &L)
+{
+#pragma unroll
+    for (int j = 1; j < 8; j++) x[j] = c_mul(x[j], cplx{FFT_G_RE(j), FFT_G_IM(j)});
+    dft8<false>(x);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int k2 = br3(i);
+        xbuf[L.x1w + k2 * FFT_ROW] = c_mul(x[i], tw1[k2 * 64 + L.lane]);
+    }
+    WAVE_SYNC();
+#pragma unroll
+    for (int b = 0; b < 8; b++) x[b] = xbuf[L.x1r + 8 * b];
+    WAVE_SYNC();
+    dft8<false>(x);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int c = br3(i);
+        const cplx v = c == 0 ? x[i] : c_mul(x[i], tw2[c * 8 + L.a]);
+        xbuf[L.x2a + 8 * c + ((L.a + c) & 7)] = v;
+    }
+    WAVE_SYNC();
+    // now this lane is (k2, c = lane & 7); read a = 0..7
+#pragma unroll
+    for (int a = 0; a < 8; a++) x[a] = xbuf[L.x2a + 8 * L.a + ((a + L.a) & 7)];
+    WAVE_SYNC();
+    dft8<false>(x);
+    cplx y[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) y[br3(i)] = x[i];
+#pragma unroll
+    for (int d = 0; d < 8; d++) x[d] = y[d];
+}
+
+// Inverse transform (includes 1/512 and the conj(w^j) untwist).
+//   in : x[d]  = X_k, k = fft_freq_index(lane, d)
+//   out: x[j2] = y_j for j = lane + 64 j2:  a_j = Re y_j,  a_{j+512} = -Im y_j  (before rounding)
+FF_FN void fft_inverse(cplx (&x)[8], cplx *xbuf, const cplx *tw1, const cplx *tw2, const FftLane &L)
+{
+    // pass 3 inverse: d -> a
+    dft8<true>(x);
+    // lane = (k2, c): write a (bit-reversed registers), twiddle 2 conj
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int a = br3(i);
+        xbuf[L.x2a + 8 * L.a + ((a + L.a) & 7)] = x[i];
+    }
+    WAVE_SYNC();
+    // lane = (k2, a): read c = 0..7, multiply by conj(V^(a c))
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const cplx v = xbuf[L.x2a + 8 * c + ((L.a + c) & 7)];
+        x[c] = c == 0 ? v : c_mul_conj(v, tw2[c * 8 + L.a]);
+    }
+    WAVE_SYNC();
+    // pass 2 inverse: c -> b
+    dft8<true>(x);
+#pragma unroll
+    for (int i = 0; i < 8; i++) xbuf[L.x1r + 8 * br3(i)] = x[i];
+    WAVE_SYNC();
+    // lane = j1: read k2 = 0..7, multiply by conj(tw1)
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2++) x[k2] = c_mul_conj(xbuf[L.x1w + k2 * FFT_ROW], tw1[k2 * 64 + L.lane]);
+    WAVE_SYNC();
+    // pass 1 inverse: k2 -> j2, then conj(g^j2) / 512
+    dft8<true>(x);
+    cplx y[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) y[br3(i)] = x[i];
+    const double sc = 1.0 / 512.0;
+    x[0] = cplx{y[0].re * sc, y[0].im * sc};
+#pragma unroll
+    for (int j = 1; j < 8; j++) x[j] = c_mul_conj(y[j], cplx{FFT_G_RE(j) * sc, FFT_G_IM(j) * sc});
+}
+
+// round-to-nearest-even to the low 32 bits (two's complement), valid for |v| < 2^51
+// (fft.mako:272-277: round -> int64 -> truncate to int32)
+FF_FN u32 fft_round_to_u32(double v)
+{
+    const double magic = 6755399441055744.0;   // 1.5 * 2^52
+    union { double d; u64 u; } c;
+    c.d = v + magic;
+    return (u32)c.u;
+}
+
+// host-side table construction (w = exp(-i pi / 1024))
+static inline void fft_make_tables(cplx *tw1, cplx *tw2)
+{
+    const long double pi = 3.14159265358979323846264338327950288L;
+    for (int k2 = 0; k2 < 8; k2++)
+        for (int j1 = 0; j1 < 64; j1++) {
+            const long double ang = -pi * (long double)(j1 * (1 + 4 * k2)) / 1024.0L;
+            tw1[k2 * 64 + j1] = cplx{(double)cosl(ang), (double)sinl(ang)};
+        }
+    for (int c = 0; c < 8; c++)
+        for (int a = 0; a < 8; a++) {
+            const long double ang = -2.0L * pi * (long double)(a * c) / 64.0L;
+            tw2[c * 8 + a] = cplx{(double)cosl(ang), (double)sinl(ang)};
+        }
+}

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "blind_rotate.h"
+#include "blind_rotate_fft.h"
 
 #define BR_BLOCK_THREADS 512
 #define BR_WAVES_PER_BLOCK 8
@@ -20,15 +21,15 @@ struct BrLaunch {
     BrJob job[2];
     long bits_per_job;
     long nbits_total;
-    const u64 *bk;        // wave layout, [n][8][1024]
+    const void *bk;       // wave layout: NTT u64 [n][8][1024] / FFT complex128 [n][8][512]
     int n;
     i32 mu;
     i32 *out_a;           // extracted LWE(1024): out_a[g * out_a_stride + j]
     i32 *out_b;           // out_b[g * out_b_stride]
     long out_a_stride;
     long out_b_stride;
-    const u64 *tw1f;
-    const u64 *tw1i;
+    const void *tw_a;     // NTT: tw1f u64[1024]; FFT: tw1 complex[512]
+    const void *tw_b;     // NTT: tw1i u64[1024]; FFT: tw2 complex[64]
 };
 
 struct KsLaunch {
@@ -63,10 +64,18 @@ struct LweView {
 };
 
 hipError_t kernels_init_device();
-hipError_t launch_bootstrap(const BrLaunch &P, hipStream_t stream);
-hipError_t launch_blind_rotate_accum(i32 *accum, const u64 *bk, const i32 *bara, long bara_stride, int row0,
-                                     int n_rows, int external_mul_only, long batch, const u64 *tw1f,
-                                     const u64 *tw1i, hipStream_t stream);
+// transform: 0 = NTT, 1 = FFT
+hipError_t launch_bootstrap(const BrLaunch &P, int transform, hipStream_t stream);
+hipError_t launch_blind_rotate_accum(i32 *accum, const void *bk, const i32 *bara, long bara_stride, int row0,
+                                     int n_rows, int external_mul_only, long batch, const void *tw_a,
+                                     const void *tw_b, int transform, hipStream_t stream);
+hipError_t launch_fft_forward(cplx *out, const i32 *in, long batch, const cplx *tw1, const cplx *tw2,
+                              hipStream_t stream);
+hipError_t launch_fft_inverse(i32 *out, const cplx *in, long batch, const cplx *tw1, const cplx *tw2,
+                              hipStream_t stream);
+hipError_t launch_bkf_from_coeffs(cplx *out, const i32 *in, long polys, const cplx *tw1, const cplx *tw2,
+                                  hipStream_t stream);
+hipError_t launch_bkf_permute(cplx *out, const cplx *in, long polys, int to_reference, hipStream_t stream);
 hipError_t launch_ntt_forward(u64 *out, const void *in, int mode, long batch, const u64 *tw1f, const u64 *tw1i,
                               hipStream_t stream);
 hipError_t launch_ntt_inverse(void *out, const u64 *in, int mode, long batch, const u64 *tw1f, const u64 *tw1i,

@@ -48,7 +48,7 @@ __device__ __forceinline__ BrLds carve_br_lds(int wave)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_bootstrap(BrLaunch P)
 {
-    load_tables(P.tw1f, P.tw1i);
+    load_tables((const u64 *)P.tw_a, (const u64 *)P.tw_b);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long gbit = (long)blockIdx.x * BR_WAVES_PER_BLOCK + wave;
     if (gbit >= P.nbits_total) return;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_bootstrap(BrLaunch P)
     const u32 barb = br_prologue(P.job[job].s0, P.job[job].s1, P.job[job].c0, bit, P.n, lds, lane);
     WAVE_SYNC();
     u32 acc[2][16];
-    br_blind_rotate(acc, P.bk, P.n, barb, P.mu, lds, L);
+    br_blind_rotate(acc, (const u64 *)P.bk, P.n, barb, P.mu, lds, L);
     br_extract(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, acc, lane);
 }
 
@@ -111,6 +111,162 @@ __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_blind_rotate_accum(
     for (int m = 0; m < 2; m++)
 #pragma unroll
         for (int r = 0; r < 16; r++) my[m * 1024 + lane + 64 * r] = (i32)acc[m][r];
+}
+
+// ------------------------------------------------------------------------------------------
+// FFT variants (BASELINE config 5).  LDS: tw1 (8 KiB) | tw2 (1 KiB) | per wave: xbuf 9216 B,
+// accumulator mirror 8 KiB, bara 1 KiB
+// ------------------------------------------------------------------------------------------
+#define FTABLE_LDS_BYTES ((FFT_TW1_ELEMS + FFT_TW2_ELEMS) * 16)
+#define WAVE_FXBUF_BYTES (FFT_XBUF_ELEMS * 16)
+#define WAVE_BRF_LDS_BYTES (WAVE_FXBUF_BYTES + WAVE_ACC_BYTES + WAVE_BARA_BYTES)
+
+__device__ __forceinline__ void load_ftables(const cplx *__restrict__ g_tw1, const cplx *__restrict__ g_tw2)
+{
+    cplx *t = (cplx *)g_smem;
+    for (int i = threadIdx.x; i < FFT_TW1_ELEMS; i += blockDim.x) t[i] = g_tw1[i];
+    for (int i = threadIdx.x; i < FFT_TW2_ELEMS; i += blockDim.x) t[FFT_TW1_ELEMS + i] = g_tw2[i];
+    __syncthreads();
+}
+
+__device__ __forceinline__ BrFftLds carve_brf_lds(int wave)
+{
+    unsigned char *base = g_smem + FTABLE_LDS_BYTES + wave * WAVE_BRF_LDS_BYTES;
+    BrFftLds lds;
+    lds.xbuf = (cplx *)base;
+    lds.acc = (i32 *)(base + WAVE_FXBUF_BYTES);
+    lds.bara = (uint16_t *)(base + WAVE_FXBUF_BYTES + WAVE_ACC_BYTES);
+    lds.tw1 = (const cplx *)g_smem;
+    lds.tw2 = (const cplx *)g_smem + FFT_TW1_ELEMS;
+    return lds;
+}
+
+__global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_bootstrap_fft(BrLaunch P)
+{
+    load_ftables((const cplx *)P.tw_a, (const cplx *)P.tw_b);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long gbit = (long)blockIdx.x * BR_WAVES_PER_BLOCK + wave;
+    if (gbit >= P.nbits_total) return;
+    const int job = gbit >= P.bits_per_job ? 1 : 0;
+    const long bit = gbit - (job ? P.bits_per_job : 0);
+
+    const BrFftLds lds = carve_brf_lds(wave);
+    const FftLane L = fft_lane_init(lane);
+    BrLds plds;
+    plds.bara = lds.bara;
+    const u32 barb = br_prologue(P.job[job].s0, P.job[job].s1, P.job[job].c0, bit, P.n, plds, lane);
+    WAVE_SYNC();
+    u32 acc[2][16];
+    brf_blind_rotate(acc, (const cplx *)P.bk, P.n, barb, P.mu, lds, L);
+    br_extract(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, acc, lane);
+}
+
+__global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_blind_rotate_accum_fft(
+    i32 *__restrict__ accum, const cplx *__restrict__ bk, const i32 *__restrict__ bara, long bara_stride,
+    int row0, int n_rows, int external_mul_only, long batch, const cplx *__restrict__ tw1,
+    const cplx *__restrict__ tw2)
+{
+    load_ftables(tw1, tw2);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long bit = (long)blockIdx.x * BR_WAVES_PER_BLOCK + wave;
+    if (bit >= batch) return;
+    const BrFftLds lds = carve_brf_lds(wave);
+    const FftLane L = fft_lane_init(lane);
+    i32 *my = accum + bit * 2048;
+    u32 acc[2][16];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            acc[m][r] = (u32)my[m * 1024 + lane + 64 * r];
+            lds.acc[m * 1024 + lane + 64 * r] = (i32)acc[m][r];
+        }
+    WAVE_SYNC();
+    if (external_mul_only) {
+        u32 res[2][16];
+        brf_external_product(
+            res,
+            [&](int m, u32(&T)[16]) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) T[r] = acc[m][r];
+            },
+            bk + (long)row0 * BKF_ROW_ELEMS, lds, L);
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][r] = res[m][r];
+    } else {
+        for (int i = 0; i < n_rows; i++) {
+            const u32 a = WAVE_UNIFORM((u32)bara[bit * bara_stride + i]) & 2047u;
+            if (a == 0) continue;
+            brf_step(acc, a, bk + (long)(row0 + i) * BKF_ROW_ELEMS, lds, L);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) my[m * 1024 + lane + 64 * r] = (i32)acc[m][r];
+}
+
+#define FFT_BLOCK_THREADS 256
+#define FFT_WAVES_PER_BLOCK 4
+
+__device__ __forceinline__ cplx *carve_fft_xbuf(int wave)
+{
+    return (cplx *)(g_smem + FTABLE_LDS_BYTES + wave * WAVE_FXBUF_BYTES);
+}
+
+// forward folded FFT of int32 polynomials; WAVE_LAYOUT = false: natural frequency order
+// (fft_transform_ref), true: the key layout
+template <bool WAVE_LAYOUT>
+__global__ __launch_bounds__(FFT_BLOCK_THREADS) void k_fft_forward(cplx *__restrict__ out, const i32 *__restrict__ in,
+                                                                   long batch, const cplx *__restrict__ tw1,
+                                                                   const cplx *__restrict__ tw2)
+{
+    load_ftables(tw1, tw2);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long p = (long)blockIdx.x * FFT_WAVES_PER_BLOCK + wave;
+    if (p >= batch) return;
+    const FftLane L = fft_lane_init(lane);
+    cplx x[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+        x[r] = cplx{(double)in[p * 1024 + lane + 64 * r], -(double)in[p * 1024 + lane + 64 * r + 512]};
+    fft_forward(x, carve_fft_xbuf(wave), (const cplx *)g_smem, (const cplx *)g_smem + FFT_TW1_ELEMS, L);
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+        out[p * 512 + (WAVE_LAYOUT ? bkf_elem_offset(lane, r) : fft_freq_index(lane, r))] = x[r];
+}
+
+__global__ __launch_bounds__(FFT_BLOCK_THREADS) void k_fft_inverse(i32 *__restrict__ out, const cplx *__restrict__ in,
+                                                                   long batch, const cplx *__restrict__ tw1,
+                                                                   const cplx *__restrict__ tw2)
+{
+    load_ftables(tw1, tw2);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long p = (long)blockIdx.x * FFT_WAVES_PER_BLOCK + wave;
+    if (p >= batch) return;
+    const FftLane L = fft_lane_init(lane);
+    cplx x[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) x[r] = in[p * 512 + fft_freq_index(lane, r)];
+    fft_inverse(x, carve_fft_xbuf(wave), (const cplx *)g_smem, (const cplx *)g_smem + FFT_TW1_ELEMS, L);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        out[p * 1024 + lane + 64 * r] = (i32)fft_round_to_u32(x[r].re);
+        out[p * 1024 + lane + 64 * r + 512] = (i32)fft_round_to_u32(-x[r].im);
+    }
+}
+
+// natural order <-> wave layout of FFT-domain key polynomials (pure permutation)
+__global__ void k_bkf_permute(cplx *__restrict__ out, const cplx *__restrict__ in, long polys, int to_reference)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= polys * 512) return;
+    const long p = t >> 9;
+    const int e = (int)(t & 511), lane = e & 63, reg = e >> 6;
+    if (to_reference) out[p * 512 + fft_freq_index(lane, reg)] = in[p * 512 + bkf_elem_offset(lane, reg)];
+    else out[p * 512 + bkf_elem_offset(lane, reg)] = in[p * 512 + fft_freq_index(lane, reg)];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -413,31 +569,75 @@ __global__ void k_tlwe_extract(i32 *__restrict__ ra, i32 *__restrict__ rb, const
 static inline unsigned blocks_for(long n, int per) { return (unsigned)((n + per - 1) / per); }
 
 static const size_t kBrLds = TABLE_LDS_BYTES + (size_t)BR_WAVES_PER_BLOCK * WAVE_BR_LDS_BYTES;
+static const size_t kBrfLds = FTABLE_LDS_BYTES + (size_t)BR_WAVES_PER_BLOCK * WAVE_BRF_LDS_BYTES;
+static const size_t kFftLds = FTABLE_LDS_BYTES + (size_t)FFT_WAVES_PER_BLOCK * WAVE_FXBUF_BYTES;
 
-// per-device one-time setup: the fused kernels use 156 KiB of dynamic LDS (> the 64 KiB default cap)
+// per-device one-time setup: the fused kernels use ~156 KiB of dynamic LDS (> the 64 KiB default cap)
 hipError_t kernels_init_device()
 {
     hipError_t e = hipFuncSetAttribute((const void *)k_bootstrap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrLds);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void *)k_blind_rotate_accum, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrLds);
+    e = hipFuncSetAttribute((const void *)k_blind_rotate_accum, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrLds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_bootstrap_fft, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrfLds);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void *)k_blind_rotate_accum_fft, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrfLds);
 }
 
-hipError_t launch_bootstrap(const BrLaunch &P, hipStream_t stream)
+hipError_t launch_bootstrap(const BrLaunch &P, int transform, hipStream_t stream)
 {
     if (P.nbits_total == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_bootstrap, dim3(blocks_for(P.nbits_total, BR_WAVES_PER_BLOCK)), dim3(BR_BLOCK_THREADS),
-                       kBrLds, stream, P);
+    const dim3 grid(blocks_for(P.nbits_total, BR_WAVES_PER_BLOCK)), block(BR_BLOCK_THREADS);
+    if (transform == 0) hipLaunchKernelGGL(k_bootstrap, grid, block, kBrLds, stream, P);
+    else hipLaunchKernelGGL(k_bootstrap_fft, grid, block, kBrfLds, stream, P);
     return hipGetLastError();
 }
 
-hipError_t launch_blind_rotate_accum(i32 *accum, const u64 *bk, const i32 *bara, long bara_stride, int row0,
-                                     int n_rows, int external_mul_only, long batch, const u64 *tw1f,
-                                     const u64 *tw1i, hipStream_t stream)
+hipError_t launch_blind_rotate_accum(i32 *accum, const void *bk, const i32 *bara, long bara_stride, int row0,
+                                     int n_rows, int external_mul_only, long batch, const void *tw_a,
+                                     const void *tw_b, int transform, hipStream_t stream)
 {
     if (batch == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_blind_rotate_accum, dim3(blocks_for(batch, BR_WAVES_PER_BLOCK)), dim3(BR_BLOCK_THREADS),
-                       kBrLds, stream, accum, bk, bara, bara_stride, row0, n_rows, external_mul_only, batch, tw1f,
-                       tw1i);
+    const dim3 grid(blocks_for(batch, BR_WAVES_PER_BLOCK)), block(BR_BLOCK_THREADS);
+    if (transform == 0)
+        hipLaunchKernelGGL(k_blind_rotate_accum, grid, block, kBrLds, stream, accum, (const u64 *)bk, bara, bara_stride,
+                           row0, n_rows, external_mul_only, batch, (const u64 *)tw_a, (const u64 *)tw_b);
+    else
+        hipLaunchKernelGGL(k_blind_rotate_accum_fft, grid, block, kBrfLds, stream, accum, (const cplx *)bk, bara,
+                           bara_stride, row0, n_rows, external_mul_only, batch, (const cplx *)tw_a, (const cplx *)tw_b);
+    return hipGetLastError();
+}
+
+hipError_t launch_fft_forward(cplx *out, const i32 *in, long batch, const cplx *tw1, const cplx *tw2, hipStream_t stream)
+{
+    if (batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fft_forward<false>, dim3(blocks_for(batch, FFT_WAVES_PER_BLOCK)), dim3(FFT_BLOCK_THREADS),
+                       kFftLds, stream, out, in, batch, tw1, tw2);
+    return hipGetLastError();
+}
+
+hipError_t launch_fft_inverse(i32 *out, const cplx *in, long batch, const cplx *tw1, const cplx *tw2, hipStream_t stream)
+{
+    if (batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fft_inverse, dim3(blocks_for(batch, FFT_WAVES_PER_BLOCK)), dim3(FFT_BLOCK_THREADS), kFftLds,
+                       stream, out, in, batch, tw1, tw2);
+    return hipGetLastError();
+}
+
+hipError_t launch_bkf_from_coeffs(cplx *out, const i32 *in, long polys, const cplx *tw1, const cplx *tw2,
+                                  hipStream_t stream)
+{
+    if (polys == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fft_forward<true>, dim3(blocks_for(polys, FFT_WAVES_PER_BLOCK)), dim3(FFT_BLOCK_THREADS),
+                       kFftLds, stream, out, in, polys, tw1, tw2);
+    return hipGetLastError();
+}
+
+hipError_t launch_bkf_permute(cplx *out, const cplx *in, long polys, int to_reference, hipStream_t stream)
+{
+    if (polys == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_bkf_permute, dim3(blocks_for(polys * 512, 256)), dim3(256), 0, stream, out, in, polys,
+                       to_reference);
     return hipGetLastError();
 }
 

@@ -28,6 +28,8 @@ class DeviceParams:
 _NP_TO_TORCH = {
     numpy.dtype('int32'): torch.int32,
     numpy.dtype('float32'): torch.float32,
+    numpy.dtype('float64'): torch.float64,
+    numpy.dtype('complex128'): torch.complex128,
     numpy.dtype('uint64'): torch.uint64 if hasattr(torch, 'uint64') else torch.int64,
     numpy.dtype('int64'): torch.int64,
     numpy.dtype('bool'): torch.bool,

@@ -101,6 +101,58 @@ class NttTransformRef:
         return g.gnum_to_u64(g.gnum(d1) * g.gnum(d2) * coeff)
 
 
+class FftTransformRef:
+    """Restatement of the pure-NumPy part of polynomial_transform_fft.py / transform/fft.py
+    (both import reikna at module top).  numpy.fft is the reference's own engine here."""
+
+    @staticmethod
+    def transformed_dtype():
+        return numpy.dtype('complex128')                  # polynomial_transform_fft.py:28-29
+
+    @staticmethod
+    def transformed_length(N):
+        return N // 2                                     # polynomial_transform_fft.py:51-52
+
+    @staticmethod
+    def fft_transform_ref(data, inverse=False, i32_conversion=False):
+        if i32_conversion and not inverse:                # transform/fft.py:27-51
+            N = data.shape[-1]
+        else:
+            N = data.shape[-1] * 2
+        batch_shape = data.shape[:-1]
+        data = data.reshape(int(numpy.prod(batch_shape, dtype=numpy.int64)), data.shape[-1])
+        coeffs = numpy.exp(-2j * numpy.pi * numpy.arange(N // 2) / N / 2)
+        f64_to_i32 = lambda x: numpy.round(x).astype(numpy.int64).astype(numpy.int32)
+        if inverse:
+            final_shape = batch_shape + ((N,) if i32_conversion else (N // 2,))
+            res = numpy.fft.ifft(data).conj() * coeffs
+            if i32_conversion:
+                res = numpy.concatenate([f64_to_i32(res.real), f64_to_i32(res.imag)], axis=1)
+            return res.reshape(final_shape)
+        else:
+            if i32_conversion:
+                data = (data[:, :N // 2] - 1j * data[:, N // 2:])
+            return numpy.fft.fft(data * coeffs).reshape(batch_shape + (N // 2,))
+
+    def forward_transform_ref(self, data):
+        return self.fft_transform_ref(data, i32_conversion=True)
+
+    def inverse_transform_ref(self, data):
+        return self.fft_transform_ref(data, i32_conversion=True, inverse=True)
+
+    @staticmethod
+    def transformed_space_add_ref(d1, d2):
+        return d1 + d2
+
+    @staticmethod
+    def transformed_space_mul_ref(d1, d2):
+        return d1 * d2
+
+    @staticmethod
+    def transformed_space_mul_prepared_ref(d1, d2):
+        return d1 * d2                                    # polynomial_transform_fft.py:71-72
+
+
 _loaded = None
 
 
@@ -139,6 +191,7 @@ def load():
     ntt_cpu.gnum_to_u64 = numpy.vectorize(lambda x: numpy.uint64(x.val), otypes=[numpy.uint64])
 
     transform = NttTransformRef(ntt_cpu)
+    fft_transform = FftTransformRef()
 
     # synthetic nufhe.numeric_functions / numeric_functions_gpu (dtypes + double_to_t32)
     nf = types.ModuleType(PKG + '.numeric_functions')
@@ -152,14 +205,15 @@ def load():
 
     pt = types.ModuleType(PKG + '.polynomial_transform')
     def get_transform(transform_type):
-        assert transform_type == 'NTT'
-        return transform
+        assert transform_type in ('NTT', 'FFT')
+        return transform if transform_type == 'NTT' else fft_transform
     pt.get_transform = get_transform
     sys.modules[PKG + '.polynomial_transform'] = pt
 
     ns = types.SimpleNamespace(
         ntt_cpu=ntt_cpu,
         transform=transform,
+        fft_transform=fft_transform,
         numeric_functions_cpu=_load('numeric_functions_cpu', 'numeric_functions_cpu.py'),
         polynomials_cpu=_load('polynomials_cpu', 'polynomials_cpu.py'),
         lwe_cpu=_load('lwe_cpu', 'lwe_cpu.py'),

@@ -77,3 +77,39 @@ def bootstrap_bit(bk_internal, n, src0, p0, src1, p1, c0, mu):
                             _p(a1, c_i32p), _p(b1, c_i32p), ctypes.c_int32(p1),
                             ctypes.c_int32(c0), ctypes.c_int32(mu))
     return out_a, out_b[0]
+
+
+c_f64p = ctypes.POINTER(ctypes.c_double)
+
+
+def fft_forward(x):
+    x = numpy.ascontiguousarray(x, numpy.int32)
+    out = numpy.empty(1024, numpy.float64)
+    lib().emu_fft_forward(_p(out, c_f64p), _p(x, c_i32p))
+    return out.view(numpy.complex128)
+
+
+def fft_inverse(x):
+    x = numpy.ascontiguousarray(x, numpy.complex128).view(numpy.float64)
+    out = numpy.empty(1024, numpy.int32)
+    lib().emu_fft_inverse(_p(out, c_i32p), _p(x, c_f64p))
+    return out
+
+
+def bkf_from_reference(bk):
+    bk = numpy.ascontiguousarray(bk, numpy.complex128)
+    out = numpy.empty_like(bk)
+    lib().emu_bkf_from_reference(_p(out.view(numpy.float64), c_f64p), _p(bk.view(numpy.float64), c_f64p),
+                                 ctypes.c_long(bk.size // 512))
+    return out
+
+
+def bootstrap_bit_fft(bk_internal, n, src0, p0, src1, p1, c0, mu):
+    a0 = numpy.ascontiguousarray(src0[0], numpy.int32); b0 = numpy.ascontiguousarray(src0[1], numpy.int32).reshape(1)
+    a1 = numpy.ascontiguousarray(src1[0], numpy.int32); b1 = numpy.ascontiguousarray(src1[1], numpy.int32).reshape(1)
+    out_a = numpy.empty(1024, numpy.int32); out_b = numpy.empty(1, numpy.int32)
+    lib().emu_bootstrap_bit_fft(_p(out_a, c_i32p), _p(out_b, c_i32p), _p(bk_internal.view(numpy.float64), c_f64p),
+                                ctypes.c_int(n), _p(a0, c_i32p), _p(b0, c_i32p), ctypes.c_int32(p0),
+                                _p(a1, c_i32p), _p(b1, c_i32p), ctypes.c_int32(p1),
+                                ctypes.c_int32(c0), ctypes.c_int32(mu))
+    return out_a, out_b[0]

@@ -9,6 +9,8 @@
 #include "../../nufhe_amd/csrc/ntt1024.h"
 #include "../../nufhe_amd/csrc/ntt_tables.h"
 #include "../../nufhe_amd/csrc/blind_rotate.h"
+#include "../../nufhe_amd/csrc/fft512.h"
+#include "../../nufhe_amd/csrc/blind_rotate_fft.h"
 #include "emu_wave.h"
 
 static u64 g_tw1f[1024], g_tw1i[1024];
@@ -95,6 +97,74 @@ void emu_bootstrap_bit(i32 *out_a, i32 *out_b, const u64 *bk_internal, int n,
         WAVE_SYNC();
         u32 acc[2][16];
         br_blind_rotate(acc, bk_internal, n, barb, mu, lds, L);
+        br_extract(out_a, out_b, acc, lane);
+    });
+}
+
+
+static cplx g_ftw1[FFT_TW1_ELEMS], g_ftw2[FFT_TW2_ELEMS];
+static bool g_ftables = false;
+static void ftables() { if (!g_ftables) { fft_make_tables(g_ftw1, g_ftw2); g_ftables = true; } }
+
+// forward folded FFT of one int32 polynomial; out: 512 complex (re, im interleaved), natural order
+void emu_fft_forward(double *out, const i32 *in)
+{
+    ftables();
+    std::vector<cplx> xbuf(FFT_XBUF_ELEMS);
+    emu_run_wave([&](int lane) {
+        FftLane L = fft_lane_init(lane);
+        cplx x[8];
+        for (int r = 0; r < 8; r++) x[r] = cplx{(double)in[lane + 64 * r], -(double)in[lane + 64 * r + 512]};
+        fft_forward(x, xbuf.data(), g_ftw1, g_ftw2, L);
+        for (int r = 0; r < 8; r++) { int k = fft_freq_index(lane, r); out[2 * k] = x[r].re; out[2 * k + 1] = x[r].im; }
+    });
+}
+
+void emu_fft_inverse(i32 *out, const double *in)
+{
+    ftables();
+    std::vector<cplx> xbuf(FFT_XBUF_ELEMS);
+    emu_run_wave([&](int lane) {
+        FftLane L = fft_lane_init(lane);
+        cplx x[8];
+        for (int r = 0; r < 8; r++) { int k = fft_freq_index(lane, r); x[r] = cplx{in[2 * k], in[2 * k + 1]}; }
+        fft_inverse(x, xbuf.data(), g_ftw1, g_ftw2, L);
+        for (int r = 0; r < 8; r++) {
+            out[lane + 64 * r] = (i32)fft_round_to_u32(x[r].re);
+            out[lane + 64 * r + 512] = (i32)fft_round_to_u32(-x[r].im);
+        }
+    });
+}
+
+
+// natural-order FFT-domain key polynomials (complex128 [polys][512]) -> wave layout
+void emu_bkf_from_reference(double *out, const double *in, long polys)
+{
+    for (long p = 0; p < polys; p++)
+        for (int lane = 0; lane < 64; lane++)
+            for (int r = 0; r < 8; r++) {
+                const long o = p * 512 + bkf_elem_offset(lane, r), i = p * 512 + fft_freq_index(lane, r);
+                out[2 * o] = in[2 * i]; out[2 * o + 1] = in[2 * i + 1];
+            }
+}
+
+void emu_bootstrap_bit_fft(i32 *out_a, i32 *out_b, const double *bk_internal, int n,
+                           const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,
+                           i32 c0, i32 mu)
+{
+    ftables();
+    std::vector<cplx> xbuf(FFT_XBUF_ELEMS);
+    std::vector<i32> accbuf(2048);
+    std::vector<uint16_t> bara(BR_MAX_LWE);
+    BrFftLds lds{xbuf.data(), accbuf.data(), bara.data(), g_ftw1, g_ftw2};
+    BrLds plds{nullptr, accbuf.data(), bara.data(), nullptr, nullptr};
+    BrSource s0{a0, b0, 0, 0, p0}, s1{a1, b1, 0, 0, p1};
+    emu_run_wave([&](int lane) {
+        FftLane L = fft_lane_init(lane);
+        u32 barb = br_prologue(s0, s1, c0, 0, n, plds, lane);
+        WAVE_SYNC();
+        u32 acc[2][16];
+        brf_blind_rotate(acc, (const cplx *)bk_internal, n, barb, mu, lds, L);
         br_extract(out_a, out_b, acc, lane);
     });
 }

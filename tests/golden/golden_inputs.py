@@ -183,3 +183,13 @@ def blind_rotate_inputs():
     bara[0, 0] = 1024 + 17
     bara[1, 1] = 0
     return acc, bk, bara
+
+
+def fft_extmul_inputs():
+    """FFT external product (test/test_tgsw.py:118-154 with transform_type='FFT'), realistic
+    magnitudes: coefficient-domain TGSW rows are full-range int32 (transformed by the caller),
+    accumulators full-range."""
+    rs = _rs(1030)
+    tgsw = rs.randint(-2**31, 2**31, size=(3, 2, 2, 2, 1024), dtype=numpy.int32)
+    accum = rs.randint(-2**31, 2**31, size=(2, 3, 2, 1024), dtype=numpy.int32)
+    return accum, tgsw, 1

@@ -192,6 +192,18 @@ def main():
     out['blind_rotate_ext_a'] = ra; out['blind_rotate_ext_b'] = rb
     print("blind rotate done", time.time() - t0)
 
+    # ---- FFT transform path (BASELINE config 5): the reference's functions with transform_type='FFT'
+    ft = ref.fft_transform
+    out['fft_forward'] = ft.forward_transform_ref(polys_i32)                 # transform/fft.py:27-51
+    out['fft_inverse_of_forward'] = ft.inverse_transform_ref(out['fft_forward'])
+    tl_f = ref_shim.RefTLweParams(1024, 1, 'FFT')
+    tg_f = ref_shim.RefTGswParams(tl_f, 2, 10)
+    accum, tgsw, row = gi.fft_extmul_inputs()
+    bkf = ft.forward_transform_ref(tgsw)                                     # TLweTransformSamples (FFT)
+    acc = accum.copy()
+    ref.tgsw_cpu.TGswTransformedExternalMulReference(tg_f, accum.shape[:-2], bkf.shape[0], None)(acc, bkf, row)
+    out['fft_extmul'] = acc
+
     path = os.path.join(HERE, 'reference_outputs.npz')
     numpy.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes; cases:", len(out))

@@ -103,8 +103,9 @@ def test_parameters_match_reference_defaults():
     assert int(p.tgsw_params.offset) == -2145386496   # (int32)(2^31 + 2^21), tgsw.py:49-52
     assert p.tgsw_params.tlwe_params.extracted_lweparams.size == 1024
     assert p == NuFHEParameters() and hash(p) == hash(NuFHEParameters())
+    assert NuFHEParameters(transform_type='FFT') != p
     with pytest.raises(NotImplementedError):
-        NuFHEParameters(transform_type='FFT')
+        NuFHEParameters(tlwe_mask_size=2)
 
 
 def test_rng_order_matches_oracle(orc):

@@ -100,3 +100,44 @@ def test_bootstrap_wave_body_full_key(orc, oracle_keys):
     bki = emu.bk_from_reference(ck.bk)
     ga, gb = emu.bootstrap_bit(bki, 500, (c1[0][0], c1[1]), -1, (c2[0][0], c2[1]), -1, MU, MU)
     assert (ga == ea[0]).all() and gb == eb[0]
+
+
+def test_fft_forward_inverse_vs_numpy():
+    """Device FFT-512 (emulated) vs the numpy restatement of fft_transform_ref."""
+    from oracle import oracle_fft as of
+    rs = numpy.random.RandomState(41)
+    for case in range(3):
+        if case == 0:
+            a = rs.randint(-2**31, 2**31, size=1024, dtype=numpy.int32)
+        elif case == 1:
+            a = numpy.zeros(1024, numpy.int32); a[1] = 1; a[700] = -3
+        else:
+            a = rs.randint(-512, 512, size=1024).astype(numpy.int32)
+        f = emu.fft_forward(a)
+        ref = of.fft_forward(a)
+        scale = max(1.0, numpy.abs(ref).max())
+        assert numpy.abs(f - ref).max() / scale < 1e-13
+        assert (emu.fft_inverse(f) == a).all()
+        assert (emu.fft_inverse(ref) == of.fft_inverse(ref)).all()
+    # product of a full-range polynomial with a small one is exact (test_computation.py:71-124)
+    a = rs.randint(-2**31, 2**31, size=1024, dtype=numpy.int32)
+    b = rs.randint(-1000, 1000, size=1024).astype(numpy.int32)
+    prod = emu.fft_inverse(emu.fft_forward(a) * emu.fft_forward(b))
+    from oracle import oracle as orc
+    assert (prod == orc.poly_mul_schoolbook(a[None, :], b[None, :])[0]).all()
+
+
+@pytest.mark.slow
+def test_bootstrap_wave_body_fft_full_key(orc, oracle_keys):
+    """FFT variant of the fused body on the full-size key, one bit: equals the EXACT (NTT) oracle --
+    the fp64 rounding error stays below 0.5 LSB (FFT tolerance statement)."""
+    from oracle import oracle_fft as of
+    lwe_key, tlwe_key, ck = oracle_keys
+    rng = orc.DeterministicRNG(456)
+    c1 = orc.encrypt(rng, lwe_key, numpy.array([True])); c2 = orc.encrypt(rng, lwe_key, numpy.array([False]))
+    MU = 2**29
+    ta = (-c1[0] - c2[0]).astype(numpy.int32); tb = (numpy.int32(MU) - c1[1] - c2[1]).astype(numpy.int32)
+    ea, eb = orc.bootstrap_extract(ck.bk, ta, tb, MU)
+    bkf = of.bk_from_coeffs(of.tgsw_coeffs_from_reference_bk(ck.bk))
+    ga, gb = emu.bootstrap_bit_fft(emu.bkf_from_reference(bkf), 500, (c1[0][0], c1[1]), -1, (c2[0][0], c2[1]), -1, MU, MU)
+    assert (ga == ea[0]).all() and gb == eb[0]

@@ -1,0 +1,171 @@
+"""
+GPU tests of the FFT transform path (BASELINE config 5).
+
+Stated tolerance: fp64 rounding may move a coefficient of an external product by
++-1 torus LSB (2^-32) when the rounding error of the complex arithmetic reaches 0.5 before
+`round`; the contract is
+  * transforms: relative error <= 1e-12 vs numpy.fft (the reference asserts `allclose`,
+    test/test_transform/test_computation.py:67-68),
+  * product of a full-range int32 polynomial with a small one: EXACT (test_computation.py:106-124),
+  * one external product: max |delta| <= 1 LSB vs the exact (NTT) result on <= 1e-4 of coefficients,
+  * a whole gate (500 external products + keyswitch): decrypted bits identical; every output word
+    within 2^16 LSB (2^-16 torus) of the exact path, i.e. 2^-12 of the 1/16 decision margin.
+On the seeded inputs below the observed deviation is ZERO (bit-identical to the exact path), which
+the tests also record.
+"""
+
+import ctypes
+
+import numpy
+import pytest
+
+import golden_inputs as gi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def thr():
+    from nufhe_amd.device import DeviceThread
+    return DeviceThread(0)
+
+
+@pytest.fixture(scope='module')
+def H():
+    import gpu_helpers
+    return gpu_helpers
+
+
+def call(name, *args):
+    from nufhe_amd import _lib
+    _lib.call(name, *args)
+
+
+def ptr(t):
+    from nufhe_amd.device import ptr as p
+    return p(t)
+
+
+def _fft_forward(thr, H, data):
+    d = H.dev(thr, data)
+    out = thr.array(data.shape[:-1] + (1024,), numpy.float64)       # 512 complex = 1024 doubles
+    call("nufhe_fft_forward_i32", thr.handle, ptr(out), ptr(d), data.size // 1024)
+    return H.host(out).view(numpy.complex128)
+
+
+def _fft_inverse(thr, H, data):
+    d = H.dev(thr, numpy.ascontiguousarray(data).view(numpy.float64))
+    out = thr.array(data.shape[:-1] + (1024,), numpy.int32)
+    call("nufhe_fft_inverse_i32", thr.handle, ptr(out), ptr(d), data.size // 512)
+    return H.host(out)
+
+
+def test_fft_transform_vs_reference_golden(thr, H, golden, orc):
+    polys_i32, _ = gi.ntt_inputs()
+    f = _fft_forward(thr, H, polys_i32)
+    ref = golden['fft_forward']
+    assert numpy.abs(f - ref).max() / numpy.abs(ref).max() < 1e-12
+    assert (_fft_inverse(thr, H, f) == polys_i32).all()
+    assert (_fft_inverse(thr, H, ref) == golden['fft_inverse_of_forward']).all()
+    # ragged batch + exact product with a small polynomial
+    rs = numpy.random.RandomState(51)
+    a = rs.randint(-2**31, 2**31, size=(37, 1024), dtype=numpy.int32)
+    b = rs.randint(-1000, 1000, size=(37, 1024)).astype(numpy.int32)
+    prod = _fft_inverse(thr, H, _fft_forward(thr, H, a) * _fft_forward(thr, H, b))
+    assert (prod == orc.poly_mul_schoolbook(a, b)).all()
+
+
+def _fft_key(thr, bkf):
+    from nufhe_amd.bootstrap import NativeCloudKey
+    native = NativeCloudKey(thr, bkf.shape[0], 'FFT')
+    arr = numpy.ascontiguousarray(bkf, numpy.complex128)
+    call("nufhe_bk_upload_reference", native.handle, arr.ctypes.data_as(ctypes.c_void_p))
+    return native
+
+
+def test_fft_external_mul_vs_reference_golden(thr, H, golden, orc):
+    from oracle import oracle_fft as of
+    accum, tgsw, row = gi.fft_extmul_inputs()
+    bkf = of.bk_from_coeffs(tgsw)
+    native = _fft_key(thr, bkf)
+    back = numpy.empty_like(bkf)
+    call("nufhe_bk_download_reference", native.handle, back.ctypes.data_as(ctypes.c_void_p))
+    assert (back == bkf).all()
+    acc = H.dev(thr, accum)
+    call("nufhe_external_mul", thr.handle, native.handle, ptr(acc), row, 6)
+    got = H.host(acc)
+    ref = golden['fft_extmul']          # reference functions with transform_type='FFT' (== exact here)
+    delta = got.astype(numpy.int64) - ref.astype(numpy.int64)
+    assert numpy.abs(delta).max() <= 1 and (delta != 0).mean() <= 1e-4
+    print("FFT external product: coefficients differing from the reference:", int((delta != 0).sum()))
+    # the key transformed on the device (nufhe_bk_from_coeffs) gives the same product
+    native2 = __import__('nufhe_amd.bootstrap', fromlist=['NativeCloudKey']).NativeCloudKey(thr, 3, 'FFT')
+    d_tgsw = H.dev(thr, tgsw)
+    call("nufhe_bk_from_coeffs", native2.handle, ptr(d_tgsw))
+    acc2 = H.dev(thr, accum)
+    call("nufhe_external_mul", thr.handle, native2.handle, ptr(acc2), row, 6)
+    d2 = H.host(acc2).astype(numpy.int64) - ref.astype(numpy.int64)
+    assert numpy.abs(d2).max() <= 1 and (d2 != 0).mean() <= 1e-4
+
+
+@pytest.fixture(scope='module')
+def fft_env(thr, H, orc, oracle_keys):
+    import nufhe_amd
+    from oracle import oracle_fft as of
+    lwe_key, tlwe_key, ck = oracle_keys
+    bkf = of.bk_from_coeffs(of.tgsw_coeffs_from_reference_bk(ck.bk))
+    params = nufhe_amd.NuFHEParameters(transform_type='FFT')
+    ckf = orc.CloudKeyArrays(bkf, ck.ks_a, ck.ks_b, ck.ks_cv)
+    cloud_key = H.cloud_key_from_arrays(thr, ckf, params)
+    secret_key = H.secret_key_from_array(thr, lwe_key, params)
+    ctx = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(456), thread=thr)
+    return dict(ctx=ctx, vm=ctx.make_virtual_machine(cloud_key), sk=secret_key, ck=ck, lwe_key=lwe_key, params=params)
+
+
+def test_config5_fft_gates_vs_exact_path(fft_env, thr, H, orc):
+    """NAND and MUX with the FFT transform vs the exact (NTT) oracle: tolerance contract + record."""
+    vm = fft_env['vm']; ctx = fft_env['ctx']; sk = fft_env['sk']; ck = fft_env['ck']; lwe_key = fft_env['lwe_key']
+    rng = orc.DeterministicRNG(456)
+    B = 64
+    ms = [rng.uniform_bool((B,)).astype(bool) for _ in range(3)]
+    cs = [orc.encrypt(rng, lwe_key, m) for m in ms]
+    ds = [H.ciphertext_from_arrays(thr, c, fft_env['params']) for c in cs]
+    for name, got, exp, truth in (
+            ('nand', vm.gate_nand(ds[0], ds[1]), orc.gate('gate_nand', ck, cs[0], cs[1]), ~(ms[0] & ms[1])),
+            ('mux', vm.gate_mux(ds[0], ds[1], ds[2]), orc.gate_mux(ck, cs[0], cs[1], cs[2]),
+             numpy.where(ms[0], ms[1], ms[2]))):
+        assert (ctx.decrypt(sk, got) == truth).all(), name
+        ra, rb, rcv = H.ct_arrays(got)
+        da = (ra.astype(numpy.int64) - exp[0].astype(numpy.int64) + 2**31) % 2**32 - 2**31
+        db = (rb.astype(numpy.int64) - exp[1].astype(numpy.int64) + 2**31) % 2**32 - 2**31
+        assert numpy.abs(da).max() <= 2**16 and numpy.abs(db).max() <= 2**16, name
+        print("FFT %s: output words differing from the exact path: %d of %d" % (
+            name, int((da != 0).sum() + (db != 0).sum()), da.size + db.size))
+
+
+def test_config5_fft_context_end_to_end_4096(thr):
+    """transform_type='FFT' through the public API: GPU key generation, 4096-bit NAND, every
+    decrypted bit equals the truth table; the FFT key encrypts the same TGSW samples as the NTT key
+    generated from the same seed (key generation is transform independent)."""
+    import nufhe_amd
+    ctx = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(123), thread=thr)
+    sk, cloud = ctx.make_key_pair(transform_type='FFT')
+    vm = ctx.make_virtual_machine(cloud)
+    rs = numpy.random.RandomState(9)
+    m1 = rs.randint(0, 2, size=4096).astype(bool); m2 = rs.randint(0, 2, size=4096).astype(bool)
+    c1 = ctx.encrypt(sk, m1); c2 = ctx.encrypt(sk, m2)
+    r = vm.gate_nand(c1, c2)
+    assert (ctx.decrypt(sk, r) == ~(m1 & m2)).all()
+    # same seed, NTT parameters: identical ciphertext out of the two transforms?  (recorded)
+    ctx2 = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(123), thread=thr)
+    sk2, cloud2 = ctx2.make_key_pair(transform_type='NTT')
+    vm2 = ctx2.make_virtual_machine(cloud2)
+    r2 = vm2.gate_nand(c1, c2)
+    import gpu_helpers as H
+    a1, b1, _ = H.ct_arrays(r); a2, b2, _ = H.ct_arrays(r2)
+    d = (a1.astype(numpy.int64) - a2.astype(numpy.int64) + 2**31) % 2**32 - 2**31
+    assert numpy.abs(d).max() <= 2**16
+    print("FFT vs NTT, 4096-bit NAND: differing words:", int((d != 0).sum()), "of", d.size)
+    # serialization round trip of an FFT key
+    cloud3 = ctx.load_cloud_key(cloud.dumps())
+    assert cloud3 == cloud

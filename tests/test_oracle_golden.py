@@ -221,3 +221,20 @@ def test_blind_rotate_composition(orc, golden):
     eq(res, golden['blind_rotate_acc'])
     ra, rb = orc.tlwe_extract_lwe_samples(res)
     eq(ra, golden['blind_rotate_ext_a']); eq(rb, golden['blind_rotate_ext_b'])
+
+
+# ---- FFT transform path ------------------------------------------------------------------------
+
+def test_fft_oracle_vs_reference(orc, golden):
+    """numpy restatement (oracle/oracle_fft.py) vs the reference's functions run with
+    transform_type='FFT'; and both equal the exact (NTT) external product on these inputs."""
+    from oracle import oracle_fft as of
+    polys_i32, _ = gi.ntt_inputs()
+    assert numpy.allclose(of.fft_forward(polys_i32), golden['fft_forward'], rtol=1e-12, atol=1e-3)
+    eq(of.fft_inverse(golden['fft_forward']), golden['fft_inverse_of_forward'])
+    eq(golden['fft_inverse_of_forward'], polys_i32)
+    accum, tgsw, row = gi.fft_extmul_inputs()
+    res = of.external_mul(accum, of.bk_from_coeffs(tgsw), row)
+    eq(res, golden['fft_extmul'])
+    exact = orc.tgsw_external_mul(accum, orc.tlwe_transform_samples(tgsw), row)
+    eq(golden['fft_extmul'], exact)
