@@ -35,6 +35,20 @@ A_BR_NAND = A_BK + 2 * A_LWE + A_EXT             # bootstrap kernel alone, one b
 HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def pmc_traffic(transform, gate, bits):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command,
+    corrected as MI355X_MICROARCH.md prescribes); None for configurations that were not measured."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            entry = json.load(f)[transform]
+    except Exception:
+        return None
+    if gate != "nand" or bits != 4096:
+        return None
+    return entry["hbm_bytes_per_launch"]
+
+
 def cpu_baseline(gate, sample_bits):
     """Times the CPU oracle (a C restatement of the reference's *_cpu.py composition, OpenMP over
     bits) on a bounded sample of the same workload, on this host's cores."""
@@ -170,7 +184,7 @@ def main():
                 "bound": "hbm", "kernel": "k_bootstrap%s (fused mod-switch + blind rotate + extract)" % (
                     "_fft" if args.transform == "FFT" else ""),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(args.transform, args.gate, B),
                 "kernel_ms": br_avg, "keyswitch_ms": ks_avg,
                 "algorithmic_bytes_per_launch": a_kernel,
                 "gate_streaming_model_GBs": a_gate / (ms_per_step * 1e-3) / 1e9,
