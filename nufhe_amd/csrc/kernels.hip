@@ -406,45 +406,76 @@ __global__ __launch_bounds__(NTT_BLOCK_THREADS) void k_bk_from_coeffs(u64 *__res
 // wave-uniform digit; per-thread accumulators stay in registers.  j-slices combine with integer
 // atomics (order independent => bit-exact).
 // ------------------------------------------------------------------------------------------
+// LDS: 2 stages x 4 rows (row 0 = zeros for digit 0) x 512 int32
+#define KS_ROW_WORDS 512
+#define KS_STAGE_WORDS (4 * KS_ROW_WORDS)
+
 __global__ __launch_bounds__(KS_BLOCK_THREADS) void k_keyswitch_a(KsLaunch P)
 {
+    __shared__ __attribute__((aligned(16))) u32 rows_lds[2 * KS_STAGE_WORDS];
     const int tid = threadIdx.x;
     const long bit0 = (long)blockIdx.x * KS_TILE_BITS;
     const int j0 = blockIdx.y * P.j_per_block;
-    const int c0 = tid, c1 = tid + KS_BLOCK_THREADS;
+    const int c0 = 2 * tid, c1 = 2 * tid + 1;        // this thread's two adjacent columns
     const bool v0 = c0 < P.n, v1 = c1 < P.n;
     const int nb = (int)((P.nbits - bit0) < KS_TILE_BITS ? (P.nbits - bit0) : KS_TILE_BITS);
 
     u32 acc0[KS_TILE_BITS], acc1[KS_TILE_BITS];
 #pragma unroll
     for (int t = 0; t < KS_TILE_BITS; t++) { acc0[t] = 0; acc1[t] = 0; }
+    // zero rows (digit 0) of both stages
+    rows_lds[c0] = 0; rows_lds[c1] = 0;
+    rows_lds[KS_STAGE_WORDS + c0] = 0; rows_lds[KS_STAGE_WORDS + c1] = 0;
 
-    for (int j = j0; j < j0 + P.j_per_block; j++) {
-        // source coefficients of this tile's bits: wave-uniform values
-        u32 aj[KS_TILE_BITS];
+    // prefetch the three non-zero rows of the first (j, k)
+    u32 pa[3], pb[3];
+    {
+        const i32 *rows = P.ks_a3 + ((long)(j0 * 8) * 3) * P.n;
 #pragma unroll
-        for (int t = 0; t < KS_TILE_BITS; t++) {
-            u32 v = 0;
-            if (t < nb) {
-                v = (u32)P.src1_a[(bit0 + t) * P.src1_stride + j];
-                if (P.src2_a) v += (u32)P.src2_a[(bit0 + t) * P.src2_stride + j];
-            }
-            aj[t] = WAVE_UNIFORM(v) + (1u << 15);   // + prec_offset, lwe_cpu.py:70
+        for (int h = 0; h < 3; h++) {
+            pa[h] = v0 ? (u32)rows[h * P.n + c0] : 0u;
+            pb[h] = v1 ? (u32)rows[h * P.n + c1] : 0u;
         }
+    }
+    const int steps = P.j_per_block * 8;
+    u32 aj[KS_TILE_BITS];
+    for (int s = 0; s < steps; s++) {
+        const int j = j0 + (s >> 3), k = s & 7;
+        u32 *stage = rows_lds + (s & 1) * KS_STAGE_WORDS;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const i32 *rows = P.ks_a3 + ((long)(j * 8 + k) * 3) * P.n;
-            const u32 r10 = v0 ? (u32)rows[c0] : 0, r20 = v0 ? (u32)rows[P.n + c0] : 0,
-                      r30 = v0 ? (u32)rows[2 * P.n + c0] : 0;
-            const u32 r11 = v1 ? (u32)rows[c1] : 0, r21 = v1 ? (u32)rows[P.n + c1] : 0,
-                      r31 = v1 ? (u32)rows[2 * P.n + c1] : 0;
+        for (int h = 0; h < 3; h++) {
+            stage[(h + 1) * KS_ROW_WORDS + c0] = pa[h];
+            stage[(h + 1) * KS_ROW_WORDS + c1] = pb[h];
+        }
+        if (s + 1 < steps) {   // prefetch the next (j, k) while this one is consumed
+            const i32 *rows = P.ks_a3 + ((long)((j0 * 8 + s + 1)) * 3) * P.n;
+#pragma unroll
+            for (int h = 0; h < 3; h++) {
+                pa[h] = v0 ? (u32)rows[h * P.n + c0] : 0u;
+                pb[h] = v1 ? (u32)rows[h * P.n + c1] : 0u;
+            }
+        }
+        if (k == 0) {
+            // source coefficients of this tile's bits for input coefficient j: wave-uniform
 #pragma unroll
             for (int t = 0; t < KS_TILE_BITS; t++) {
-                const u32 dg = (aj[t] >> (30 - 2 * k)) & 3u;   // lwe_cpu.py:76 (arithmetic == logical after & 3)
-                const u32 m1 = dg == 1u ? ~0u : 0u, m2 = dg == 2u ? ~0u : 0u, m3 = dg == 3u ? ~0u : 0u;
-                acc0[t] -= (r10 & m1) | (r20 & m2) | (r30 & m3);
-                acc1[t] -= (r11 & m1) | (r21 & m2) | (r31 & m3);
+                u32 v = 0;
+                if (t < nb) {
+                    v = (u32)P.src1_a[(bit0 + t) * P.src1_stride + j];
+                    if (P.src2_a) v += (u32)P.src2_a[(bit0 + t) * P.src2_stride + j];
+                }
+                aj[t] = WAVE_UNIFORM(v) + (1u << 15);   // + prec_offset, lwe_cpu.py:70
             }
+        }
+        __syncthreads();   // stage (s & 1) is complete; stage ((s + 1) & 1) is free again
+        const int sh = 30 - 2 * k;
+        const u64 *stage64 = (const u64 *)stage + tid;
+#pragma unroll
+        for (int t = 0; t < KS_TILE_BITS; t++) {
+            const u32 dg = (aj[t] >> sh) & 3u;               // lwe_cpu.py:76
+            const u64 v = stage64[dg * (KS_ROW_WORDS / 2)];   // both columns of the selected row
+            acc0[t] -= (u32)v;
+            acc1[t] -= (u32)(v >> 32);
         }
     }
 #pragma unroll
@@ -456,31 +487,43 @@ __global__ __launch_bounds__(KS_BLOCK_THREADS) void k_keyswitch_a(KsLaunch P)
     }
 }
 
-// finalize: copy the accumulated mask into the result view, and compute b and the variance with
-// the reference's sequential (j, k) order (float sum order matters): lwe_cpu.py:80-92
+// finalize: copy the accumulated mask into the result view, and compute b and the variance.
+// The float32 variance must be summed in the reference's sequential (j, k) order to be
+// bit-identical (lwe_cpu.py:80-92): the block gathers the 8192 selected terms into LDS in
+// parallel, then one lane adds them in order.
 __global__ __launch_bounds__(256) void k_keyswitch_finalize(KsFinal P)
 {
+    __shared__ float cv_terms[8192];
+    __shared__ u32 b_sum;
     const long bit = blockIdx.x;
+    if (threadIdx.x == 0) b_sum = 0;
+    __syncthreads();
     for (int c = threadIdx.x; c < P.n; c += blockDim.x)
         P.out_a[bit * P.out_a_stride + c] = (i32)P.acc[bit * P.n + c];
+    u32 bpart = 0;
+    for (int j = threadIdx.x; j < 1024; j += blockDim.x) {
+        u32 a = (u32)P.src1_a[bit * P.src1_stride + j];
+        if (P.src2_a) a += (u32)P.src2_a[bit * P.src2_stride + j];
+        a += 1u << 15;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const u32 dg = (a >> (30 - 2 * k)) & 3u;
+            const int idx = (j * 8 + k) * 4 + (int)dg;
+            bpart += (u32)P.ks_b[idx];
+            cv_terms[j * 8 + k] = P.ks_cv[idx];
+        }
+    }
+    atomicAdd(&b_sum, bpart);
+    __syncthreads();
     if (threadIdx.x == 0) {
         u32 b = (u32)P.c0 + (u32)P.src1_b[bit * P.src1_bstride];
         if (P.src2_b) b += (u32)P.src2_b[bit * P.src2_bstride];
-        float cv = 0.0f;
-        for (int j = 0; j < 1024; j++) {
-            u32 a = (u32)P.src1_a[bit * P.src1_stride + j];
-            if (P.src2_a) a += (u32)P.src2_a[bit * P.src2_stride + j];
-            a += 1u << 15;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const u32 dg = (a >> (30 - 2 * k)) & 3u;
-                const int idx = (j * 8 + k) * 4 + (int)dg;
-                b -= (u32)P.ks_b[idx];
-                cv += P.ks_cv[idx];
-            }
+        P.out_b[bit * P.out_b_stride] = (i32)(b - b_sum);
+        if (P.out_cv) {
+            float cv = 0.0f;
+            for (int i = 0; i < 8192; i++) cv += cv_terms[i];
+            P.out_cv[bit * P.out_b_stride] = cv;
         }
-        P.out_b[bit * P.out_b_stride] = (i32)b;
-        if (P.out_cv) P.out_cv[bit * P.out_b_stride] = cv;
     }
 }
 
