@@ -11,97 +11,137 @@
 #define BKF_POLY_ELEMS 512                 /* complex per key polynomial */
 #define BKF_ROW_ELEMS (8 * BKF_POLY_ELEMS)
 
+// Per-wave LDS (18432 bytes): two FFT exchange buffers A | B of 9216 bytes each.
+//  * the accumulator mirror int32[2][1024] (8 KiB) is ALIASED onto buffer B: it is only read at
+//    the start of a step (rotated reads of both polynomials into registers) and rewritten at its
+//    end; in between B is an exchange buffer;
+//  * bara (u16 x 512) lives in the 8 x 128 bytes of row padding of buffer A, which the exchanges
+//    never touch.
 struct BrFftLds {
-    cplx *xbuf;          // FFT_XBUF_ELEMS complex
-    i32 *acc;            // [2][1024] accumulator mirror
-    uint16_t *bara;      // [BR_MAX_LWE]
+    cplx *xbufA;         // FFT_XBUF_ELEMS complex
+    cplx *xbufB;         // FFT_XBUF_ELEMS complex; acc mirror aliases its first 8 KiB
     const cplx *tw1;     // [512]
     const cplx *tw2;     // [64]
 };
 
-// res[mo][r] = coefficient lane + 64 r of  sum_{m,d} digit_d(T_m) (*) BK_row[m][d][mo]
-template <class TSource>
-FF_FN void brf_external_product(u32 (&res)[2][16], TSource &&tsrc, const cplx *row, const BrFftLds &lds,
-                                const FftLane &L)
+FF_FN i32 *brf_acc_mirror(const BrFftLds &lds) { return (i32 *)lds.xbufB; }
+
+FF_FN uint16_t *brf_bara_slot(const BrFftLds &lds, int i)
 {
-    const int lane = L.lane;
-    cplx sum[2][8];
+    // u16 index i -> padding of row (i >> 6): bytes [row * 1152 + 1024, row * 1152 + 1152)
+    return (uint16_t *)((unsigned char *)lds.xbufA + (i >> 6) * (FFT_ROW * 16) + 1024) + (i & 63);
+}
+
+// linear combination + mod-switch of the n mask coefficients into LDS, returns barb (cf. br_prologue)
+FF_FN u32 brf_prologue(const BrSource &s0, const BrSource &s1, i32 c0, long bit, int n, const BrFftLds &lds,
+                       int lane)
+{
+    for (int i = lane; i < n; i += 64) {
+        u32 v = 0;
+        if (s0.p) v += (u32)s0.p * (u32)s0.a[bit * s0.a_stride + i];
+        if (s1.p) v += (u32)s1.p * (u32)s1.a[bit * s1.a_stride + i];
+        *brf_bara_slot(lds, i) = (uint16_t)br_modswitch(v);
+    }
+    u32 vb = (u32)c0;
+    if (s0.p) vb += (u32)s0.p * (u32)s0.b[bit * s0.b_stride];
+    if (s1.p) vb += (u32)s1.p * (u32)s1.b[bit * s1.b_stride];
+    return br_modswitch(vb);
+}
+
+// MAC of the two transformed digit polynomials (d = 0, 1) of input polynomial m against
+// BK_row[m][d][mo], mo = 0, 1 (tgsw_cpu.py:63-77)
+FF_FN void brf_mac_pair(cplx (&sum)[2][8], const cplx (&x)[2][8], const cplx *row, int m, int lane)
+{
 #pragma unroll
-    for (int r = 0; r < 8; r++) { sum[0][r] = cplx{0.0, 0.0}; sum[1][r] = cplx{0.0, 0.0}; }
-#pragma unroll 1
-    for (int m = 0; m < 2; m++) {
-        u32 T[16];
-        tsrc(m, T);
-#pragma unroll 1
-        for (int d = 0; d < 2; d++) {
-            cplx x[8];
+    for (int d = 0; d < 2; d++) {
+        const cplx *poly = row + (m * 2 + d) * 2 * BKF_POLY_ELEMS;
+#pragma unroll
+        for (int mo = 0; mo < 2; mo++) {
+            const cplx *p = poly + mo * BKF_POLY_ELEMS + lane;
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const i32 dr = d == 0 ? br_digit<0>(T[r]) : br_digit<1>(T[r]);
-                const i32 di = d == 0 ? br_digit<0>(T[r + 8]) : br_digit<1>(T[r + 8]);
-                x[r] = cplx{(double)dr, -(double)di};     // a_j - i a_{j+512}
-            }
-            fft_forward(x, lds.xbuf, lds.tw1, lds.tw2, L);
-            const cplx *poly = row + (m * 2 + d) * 2 * BKF_POLY_ELEMS;
-#pragma unroll
-            for (int mo = 0; mo < 2; mo++) {
-                const cplx *p = poly + mo * BKF_POLY_ELEMS + lane;
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const cplx k = p[r * 64];
-                    sum[mo][r].re += x[r].re * k.re - x[r].im * k.im;
-                    sum[mo][r].im += x[r].re * k.im + x[r].im * k.re;
-                }
+                const cplx k = p[r * 64];
+                sum[mo][r].re += x[d][r].re * k.re - x[d][r].im * k.im;
+                sum[mo][r].im += x[d][r].re * k.im + x[d][r].im * k.re;
             }
         }
     }
+}
+
+// res[mo][r] = coefficient lane + 64 r of  sum_{m,d} digit_d(T_m) (*) BK_row[m][d][mo];
+// T[m][r] = coefficient lane + 64 r of input polynomial m.  The two digit polynomials of each m are
+// transformed together, and so are the two output polynomials (fft_*_n<2>).
+FF_FN void brf_external_product(u32 (&res)[2][16], const u32 (&T)[2][16], const cplx *row, const BrFftLds &lds,
+                                const FftLane &L)
+{
+    cplx *const bufs[2] = {lds.xbufA, lds.xbufB};
+    cplx sum[2][8];
 #pragma unroll
-    for (int mo = 0; mo < 2; mo++) {
-        fft_inverse(sum[mo], lds.xbuf, lds.tw1, lds.tw2, L);
+    for (int r = 0; r < 8; r++) { sum[0][r] = cplx{0.0, 0.0}; sum[1][r] = cplx{0.0, 0.0}; }
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        cplx x[2][8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            x[0][r] = cplx{(double)br_digit<0>(T[m][r]), -(double)br_digit<0>(T[m][r + 8])};   // a_j - i a_{j+512}
+            x[1][r] = cplx{(double)br_digit<1>(T[m][r]), -(double)br_digit<1>(T[m][r + 8])};
+        }
+        fft_forward_n<2>(x, bufs, lds.tw1, lds.tw2, L);
+        brf_mac_pair(sum, x, row, m, L.lane);
+#if defined(__HIP_DEVICE_COMPILE__)
+        // keep the key loads of the next polynomial below this point (register pressure)
+        asm volatile("" ::: "memory");
+#endif
+    }
+    fft_inverse_n<2>(sum, bufs, lds.tw1, lds.tw2, L);
+#pragma unroll
+    for (int mo = 0; mo < 2; mo++)
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             res[mo][r] = fft_round_to_u32(sum[mo][r].re);
             res[mo][r + 8] = fft_round_to_u32(-sum[mo][r].im);
         }
-    }
 }
 
-FF_FN void brf_init_acc(u32 (&acc)[2][16], u32 barb, i32 mu, i32 *lds_acc, int lane)
+FF_FN void brf_init_acc(u32 (&acc)[2][16], u32 barb, i32 mu, const BrFftLds &lds, int lane)
 {
+    i32 *mirror = brf_acc_mirror(lds);
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const u32 j = (u32)(lane + 64 * r);
         const u32 t = (j + barb) & 2047u;
         acc[0][r] = 0;
         acc[1][r] = (t < 1024u) ? (u32)mu : 0u - (u32)mu;
-        lds_acc[j] = 0;
-        lds_acc[1024 + j] = (i32)acc[1][r];
+        mirror[j] = 0;
+        mirror[1024 + j] = (i32)acc[1][r];
     }
     WAVE_SYNC();
 }
 
+// One blind-rotate step: ACC += BK_row (.) ((X^a - 1) ACC)  (bootstrap.py:96-109)
 FF_FN void brf_step(u32 (&acc)[2][16], u32 a, const cplx *row, const BrFftLds &lds, const FftLane &L)
 {
     const int lane = L.lane;
-    u32 res[2][16];
-    brf_external_product(
-        res,
-        [&](int m, u32 (&T)[16]) {
+    i32 *mirror = brf_acc_mirror(lds);
+    u32 T[2][16];
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const u32 j = (u32)(lane + 64 * r);
-                const u32 t = (j - a) & 2047u;
-                const u32 v = (u32)lds.acc[m * 1024 + (t & 1023u)];
-                T[r] = ((t & 1024u) ? 0u - v : v) - acc[m][r];
-            }
-        },
-        row, lds, L);
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const u32 j = (u32)(lane + 64 * r);
+            const u32 t = (j - a) & 2047u;
+            const u32 v = (u32)mirror[m * 1024 + (t & 1023u)];
+            T[m][r] = ((t & 1024u) ? 0u - v : v) - acc[m][r];     // polynomials_cpu.py:46-58
+        }
+    WAVE_SYNC();    // every lane has read the mirror before buffer B is reused for exchanges
+    u32 res[2][16];
+    brf_external_product(res, T, row, lds, L);
 #pragma unroll
     for (int mo = 0; mo < 2; mo++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             acc[mo][r] += res[mo][r];
-            lds.acc[mo * 1024 + lane + 64 * r] = (i32)acc[mo][r];
+            mirror[mo * 1024 + lane + 64 * r] = (i32)acc[mo][r];
         }
     WAVE_SYNC();
 }
@@ -109,9 +149,9 @@ FF_FN void brf_step(u32 (&acc)[2][16], u32 a, const cplx *row, const BrFftLds &l
 FF_FN void brf_blind_rotate(u32 (&acc)[2][16], const cplx *bk, int n, u32 barb, i32 mu, const BrFftLds &lds,
                             const FftLane &L)
 {
-    brf_init_acc(acc, barb, mu, lds.acc, L.lane);
+    brf_init_acc(acc, barb, mu, lds, L.lane);
     for (int i = 0; i < n; i++) {
-        const u32 a = WAVE_UNIFORM((u32)lds.bara[i]);
+        const u32 a = WAVE_UNIFORM((u32)*brf_bara_slot(lds, i));
         if (a == 0) continue;
         brf_step(acc, a, bk + (long)i * BKF_ROW_ELEMS, lds, L);
     }

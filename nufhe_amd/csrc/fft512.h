@@ -113,82 +113,124 @@ FF_FN void dft8(cplx (&x)[8])
                      (j) == 3 ? -0.55557023301960222474 : (j) == 4 ? -0.70710678118654752440 :                  \
                      (j) == 5 ? -0.83146961230254523708 : (j) == 6 ? -0.92387953251128675613 : -0.98078528040323044913)
 
-// Forward transform.
-//   in : x[j2] = (a_j, -a_{j+512}) for j = lane + 64 j2   (i.e. a_j - i a_{j+512})
-//   out: x[d]  = X_k, k = fft_freq_index(lane, d)
-FF_FN void fft_forward(cplx (&x)[8], cplx *xbuf, const cplx *tw1, const cplx *tw2, const FftLane &L)
+// Forward transform of NX independent polynomials at once (their passes are interleaved between
+// the wave-level sync points, so one LDS round trip serves NX transforms).
+//   in : x[i][j2] = (a_j, -a_{j+512}) for j = lane + 64 j2   (i.e. a_j - i a_{j+512})
+//   out: x[i][d]  = X_k, k = fft_freq_index(lane, d)
+// xbuf[i]: private exchange buffer of transform i (FFT_XBUF_ELEMS complex each)
+template <int NX>
+FF_FN void fft_forward_n(cplx (&x)[NX][8], cplx *const (&xbuf)[NX], const cplx *tw1, const cplx *tw2,
+                         const FftLane &L)
 {
 #pragma unroll
-    for (int j = 1; j < 8; j++) x[j] = c_mul(x[j], cplx{FFT_G_RE(j), FFT_G_IM(j)});
-    dft8<false>(x);
+    for (int t = 0; t < NX; t++) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int k2 = br3(i);
-        xbuf[L.x1w + k2 * FFT_ROW] = c_mul(x[i], tw1[k2 * 64 + L.lane]);
+        for (int j = 1; j < 8; j++) x[t][j] = c_mul(x[t][j], cplx{FFT_G_RE(j), FFT_G_IM(j)});
+        dft8<false>(x[t]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int k2 = br3(i);
+            xbuf[t][L.x1w + k2 * FFT_ROW] = c_mul(x[t][i], tw1[k2 * 64 + L.lane]);
+        }
     }
     WAVE_SYNC();
 #pragma unroll
-    for (int b = 0; b < 8; b++) x[b] = xbuf[L.x1r + 8 * b];
-    WAVE_SYNC();
-    dft8<false>(x);
+    for (int t = 0; t < NX; t++)
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int c = br3(i);
-        const cplx v = c == 0 ? x[i] : c_mul(x[i], tw2[c * 8 + L.a]);
-        xbuf[L.x2a + 8 * c + ((L.a + c) & 7)] = v;
+        for (int b = 0; b < 8; b++) x[t][b] = xbuf[t][L.x1r + 8 * b];
+    WAVE_SYNC();
+#pragma unroll
+    for (int t = 0; t < NX; t++) {
+        dft8<false>(x[t]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int c = br3(i);
+            const cplx v = c == 0 ? x[t][i] : c_mul(x[t][i], tw2[c * 8 + L.a]);
+            xbuf[t][L.x2a + 8 * c + ((L.a + c) & 7)] = v;
+        }
     }
     WAVE_SYNC();
     // now this lane is (k2, c = lane & 7); read a = 0..7
 #pragma unroll
-    for (int a = 0; a < 8; a++) x[a] = xbuf[L.x2a + 8 * L.a + ((a + L.a) & 7)];
+    for (int t = 0; t < NX; t++)
+#pragma unroll
+        for (int a = 0; a < 8; a++) x[t][a] = xbuf[t][L.x2a + 8 * L.a + ((a + L.a) & 7)];
     WAVE_SYNC();
-    dft8<false>(x);
-    cplx y[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) y[br3(i)] = x[i];
+    for (int t = 0; t < NX; t++) {
+        dft8<false>(x[t]);
+        cplx y[8];
 #pragma unroll
-    for (int d = 0; d < 8; d++) x[d] = y[d];
+        for (int i = 0; i < 8; i++) y[br3(i)] = x[t][i];
+#pragma unroll
+        for (int d = 0; d < 8; d++) x[t][d] = y[d];
+    }
 }
 
-// Inverse transform (includes 1/512 and the conj(w^j) untwist).
-//   in : x[d]  = X_k, k = fft_freq_index(lane, d)
-//   out: x[j2] = y_j for j = lane + 64 j2:  a_j = Re y_j,  a_{j+512} = -Im y_j  (before rounding)
+// Inverse transform of NX polynomials at once (includes 1/512 and the conj(w^j) untwist).
+//   in : x[i][d]  = X_k, k = fft_freq_index(lane, d)
+//   out: x[i][j2] = y_j for j = lane + 64 j2:  a_j = Re y_j,  a_{j+512} = -Im y_j  (before rounding)
+template <int NX>
+FF_FN void fft_inverse_n(cplx (&x)[NX][8], cplx *const (&xbuf)[NX], const cplx *tw1, const cplx *tw2,
+                         const FftLane &L)
+{
+#pragma unroll
+    for (int t = 0; t < NX; t++) {
+        dft8<true>(x[t]);                                   // pass 3 inverse: d -> a
+#pragma unroll
+        for (int i = 0; i < 8; i++) {                       // lane = (k2, c): write a
+            const int a = br3(i);
+            xbuf[t][L.x2a + 8 * L.a + ((a + L.a) & 7)] = x[t][i];
+        }
+    }
+    WAVE_SYNC();
+#pragma unroll
+    for (int t = 0; t < NX; t++)
+#pragma unroll
+        for (int c = 0; c < 8; c++) {                       // lane = (k2, a): read c, * conj(V^(a c))
+            const cplx v = xbuf[t][L.x2a + 8 * c + ((L.a + c) & 7)];
+            x[t][c] = c == 0 ? v : c_mul_conj(v, tw2[c * 8 + L.a]);
+        }
+    WAVE_SYNC();
+#pragma unroll
+    for (int t = 0; t < NX; t++) {
+        dft8<true>(x[t]);                                   // pass 2 inverse: c -> b
+#pragma unroll
+        for (int i = 0; i < 8; i++) xbuf[t][L.x1r + 8 * br3(i)] = x[t][i];
+    }
+    WAVE_SYNC();
+#pragma unroll
+    for (int t = 0; t < NX; t++)
+#pragma unroll
+        for (int k2 = 0; k2 < 8; k2++)                      // lane = j1: read k2, * conj(tw1)
+            x[t][k2] = c_mul_conj(xbuf[t][L.x1w + k2 * FFT_ROW], tw1[k2 * 64 + L.lane]);
+    WAVE_SYNC();
+    const double sc = 1.0 / 512.0;
+#pragma unroll
+    for (int t = 0; t < NX; t++) {
+        dft8<true>(x[t]);                                   // pass 1 inverse: k2 -> j2
+        cplx y[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) y[br3(i)] = x[t][i];
+        x[t][0] = cplx{y[0].re * sc, y[0].im * sc};
+#pragma unroll
+        for (int j = 1; j < 8; j++) x[t][j] = c_mul_conj(y[j], cplx{FFT_G_RE(j) * sc, FFT_G_IM(j) * sc});
+    }
+}
+
+// single-polynomial wrappers
+FF_FN void fft_forward(cplx (&x)[8], cplx *xbuf, const cplx *tw1, const cplx *tw2, const FftLane &L)
+{
+    cplx (&xs)[1][8] = reinterpret_cast<cplx (&)[1][8]>(x);
+    cplx *const bufs[1] = {xbuf};
+    fft_forward_n<1>(xs, bufs, tw1, tw2, L);
+}
+
 FF_FN void fft_inverse(cplx (&x)[8], cplx *xbuf, const cplx *tw1, const cplx *tw2, const FftLane &L)
 {
-    // pass 3 inverse: d -> a
-    dft8<true>(x);
-    // lane = (k2, c): write a (bit-reversed registers), twiddle 2 conj
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int a = br3(i);
-        xbuf[L.x2a + 8 * L.a + ((a + L.a) & 7)] = x[i];
-    }
-    WAVE_SYNC();
-    // lane = (k2, a): read c = 0..7, multiply by conj(V^(a c))
-#pragma unroll
-    for (int c = 0; c < 8; c++) {
-        const cplx v = xbuf[L.x2a + 8 * c + ((L.a + c) & 7)];
-        x[c] = c == 0 ? v : c_mul_conj(v, tw2[c * 8 + L.a]);
-    }
-    WAVE_SYNC();
-    // pass 2 inverse: c -> b
-    dft8<true>(x);
-#pragma unroll
-    for (int i = 0; i < 8; i++) xbuf[L.x1r + 8 * br3(i)] = x[i];
-    WAVE_SYNC();
-    // lane = j1: read k2 = 0..7, multiply by conj(tw1)
-#pragma unroll
-    for (int k2 = 0; k2 < 8; k2++) x[k2] = c_mul_conj(xbuf[L.x1w + k2 * FFT_ROW], tw1[k2 * 64 + L.lane]);
-    WAVE_SYNC();
-    // pass 1 inverse: k2 -> j2, then conj(g^j2) / 512
-    dft8<true>(x);
-    cplx y[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) y[br3(i)] = x[i];
-    const double sc = 1.0 / 512.0;
-    x[0] = cplx{y[0].re * sc, y[0].im * sc};
-#pragma unroll
-    for (int j = 1; j < 8; j++) x[j] = c_mul_conj(y[j], cplx{FFT_G_RE(j) * sc, FFT_G_IM(j) * sc});
+    cplx (&xs)[1][8] = reinterpret_cast<cplx (&)[1][8]>(x);
+    cplx *const bufs[1] = {xbuf};
+    fft_inverse_n<1>(xs, bufs, tw1, tw2, L);
 }
 
 // round-to-nearest-even to the low 32 bits (two's complement), valid for |v| < 2^51

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_blind_rotate_accum(
 // ------------------------------------------------------------------------------------------
 #define FTABLE_LDS_BYTES ((FFT_TW1_ELEMS + FFT_TW2_ELEMS) * 16)
 #define WAVE_FXBUF_BYTES (FFT_XBUF_ELEMS * 16)
-#define WAVE_BRF_LDS_BYTES (WAVE_FXBUF_BYTES + WAVE_ACC_BYTES + WAVE_BARA_BYTES)
+#define WAVE_BRF_LDS_BYTES (2 * WAVE_FXBUF_BYTES)   /* acc mirror and bara are aliased: blind_rotate_fft.h */
 
 __device__ __forceinline__ void load_ftables(const cplx *__restrict__ g_tw1, const cplx *__restrict__ g_tw2)
 {
@@ -133,9 +133,8 @@ __device__ __forceinline__ BrFftLds carve_brf_lds(int wave)
 {
     unsigned char *base = g_smem + FTABLE_LDS_BYTES + wave * WAVE_BRF_LDS_BYTES;
     BrFftLds lds;
-    lds.xbuf = (cplx *)base;
-    lds.acc = (i32 *)(base + WAVE_FXBUF_BYTES);
-    lds.bara = (uint16_t *)(base + WAVE_FXBUF_BYTES + WAVE_ACC_BYTES);
+    lds.xbufA = (cplx *)base;
+    lds.xbufB = (cplx *)(base + WAVE_FXBUF_BYTES);
     lds.tw1 = (const cplx *)g_smem;
     lds.tw2 = (const cplx *)g_smem + FFT_TW1_ELEMS;
     return lds;
@@ -152,9 +151,7 @@ __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_bootstrap_fft(BrLaunch 
 
     const BrFftLds lds = carve_brf_lds(wave);
     const FftLane L = fft_lane_init(lane);
-    BrLds plds;
-    plds.bara = lds.bara;
-    const u32 barb = br_prologue(P.job[job].s0, P.job[job].s1, P.job[job].c0, bit, P.n, plds, lane);
+    const u32 barb = brf_prologue(P.job[job].s0, P.job[job].s1, P.job[job].c0, bit, P.n, lds, lane);
     WAVE_SYNC();
     u32 acc[2][16];
     brf_blind_rotate(acc, (const cplx *)P.bk, P.n, barb, P.mu, lds, L);
@@ -173,24 +170,19 @@ __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_blind_rotate_accum_fft(
     const BrFftLds lds = carve_brf_lds(wave);
     const FftLane L = fft_lane_init(lane);
     i32 *my = accum + bit * 2048;
+    i32 *mirror = brf_acc_mirror(lds);
     u32 acc[2][16];
 #pragma unroll
     for (int m = 0; m < 2; m++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             acc[m][r] = (u32)my[m * 1024 + lane + 64 * r];
-            lds.acc[m * 1024 + lane + 64 * r] = (i32)acc[m][r];
+            mirror[m * 1024 + lane + 64 * r] = (i32)acc[m][r];
         }
     WAVE_SYNC();
     if (external_mul_only) {
         u32 res[2][16];
-        brf_external_product(
-            res,
-            [&](int m, u32(&T)[16]) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) T[r] = acc[m][r];
-            },
-            bk + (long)row0 * BKF_ROW_ELEMS, lds, L);
+        brf_external_product(res, acc, bk + (long)row0 * BKF_ROW_ELEMS, lds, L);
 #pragma unroll
         for (int m = 0; m < 2; m++)
 #pragma unroll

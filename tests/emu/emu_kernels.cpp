@@ -153,15 +153,12 @@ void emu_bootstrap_bit_fft(i32 *out_a, i32 *out_b, const double *bk_internal, in
                            i32 c0, i32 mu)
 {
     ftables();
-    std::vector<cplx> xbuf(FFT_XBUF_ELEMS);
-    std::vector<i32> accbuf(2048);
-    std::vector<uint16_t> bara(BR_MAX_LWE);
-    BrFftLds lds{xbuf.data(), accbuf.data(), bara.data(), g_ftw1, g_ftw2};
-    BrLds plds{nullptr, accbuf.data(), bara.data(), nullptr, nullptr};
+    std::vector<cplx> xbuf(2 * FFT_XBUF_ELEMS);
+    BrFftLds lds{xbuf.data(), xbuf.data() + FFT_XBUF_ELEMS, g_ftw1, g_ftw2};
     BrSource s0{a0, b0, 0, 0, p0}, s1{a1, b1, 0, 0, p1};
     emu_run_wave([&](int lane) {
         FftLane L = fft_lane_init(lane);
-        u32 barb = br_prologue(s0, s1, c0, 0, n, plds, lane);
+        u32 barb = brf_prologue(s0, s1, c0, 0, n, lds, lane);
         WAVE_SYNC();
         u32 acc[2][16];
         brf_blind_rotate(acc, (const cplx *)bk_internal, n, barb, mu, lds, L);
