@@ -99,10 +99,10 @@ FF_FN void br_external_product(u64 (&sum)[2][16], TSource &&tsrc, const u64 *row
 #pragma unroll
         for (int d = 0; d < 2; d++) {
             u64 x[16];
+            i32 dg[16];
 #pragma unroll
-            for (int r = 0; r < 16; r++)
-                x[r] = ff_from_i32(d == 0 ? br_digit<0>(T[r]) : br_digit<1>(T[r]));
-            ntt_forward(x, lds.xbuf, lds.tw1f, L);
+            for (int r = 0; r < 16; r++) dg[r] = d == 0 ? br_digit<0>(T[r]) : br_digit<1>(T[r]);
+            ntt_forward_small(x, dg, lds.xbuf, lds.tw1f, L);
             // multiply-accumulate against BK[i][m][d][mo] (tgsw_cpu.py:63-77)
             const u64 *poly = row + (m * 2 + d) * 2 * BK_POLY_ELEMS;
 #pragma unroll
@@ -117,9 +117,13 @@ FF_FN void br_external_product(u64 (&sum)[2][16], TSource &&tsrc, const u64 *row
             }
         }
     }
+    // NEG_OUT: coefficients j2 >= 1 come back negated (callers use br_coeff_to_u32)
 #pragma unroll
-    for (int mo = 0; mo < 2; mo++) ntt_inverse(sum[mo], lds.xbuf, lds.tw1i, L);
+    for (int mo = 0; mo < 2; mo++) ntt_inverse_t<true>(sum[mo], lds.xbuf, lds.tw1i, L);
 }
+
+// int32 value of coefficient register r of br_external_product's result
+FF_FN u32 br_coeff_to_u32(u64 v, int r) { return r == 0 ? (u32)ff_to_i32(v) : 0u - (u32)ff_to_i32(v); }
 
 // ACC = (0, X^(2N - barb) * mu) (bootstrap.py:176-182): body coefficient j is +mu if
 // (j + barb) mod 2N < N, else -mu.  Fills the registers and the LDS mirror.
@@ -160,7 +164,7 @@ FF_FN void br_step(u32 (&acc)[2][16], u32 a, const u64 *row, const BrLds &lds, c
     for (int mo = 0; mo < 2; mo++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            acc[mo][r] += (u32)ff_to_i32(sum[mo][r]);
+            acc[mo][r] += br_coeff_to_u32(sum[mo][r], r);
             lds.acc[mo * 1024 + lane + 64 * r] = (i32)acc[mo][r];
         }
     WAVE_SYNC();

@@ -31,9 +31,14 @@ FF_FN u64 ff_sub(u64 a, u64 b)
     return (a < b) ? d - FF_EPS : d;   // borrow: + P == - EPS (mod 2^64)
 }
 
-// a, b canonical -> canonical.  a + b - P is computed as a - (P - b): one borrow decides,
-// no 64-bit compare against P is needed.
-FF_FN u64 ff_add(u64 a, u64 b) { return ff_sub(a, FF_P - b); }
+// a, b canonical -> canonical: on carry-out or s >= P subtract P, i.e. add EPS modulo 2^64
+// (one v_lshl_add_u64, two 64-bit compares, one select, one v_lshl_add_u64 on gfx950)
+FF_FN u64 ff_add(u64 a, u64 b)
+{
+    const u64 s = a + b;
+    const u32 m = ((s < a) | (s >= FF_P)) ? 0xFFFFFFFFu : 0u;
+    return s + (u64)m;
+}
 
 FF_FN u64 ff_neg(u64 a) { return ff_sub(0, a); }
 
@@ -43,15 +48,23 @@ FF_FN u64 ff_canon(u64 x) { return x >= FF_P ? x - FF_P : x; }
 // w * (2^32 - 1), canonical for any 32-bit w
 FF_FN u64 ff_times_eps(u32 w) { return ((u64)w << 32) - w; }
 
+// lo + 2^64 * h0 -> canonical, for ANY 64-bit lo and 32-bit h0.
+// lo + h0 * eps <= (2^64 - 1) + (2^32 - 1)^2 = 2P - 2, so ONE conditional subtraction of P (= adding
+// eps modulo 2^64) finishes the job: on gfx950 a v_mad_u64_u32, two 64-bit compares, a select and
+// a 64-bit add.
+FF_FN u64 ff_reduce96(u64 lo, u32 h0)
+{
+    const u64 s = lo + (u64)h0 * FF_EPS;
+    const u32 m = ((s < lo) | (s >= FF_P)) ? 0xFFFFFFFFu : 0u;
+    return s + (u64)m;
+}
+
 // lo + 2^64 * (h0 + 2^32 h1) -> canonical    (2^64 = 2^32 - 1, 2^96 = -1)
 FF_FN u64 ff_reduce128(u64 lo, u32 h0, u32 h1)
 {
     u64 t = lo - h1;
     if (lo < h1) t -= FF_EPS;              // borrow: + P; cannot underflow again
-    u64 m = ff_times_eps(h0);
-    u64 r = t + m;
-    if (r < m) r += FF_EPS;                // carry: + 2^64 = + EPS; cannot overflow again
-    return ff_canon(r);
+    return ff_reduce96(t, h0);
 }
 
 FF_FN void ff_mul_wide(u64 a, u64 b, u64 &lo, u64 &hi)
@@ -90,9 +103,9 @@ template <int Q>
 FF_FN u64 ff_place96(u32 w0, u32 w1, u32 w2)
 {
     if constexpr (Q == 0) {          // (w1:w0) + w2 * eps
-        return ff_reduce128(((u64)w1 << 32) | w0, w2, 0);
+        return ff_reduce96(((u64)w1 << 32) | w0, w2);
     } else if constexpr (Q == 1) {   // w0 2^32 + w1 eps - w2
-        return ff_add(ff_sub((u64)w0 << 32, (u64)w2), ff_times_eps(w1));
+        return ff_reduce96(ff_sub((u64)w0 << 32, (u64)w2), w1);
     } else {               // w0 eps - (w2:w1)
         return ff_sub(ff_times_eps(w0), ((u64)w2 << 32) | w1);
     }
@@ -127,11 +140,31 @@ FF_FN u64 ff_mul_pow2(u64 x)
     else return ff_mul_pow2_lt96<T>(x);
 }
 
+// (a - b) * 2^S for canonical a, b; a twiddle 2^S with S >= 96 (mod 192) is -2^(S-96): the sign is
+// absorbed by swapping the operands of the subtraction instead of negating the product.
+template <int S>
+FF_FN u64 ff_submul_pow2(u64 a, u64 b)
+{
+    constexpr int T = ((S % 192) + 192) % 192;
+    if constexpr (T >= 96) return ff_mul_pow2_lt96<T - 96>(ff_sub(b, a));
+    else return ff_mul_pow2_lt96<T>(ff_sub(a, b));
+}
+
+// small signed integer d (|d| <= 2^10, e.g. a gadget digit) times 2^S -> canonical, for S <= 53:
+// the product fits a signed 64-bit word, so the residue is t or t + P.
+template <int S>
+FF_FN u64 ff_small_times_pow2(i32 d)
+{
+    static_assert(S >= 0 && S <= 53, "shift out of range");
+    const u64 t = (u64)((int64_t)d << S);
+    return d < 0 ? t + FF_P : t;
+}
+
 // canonical x times 2^r, r a run-time (per-lane) amount in [0, 31]
 FF_FN u64 ff_mul_pow2_var(u64 x, u32 r)
 {
     const u32 hi = (u32)(x >> 32);
     const u64 sh = x << r;                      // low 64 bits of x * 2^r
     const u32 w2 = (hi >> 1) >> (31 - r);       // bits shifted out (r = 0 safe)
-    return ff_reduce128(sh, w2, 0);
+    return ff_reduce96(sh, w2);
 }

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_blind_rotate_accum(
 #pragma unroll
         for (int m = 0; m < 2; m++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[m][r] = (u32)ff_to_i32(sum[m][r]);
+            for (int r = 0; r < 16; r++) acc[m][r] = br_coeff_to_u32(sum[m][r], r);
     } else {
         for (int i = 0; i < n_rows; i++) {
             const u32 a = WAVE_UNIFORM((u32)bara[bit * bara_stride + i]) & 2047u;

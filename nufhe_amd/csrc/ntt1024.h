@@ -98,7 +98,7 @@ FF_FN void ntt16_dif(u64 (&x)[16])
     do {                                              \
         const u64 _a = x[i], _b = x[j];               \
         x[i] = ff_add(_a, _b);                        \
-        x[j] = ff_mul_pow2<(S)>(ff_sub(_a, _b));      \
+        x[j] = ff_submul_pow2<(S)>(_a, _b);           \
     } while (0)
     // stage 0: span 8, twiddle omega^j
     BFLY(0, 8, 0);  BFLY(1, 9, W);  BFLY(2, 10, 2 * W);  BFLY(3, 11, 3 * W);
@@ -120,7 +120,7 @@ template <int W>
 FF_FN void ntt4(u64 &x0, u64 &x1, u64 &x2, u64 &x3)
 {
     const u64 u0 = ff_add(x0, x2), v0 = ff_sub(x0, x2);
-    const u64 u1 = ff_add(x1, x3), v1 = ff_mul_pow2<W>(ff_sub(x1, x3));
+    const u64 u1 = ff_add(x1, x3), v1 = ff_submul_pow2<W>(x1, x3);
     x0 = ff_add(u0, u1);
     x2 = ff_sub(u0, u1);
     x1 = ff_add(v0, v1);
@@ -132,13 +132,10 @@ FF_FN void ntt4(u64 &x0, u64 &x1, u64 &x2, u64 &x3)
 //   out: x[R]  = A_k, k = ntt_freq_index(lane, R)
 // xbuf: this wave's private LDS exchange buffer (NTT_XBUF_ELEMS u64)
 // tw1f: [16][64] table psi^((2 k2 + 1) j1) at [k2 * 64 + j1] (LDS, shared by the workgroup)
-FF_FN void ntt_forward(u64 (&x)[16], u64 *xbuf, const u64 *tw1f, const NttLane &L)
+// forward transform of already pre-twisted inputs: x[j2] = a_j * 2^(6 j2) (canonical)
+FF_FN void ntt_forward_pretwisted(u64 (&x)[16], u64 *xbuf, const u64 *tw1f, const NttLane &L)
 {
-    // pass 1: pre-twist by theta^j2 = 2^(6 j2), then cyclic 16-point with omega = 2^12
-#define PRE(j2) x[j2] = ff_mul_pow2<6 * (j2)>(x[j2])
-    PRE(1); PRE(2); PRE(3); PRE(4); PRE(5); PRE(6); PRE(7); PRE(8);
-    PRE(9); PRE(10); PRE(11); PRE(12); PRE(13); PRE(14); PRE(15);
-#undef PRE
+    // pass 1 (after the pre-twist by theta^j2 = 2^(6 j2)): cyclic 16-point with omega = 2^12
     ntt16_dif<12>(x);
     // twiddle 1 + exchange 1 (lane j1, reg k2) -> (lane (k2, q), reg r)
 #pragma unroll
@@ -178,11 +175,37 @@ FF_FN void ntt_forward(u64 (&x)[16], u64 *xbuf, const u64 *tw1f, const NttLane &
     ntt4<48>(x[12], x[13], x[14], x[15]);
 }
 
+FF_FN void ntt_forward(u64 (&x)[16], u64 *xbuf, const u64 *tw1f, const NttLane &L)
+{
+#define PRE(j2) x[j2] = ff_mul_pow2<6 * (j2)>(x[j2])
+    PRE(1); PRE(2); PRE(3); PRE(4); PRE(5); PRE(6); PRE(7); PRE(8);
+    PRE(9); PRE(10); PRE(11); PRE(12); PRE(13); PRE(14); PRE(15);
+#undef PRE
+    ntt_forward_pretwisted(x, xbuf, tw1f, L);
+}
+
+// forward transform of a polynomial with SMALL coefficients (|d| <= 2^10: gadget digits):
+// d[j2] = coefficient lane + 64 j2.  The pre-twist d * 2^(6 j2) needs no modular reduction
+// while 6 j2 + 10 < 64.
+FF_FN void ntt_forward_small(u64 (&x)[16], const i32 (&d)[16], u64 *xbuf, const u64 *tw1f, const NttLane &L)
+{
+#define PRES(j2) x[j2] = ff_small_times_pow2<6 * (j2)>(d[j2])
+#define PREG(j2) x[j2] = ff_mul_pow2<6 * (j2)>(ff_from_i32(d[j2]))
+    PRES(0); PRES(1); PRES(2); PRES(3); PRES(4); PRES(5); PRES(6); PRES(7); PRES(8);
+    PREG(9); PREG(10); PREG(11); PREG(12); PREG(13); PREG(14); PREG(15);
+#undef PRES
+#undef PREG
+    ntt_forward_pretwisted(x, xbuf, tw1f, L);
+}
+
 // Inverse transform (includes the 1/N factor, folded into tw1i).
 //   in : x[R]  = A_k, k = ntt_freq_index(lane, R), canonical
 //   out: x[j2] = canonical field element of coefficient j = lane + 64 j2
 // tw1i: [16][64] table psi^(-(2 k2 + 1) j1) / 1024 at [k2 * 64 + j1]
-FF_FN void ntt_inverse(u64 (&x)[16], u64 *xbuf, const u64 *tw1i, const NttLane &L)
+// NEG_OUT = true: for j2 >= 1 the output is MINUS the coefficient (the post-twist 2^(-6 j2) =
+// -2^(96 - 6 j2) is applied without its sign; the caller folds the sign into its accumulation).
+template <bool NEG_OUT>
+FF_FN void ntt_inverse_t(u64 (&x)[16], u64 *xbuf, const u64 *tw1i, const NttLane &L)
 {
     // pass 3 inverse: 4-point over k1b -> q with omega^-1
     ntt4<-48>(x[0], x[1], x[2], x[3]);
@@ -221,10 +244,16 @@ FF_FN void ntt_inverse(u64 (&x)[16], u64 *xbuf, const u64 *tw1i, const NttLane &
     // pass 1 inverse: cyclic 16-point over k2 -> j2 with omega^-1, then post-twist 2^(-6 j2)
     ntt16_dif<-12>(x);
     u64 y[16];
-#define POST(j2) y[j2] = ff_mul_pow2<-6 * (j2)>(x[br4(j2)])
+#define POST(j2) y[j2] = (NEG_OUT && (j2) > 0) ? ff_mul_pow2_lt96<(96 - 6 * (j2)) % 96>(x[br4(j2)]) \
+                                               : ff_mul_pow2<-6 * (j2)>(x[br4(j2)])
     POST(0); POST(1); POST(2); POST(3); POST(4); POST(5); POST(6); POST(7); POST(8);
     POST(9); POST(10); POST(11); POST(12); POST(13); POST(14); POST(15);
 #undef POST
 #pragma unroll
     for (int j2 = 0; j2 < 16; j2++) x[j2] = y[j2];
+}
+
+FF_FN void ntt_inverse(u64 (&x)[16], u64 *xbuf, const u64 *tw1i, const NttLane &L)
+{
+    ntt_inverse_t<false>(x, xbuf, tw1i, L);
 }
