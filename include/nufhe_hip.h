@@ -118,6 +118,15 @@ int nufhe_gate_binary(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nuf
 int nufhe_gate_mux(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe_lwe a, nufhe_lwe b,
                    nufhe_lwe c, long nbits);
 
+/* Client side.  out[i * out_stride] = base[i * base_stride] + sign * <a[i], key>
+ * with int32 wraparound, sign = +1 or -1:
+ *   LweEncrypt (lwe_gpu.py:186-239):  b = (mu + e) + a.s       (base = mu + e, sign = +1)
+ *   LweDecrypt (lwe_gpu.py:242-284):  phi = b - a.s            (base = b,      sign = -1)
+ *   MakeLweKeyswitchKey body (lwe_gpu.mako:18-56): b = (message + e) + a.s */
+int nufhe_lwe_phase(nufhe_ctx *ctx, int32_t *d_out, long out_stride, const int32_t *d_a, long a_stride,
+                    const int32_t *d_base, long base_stride, const int32_t *d_key, int32_t sign,
+                    long count, int size);
+
 /* ---- per-kernel entry points (reference unit tests' granularity; also used by key generation) */
 
 /* Torus32ToPhase (numeric_functions_gpu.py:39-77) */

@@ -57,6 +57,7 @@ PROTOTYPES = {
     "nufhe_keyswitch": [_vp, _vp, NufheLwe, NufheLwe, _long],
     "nufhe_gate_binary": [_vp, _vp, NufheLwe, NufheLwe, NufheLwe, _i32, _i32, _i32, _i32, _long],
     "nufhe_gate_mux": [_vp, _vp, NufheLwe, NufheLwe, NufheLwe, NufheLwe, _long],
+    "nufhe_lwe_phase": [_vp, _vp, _long, _vp, _long, _vp, _long, _vp, _i32, _long, _int],
     "nufhe_t32_to_phase": [_vp, _vp, _vp, _long, ctypes.c_uint32],
     "nufhe_shift_torus_polynomial": [_vp, _vp, _vp, _vp, _long, _long, _long, _int, _int, _int],
     "nufhe_tlwe_extract": [_vp, _vp, _vp, _vp, _long],

@@ -65,6 +65,10 @@ class NuFHEParameters:
             and self._tlwe_mask_size == other._tlwe_mask_size)
 
 
+# pickled under the reference's module path (nufhe_amd/serialization.py)
+NuFHEParameters.__module__ = 'nufhe.api_low_level'
+
+
 class NuFHESecretKey:
     """A secret key (nufhe/api_low_level.py:90-148)."""
 

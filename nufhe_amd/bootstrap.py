@@ -13,6 +13,7 @@ import pickle
 import numpy
 
 from . import _lib
+from . import serialization
 from .device import ptr
 from .lwe import LweParams, LweKey, LweSampleArray, LweKeyswitchKey, _Flat
 from .tgsw import TGswKey, TGswParams, tgsw_encrypt_int
@@ -80,16 +81,20 @@ class BootstrapKey:
         return out
 
     def dump(self, file_obj):
-        pickle.dump(self.in_out_params, file_obj)
-        pickle.dump(self.bk_params, file_obj)
-        pickle.dump(self.transformed_reference_format(), file_obj)
+        """The reference's record sequence (bootstrap.py:78-80 and the nested dumps)."""
+        serialization.write_bootstrap_key(
+            file_obj, self.in_out_params, self.bk_params, self.transformed_reference_format(),
+            serialization.bootstrap_key_variances(self.in_out_params, self.bk_params))
 
     @classmethod
     def load(cls, file_obj, thr, native: NativeCloudKey):
-        in_out_params = pickle.load(file_obj)
-        bk_params = pickle.load(file_obj)
+        in_out_params, bk_params, coeffs, _ = serialization.read_bootstrap_key(file_obj)
         fft = bk_params.tlwe_params.transform_type == 'FFT'
-        arr = numpy.ascontiguousarray(pickle.load(file_obj), numpy.complex128 if fft else numpy.uint64)
+        arr = numpy.ascontiguousarray(coeffs, numpy.complex128 if fft else numpy.uint64)
+        expected = (in_out_params.size, 2, bk_params.decomp_length, 2,
+                    bk_params.tlwe_params.polynomial_degree // (2 if fft else 1))
+        if tuple(arr.shape) != expected:
+            raise ValueError("bootstrap key array has shape %s, expected %s" % (arr.shape, expected))
         _lib.call("nufhe_bk_upload_reference", native.handle, arr.ctypes.data_as(ctypes.c_void_p))
         return cls(in_out_params, bk_params, native)
 

@@ -526,6 +526,17 @@ int nufhe_gate_mux(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe_
     return run_gate(ctx, key, result, jobs, 2, MU, nbits, true, MU);             // (0,1/8) + u1 + u2 -> KS, :657-664
 }
 
+int nufhe_lwe_phase(nufhe_ctx *ctx, int32_t *d_out, long out_stride, const int32_t *d_a, long a_stride,
+                    const int32_t *d_base, long base_stride, const int32_t *d_key, int32_t sign, long count, int size)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (count < 0 || size < 1) return fail(NUFHE_EINVAL, "bad sizes");
+    if (sign != 1 && sign != -1) return fail(NUFHE_EINVAL, "sign must be +1 or -1");
+    HIP_TRY(launch_lwe_phase(d_out, out_stride, d_a, a_stride, d_base, base_stride, d_key, sign, count, size, ctx->stream));
+    return NUFHE_OK;
+}
+
 // ---- per-kernel entry points -------------------------------------------------------------
 
 int nufhe_t32_to_phase(nufhe_ctx *ctx, int32_t *d_result, const int32_t *d_phase, long count, uint32_t mspace_size)

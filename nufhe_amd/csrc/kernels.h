@@ -90,6 +90,8 @@ hipError_t launch_keyswitch(const KsLaunch &P, const KsFinal &F, hipStream_t str
 hipError_t launch_lwe_linear(const LweView &res, const LweView &src, i32 p, int add_result, long nbits, int size,
                              hipStream_t stream);
 hipError_t launch_lwe_trivial_const(const LweView &res, i32 mu, long nbits, int size, hipStream_t stream);
+hipError_t launch_lwe_phase(i32 *out, long out_stride, const i32 *a, long a_stride, const i32 *base, long base_stride,
+                            const i32 *key, i32 sign, long count, int n, hipStream_t stream);
 hipError_t launch_t32_to_phase(i32 *result, const i32 *phase, long count, u32 mspace, hipStream_t stream);
 hipError_t launch_shift_tp(i32 *result, const i32 *source, const i32 *powers, long powers_stride, long powers_idx,
                            long batch, int polys, int minus_one, int invert_powers, hipStream_t stream);

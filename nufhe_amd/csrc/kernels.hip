@@ -559,6 +559,23 @@ __global__ void k_lwe_trivial_const(LweView res, i32 mu, long nbits, int size)
     }
 }
 
+// LWE phase / dot product: out[i] = base[i] + sign * sum_j a[i][j] * key[j]  (int32 wraparound).
+// LweEncrypt (b = mu + e + a.s, lwe_cpu.py:96-104), LweDecrypt (phi = b - a.s, :107-112) and the
+// body of MakeLweKeyswitchKey (:36) are all this kernel.  One wave per sample.
+__global__ __launch_bounds__(256) void k_lwe_phase(i32 *__restrict__ out, long out_stride, const i32 *__restrict__ a,
+                                                   long a_stride, const i32 *__restrict__ base, long base_stride,
+                                                   const i32 *__restrict__ key, i32 sign, long count, int n)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * 4 + wave;
+    if (i >= count) return;
+    u32 acc = 0;
+    for (int j = lane; j < n; j += 64) acc += (u32)a[i * a_stride + j] * (u32)key[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += (u32)__shfl_xor((int)acc, off, 64);
+    if (lane == 0) out[i * out_stride] = (i32)((u32)base[i * base_stride] + (u32)sign * acc);
+}
+
 // Torus32ToPhase, numeric_functions_cpu.py:23-37
 __global__ void k_t32_to_phase(i32 *__restrict__ result, const i32 *__restrict__ phase, long count, u32 interv)
 {
@@ -754,6 +771,15 @@ hipError_t launch_lwe_trivial_const(const LweView &res, i32 mu, long nbits, int 
     if (nbits == 0) return hipSuccess;
     hipLaunchKernelGGL(k_lwe_trivial_const, dim3(blocks_for(nbits * (size + 1), 256)), dim3(256), 0, stream, res, mu,
                        nbits, size);
+    return hipGetLastError();
+}
+
+hipError_t launch_lwe_phase(i32 *out, long out_stride, const i32 *a, long a_stride, const i32 *base, long base_stride,
+                            const i32 *key, i32 sign, long count, int n, hipStream_t stream)
+{
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_lwe_phase, dim3(blocks_for(count, 4)), dim3(256), 0, stream, out, out_stride, a, a_stride,
+                       base, base_stride, key, sign, count, n);
     return hipGetLastError();
 }
 

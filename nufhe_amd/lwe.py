@@ -15,7 +15,7 @@ import numpy
 import torch
 
 from . import _lib
-from .device import DeviceThread, lwe_desc
+from .device import DeviceThread, lwe_desc, ptr
 from .numeric_functions import Torus32, ErrorFloat
 from .random_numbers import rand_uniform_bool, rand_gaussian_torus32_host
 from .utils import arrays_equal, to_numpy
@@ -38,6 +38,10 @@ class LweParams:
 
     def __hash__(self):
         return hash((self.__class__, self.size, self.min_noise, self.max_noise))
+
+
+# pickled under the reference's module path (nufhe_amd/serialization.py)
+LweParams.__module__ = 'nufhe.lwe'
 
 
 class LweKey:
@@ -263,7 +267,14 @@ class LweKeyswitchKey:
         js = numpy.arange(ks_decomp_length)[None, :, None]
         scale = (numpy.uint32(1) << (32 - (js + 1) * ks_log2_base).astype(numpy.uint32))
         messages = in_key.astype(numpy.uint32)[:, None, None] * hs * scale          # lwe_cpu.py:54
-        dots = (noises_a.astype(numpy.uint32) * out_key.astype(numpy.uint32)).sum(-1, dtype=numpy.uint32)
+        # <noises_a, out_key> on the GPU (the body of MakeLweKeyswitchKey, lwe_gpu.mako:18-56)
+        na_dev = thr.to_device(noises_a).reshape(-1, output_size)
+        zero_dev = thr.zeros((na_dev.shape[0],), Torus32)
+        dots_dev = thr.array((na_dev.shape[0],), Torus32)
+        _lib.call("nufhe_lwe_phase", thr.handle, ptr(dots_dev), 1, ptr(na_dev), output_size, ptr(zero_dev), 1,
+                  ptr(lwe_key.key.contiguous()), 1, na_dev.shape[0], output_size)
+        dots = to_numpy(dots_dev).view(numpy.uint32).reshape(noises_b.shape)
+        del na_dev
         ks_a[:, :, 1:, :] = noises_a                                                 # lwe_cpu.py:35
         ks_b[:, :, 1:] = (messages + noises_b.astype(numpy.uint32) + dots).astype(numpy.uint32).view(Torus32)
         ks_cv[:, :, 1:] = noise**2                                                   # lwe_cpu.py:37
@@ -323,25 +334,33 @@ def lwe_keyswitch(thr: DeviceThread, result: LweSampleArray, ks: LweKeyswitchKey
 
 
 def lwe_encrypt(thr: DeviceThread, rng, result: LweSampleArray, messages, noise: float, key: LweKey):
-    """nufhe/lwe.py:325-333 + LweEncryptReference (lwe_cpu.py:96-104), host-side."""
+    """nufhe/lwe.py:325-333: randomness on the host in the reference's order (Gaussian b-noise, then
+    the uniform mask), b = mu + e + a.s on the GPU (LweEncrypt, lwe_cpu.py:96-104)."""
     messages = to_numpy(messages).astype(Torus32)
     lwe_size = key.params.size
     noises_b = rand_gaussian_torus32_host(rng, 0, noise, messages.shape)
     noises_a = rng.uniform_torus32(messages.shape + (lwe_size,))
-    key_h = to_numpy(key.key).astype(numpy.uint32)
-    dots = (noises_a.astype(numpy.uint32) * key_h).sum(-1, dtype=numpy.uint32)
-    b = (noises_b.astype(numpy.uint32) + messages.astype(numpy.uint32) + dots).astype(numpy.uint32).view(Torus32)
-    result.a.copy_(thr.to_device(noises_a))
-    result.b.copy_(thr.to_device(b.reshape(messages.shape)))
+    base = (noises_b.astype(numpy.uint32) + messages.astype(numpy.uint32)).view(Torus32)
+    a_dev = thr.to_device(noises_a).reshape(-1, lwe_size)
+    base_dev = thr.to_device(base).reshape(-1)
+    b_dev = thr.array((base_dev.shape[0],), Torus32)
+    key_dev = key.key.contiguous()
+    _lib.call("nufhe_lwe_phase", thr.handle, ptr(b_dev), 1, ptr(a_dev), lwe_size, ptr(base_dev), 1,
+              ptr(key_dev), 1, base_dev.shape[0], lwe_size)
+    result.a.copy_(a_dev.reshape(result.a.shape))
+    result.b.copy_(b_dev.reshape(result.b.shape))
     result.current_variances.fill_(float(numpy.float32(noise**2)))
 
 
 def lwe_decrypt(thr: DeviceThread, sample: LweSampleArray, key: LweKey):
-    """nufhe/lwe.py:336-343 + LweDecryptReference (lwe_cpu.py:107-112), host-side."""
-    a = to_numpy(sample.a).astype(numpy.uint32)
-    b = to_numpy(sample.b).astype(numpy.uint32)
-    key_h = to_numpy(key.key).astype(numpy.uint32)
-    return (b - (a * key_h).sum(-1, dtype=numpy.uint32)).astype(numpy.uint32).view(Torus32)
+    """nufhe/lwe.py:336-343: phase b - a.s on the GPU (LweDecrypt, lwe_cpu.py:107-112), returned
+    as a host array."""
+    flat = _Flat(sample, sample.shape)
+    out = thr.array((flat.nbits,), Torus32)
+    key_dev = key.key.contiguous()
+    _lib.call("nufhe_lwe_phase", thr.handle, ptr(out), 1, ptr(flat.a), flat.desc.a_stride, ptr(flat.b),
+              flat.desc.b_stride, ptr(key_dev), -1, flat.nbits, flat.size)
+    return to_numpy(out).reshape(sample.shape)
 
 
 def lwe_noiseless_trivial(thr: DeviceThread, result: LweSampleArray, mus):

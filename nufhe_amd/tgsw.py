@@ -32,6 +32,10 @@ class TGswParams:
         return hash((self.__class__, self.decomp_length, self.bs_log2_base, self.tlwe_params))
 
 
+# pickled under the reference's module path (nufhe_amd/serialization.py)
+TGswParams.__module__ = 'nufhe.tgsw'
+
+
 class TGswKey:
     """nufhe/tgsw.py:70-78"""
 

@@ -39,6 +39,10 @@ class TLweParams:
             self.min_noise, self.max_noise, self.transform_type))
 
 
+# pickled under the reference's module path (nufhe_amd/serialization.py)
+TLweParams.__module__ = 'nufhe.tlwe'
+
+
 class IntPolynomialArray:
     """nufhe/polynomials.py:30-40"""
 

@@ -211,3 +211,31 @@ def test_keyswitch_rejects_nonzero_base0(thr):
         params.in_out_params, ks_a, numpy.zeros((1024, 8, 4), numpy.int32), numpy.zeros((1024, 8, 4), numpy.float32)))
     with pytest.raises(ValueError):
         NuFHECloudKey._attach_keyswitch(NativeCloudKey(thr, 500), ks)
+
+
+def test_lwe_encrypt_decrypt_vs_reference_golden(thr, H, golden, orc):
+    """LweEncrypt / LweDecrypt (test_lwe.py:149-213 of the reference) through nufhe_lwe_phase, and
+    the API-level encrypt == the oracle's encrypt from the same seed."""
+    msgs, key, na, nb = gi.lwe_encrypt_inputs()
+    base = (msgs.astype(numpy.uint32) + nb.astype(numpy.uint32)).view(numpy.int32).reshape(-1)
+    d_a = H.dev(thr, na.reshape(-1, 500)); d_base = H.dev(thr, base); d_key = H.dev(thr, key)
+    out = thr.array((base.size,), numpy.int32)
+    call("nufhe_lwe_phase", thr.handle, ptr(out), 1, ptr(d_a), 500, ptr(d_base), 1, ptr(d_key), 1, base.size, 500)
+    b = H.host(out).reshape(msgs.shape)
+    assert (b == golden['lwe_encrypt_b']).all()
+    d_b = H.dev(thr, b.reshape(-1))
+    dec = thr.array((base.size,), numpy.int32)
+    call("nufhe_lwe_phase", thr.handle, ptr(dec), 1, ptr(d_a), 500, ptr(d_b), 1, ptr(d_key), -1, base.size, 500)
+    assert (H.host(dec).reshape(msgs.shape) == golden['lwe_decrypt']).all()
+
+    import nufhe_amd
+    lwe_key = orc.DeterministicRNG(3).uniform_bool((500,))
+    sk = H.secret_key_from_array(thr, lwe_key)
+    ctx = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(77), thread=thr)
+    m = numpy.random.RandomState(1).randint(0, 2, size=(5, 7)).astype(bool)
+    ct = ctx.encrypt(sk, m)
+    exp = orc.encrypt(orc.DeterministicRNG(77), lwe_key, m)
+    a, b2, cv = H.ct_arrays(ct)
+    assert (a == exp[0]).all() and (b2 == exp[1]).all() and (cv == exp[2]).all()
+    assert (ctx.decrypt(sk, ct) == m).all()
+    assert (ctx.decrypt(sk, ct[1:4, ::2]) == m[1:4, ::2]).all()      # strided view
