@@ -1,7 +1,11 @@
-"""Equivalent of the reference's examples/gate_nand.py (BASELINE config 1/2 shape): only the import
-line differs."""
+"""Equivalent of the reference's examples/gate_nand.py (BASELINE config 1/2 shape): byte for byte after the
+import block (`import nufhe` resolves to the alias package of this repository)."""
+import os
 import random
-import nufhe_amd as nufhe
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # run from a checkout
+import nufhe   # the alias package served by nufhe_amd (MI355X)
 
 size = 32
 bits1 = [random.choice([False, True]) for i in range(size)]
