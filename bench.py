@@ -90,8 +90,14 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("NUFHE_BENCH_BACKEND", "nccl")   # "gloo": test-only, ranks may share a GPU
+        if backend == "gloo":
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import nufhe_amd
     from nufhe_amd import _lib
@@ -141,7 +147,8 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=thr.device)
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device=thr.device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -160,8 +167,8 @@ def main():
         achieved = a_kernel / (br_avg * 1e-3) / 1e9
         a_gate = (A_MUX if args.gate == "mux" else A_NAND) * B
         result = {
-            "metric": "bootstrapped gates/sec (%s), 4096-bit batch per GPU, %s, n=500 N=1024 k=1 l=2" % (
-                args.gate.upper(), args.transform),
+            "metric": "bootstrapped gates/sec (%s), %d-bit batch per GPU, %s, n=500 N=1024 k=1 l=2" % (
+                args.gate.upper(), B, args.transform),
             "value": gates_per_s,
             "unit": "gates/s",
             "n_gpus": world,

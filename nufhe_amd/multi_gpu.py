@@ -49,8 +49,15 @@ def gather_arrays(local_tensors, nbits: int, group=None):
         if t.shape[0] != cap:      # ragged tail: pad to the common capacity for the collective
             padded = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
             padded[:t.shape[0]] = t
-        full = torch.empty((world * cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(full, padded.contiguous(), group=group)
+        padded = padded.contiguous()
+        if dist.get_backend(group) == 'gloo' and padded.is_cuda:
+            # test-only route (several ranks sharing one GPU over gloo): stage through the host
+            full_h = torch.empty((world * cap,) + tuple(t.shape[1:]), dtype=t.dtype)
+            dist.all_gather_into_tensor(full_h, padded.cpu(), group=group)
+            full = full_h.to(t.device)
+        else:
+            full = torch.empty((world * cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(full, padded, group=group)
         if extra:
             pieces = []
             for r in range(world):

@@ -172,3 +172,45 @@ def test_config2_config3_full_size_properties(env, orc):
     expm = orc.gate_mux(ck, *[tuple(x[:16] for x in H.ct_arrays(c)[:2]) for c in cs])
     ma, mb, mcv = H.ct_arrays(rm)
     assert (ma[:16] == expm[0]).all() and (mb[:16] == expm[1]).all()
+
+
+def test_edge_shapes_empty_scalar_and_odd(env, orc):
+    """Empty batch, 0-dim ciphertexts and batch sizes that are not multiples of the wave/tile
+    granularities (8 bits per work-group, 32 bits per keyswitch tile)."""
+    H = env['H']; thr = env['thr']; vm = env['vm']; ctx = env['ctx']; sk = env['secret_key']; ck = env['ck']
+    # empty
+    e1 = ctx.encrypt(sk, numpy.zeros((0,), bool)); e2 = ctx.encrypt(sk, numpy.zeros((0,), bool))
+    r = vm.gate_nand(e1, e2)
+    assert r.shape == (0,) and ctx.decrypt(sk, r).shape == (0,)
+    r = vm.gate_mux(e1, e2, e1)
+    assert r.shape == (0,)
+    # 0-dim
+    s1 = ctx.encrypt(sk, numpy.array(True)); s2 = ctx.encrypt(sk, numpy.array(False))
+    r = vm.gate_or(s1, s2)
+    assert r.shape == () and bool(ctx.decrypt(sk, r)) is True
+    # odd sizes, ciphertext-level parity with the oracle
+    for B in (1, 9, 33):
+        rng = numpy.random.RandomState(B)
+        m1 = rng.randint(0, 2, size=B).astype(bool); m2 = rng.randint(0, 2, size=B).astype(bool)
+        c1 = ctx.encrypt(sk, m1); c2 = ctx.encrypt(sk, m2)
+        r = vm.gate_xor(c1, c2)
+        exp = orc.gate('gate_xor', ck, H.ct_arrays(c1)[:2], H.ct_arrays(c2)[:2])
+        ra, rb, rcv = H.ct_arrays(r)
+        assert (ra == exp[0]).all() and (rb == exp[1]).all() and (rcv == exp[2]).all()
+        assert (ctx.decrypt(sk, r) == (m1 ^ m2)).all()
+
+
+def test_error_behaviour(env):
+    """Shape / key errors surface as the reference's exception types."""
+    import nufhe_amd
+    from nufhe_amd import lwe as L
+    vm = env['vm']; ctx = env['ctx']; sk = env['secret_key']; thr = env['thr']
+    c1 = ctx.encrypt(sk, numpy.zeros((4,), bool)); c2 = ctx.encrypt(sk, numpy.zeros((3,), bool))
+    with pytest.raises(ValueError):
+        vm.gate_nand(c1, c2)                                    # gates.py:57-58
+    with pytest.raises(ValueError):
+        vm.gate_nand(c1, c1, dest=ctx.encrypt(sk, numpy.zeros((5,), bool)))   # gates.py:74-78
+    with pytest.raises(ValueError):
+        L.LweSampleArray(c1.params, c1.a, c2.b, c1.current_variances)         # lwe.py:113-117
+    with pytest.raises(AttributeError):
+        vm.not_a_gate
