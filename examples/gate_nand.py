@@ -1,26 +1,49 @@
-"""Equivalent of the reference's examples/gate_nand.py (BASELINE config 1/2 shape): byte for byte after the
-import block (`import nufhe` resolves to the alias package of this repository)."""
+"""
+Bootstrapped NAND on a batch of encrypted bits through the nufhe API surface
+(what the reference's `examples/gate_nand.py` demonstrates; BASELINE config 1/2 shape).
+`import nufhe` resolves to the alias package of this repository, served by nufhe_amd on MI355X.
+
+    python examples/gate_nand.py [--bits 4096] [--transform NTT|FFT]
+"""
+import argparse
 import os
-import random
 import sys
+import time
+
+import numpy
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # run from a checkout
-import nufhe   # the alias package served by nufhe_amd (MI355X)
+import nufhe
 
-size = 32
-bits1 = [random.choice([False, True]) for i in range(size)]
-bits2 = [random.choice([False, True]) for i in range(size)]
-reference = [not (b1 and b2) for b1, b2 in zip(bits1, bits2)]
 
-ctx = nufhe.Context()
-secret_key, cloud_key = ctx.make_key_pair()
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--bits", type=int, default=32)
+    parser.add_argument("--transform", default="NTT", choices=["NTT", "FFT"])
+    opts = parser.parse_args()
 
-ciphertext1 = ctx.encrypt(secret_key, bits1)
-ciphertext2 = ctx.encrypt(secret_key, bits2)
+    plain_a = numpy.random.randint(0, 2, size=opts.bits).astype(bool)
+    plain_b = numpy.random.randint(0, 2, size=opts.bits).astype(bool)
 
-vm = ctx.make_virtual_machine(cloud_key)
-result = vm.gate_nand(ciphertext1, ciphertext2)
-result_bits = ctx.decrypt(secret_key, result)
+    context = nufhe.Context()
+    secret, cloud = context.make_key_pair(transform_type=opts.transform)
+    enc_a = context.encrypt(secret, plain_a)
+    enc_b = context.encrypt(secret, plain_b)
 
-assert all(result_bits == reference)
-print("gate_nand OK on", size, "bits")
+    machine = context.make_virtual_machine(cloud)
+    machine.gate_nand(enc_a, enc_b)                      # warm-up (first launch)
+    context.thread.synchronize()
+    started = time.perf_counter()
+    enc_out = machine.gate_nand(enc_a, enc_b)
+    context.thread.synchronize()
+    elapsed = time.perf_counter() - started
+
+    plain_out = context.decrypt(secret, enc_out)
+    if not numpy.array_equal(plain_out, ~(plain_a & plain_b)):
+        raise SystemExit("NAND mismatch")
+    print("gate_nand OK on %d bits (%s): %.3f ms, %.4f ms/bit" % (
+        opts.bits, opts.transform, 1e3 * elapsed, 1e3 * elapsed / opts.bits))
+
+
+if __name__ == "__main__":
+    main()
