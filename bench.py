@@ -82,6 +82,8 @@ def main():
                     help="NTT = BASELINE configs 2-4 (bit-exact path); FFT = config 5 (fp64, tolerance path)")
     ap.add_argument("--cpu-sample-bits", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the secondary measurements (other gate / FFT transform) reported under 'other_configs'")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -152,6 +154,42 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # secondary measurements, OUTSIDE the timed region: the other BASELINE configurations on the same
+    # ciphertexts (3 steps each after 1 warm-up); reported under "other_configs", never in "value"
+    other = {}
+    if not args.no_extra:
+        def measure(fn, nsteps=3):
+            fn()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(nsteps):
+                fn()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            return (time.perf_counter() - t1) / nsteps
+        out2 = vm.empty_ciphertext((B,))
+        other_gate = "nand" if args.gate == "mux" else "mux"
+        if other_gate == "mux":
+            dt = measure(lambda: vm.gate_mux(cs[0], cs[1], cs[2], dest=out2))
+            ok = bool((ctx.decrypt(secret_key, out2) == numpy.where(ms[0], ms[1], ms[2])).all())
+        else:
+            dt = measure(lambda: vm.gate_nand(cs[0], cs[1], dest=out2))
+            ok = bool((ctx.decrypt(secret_key, out2) == ~(ms[0] & ms[1])).all())
+        other["gate_%s_%s" % (other_gate, args.transform)] = {
+            "ms_per_step_per_gpu": 1e3 * dt, "ms_per_bit": 1e3 * dt / B, "gates_per_s_per_gpu": B / dt, "correct": ok}
+        other_tr = "FFT" if args.transform == "NTT" else "NTT"
+        ctx_o = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(123), thread=thr)
+        sk_o, ck_o = ctx_o.make_key_pair(transform_type=other_tr)     # same secret key bits (same seed)
+        vm_o = ctx_o.make_virtual_machine(ck_o)
+        dt = measure(lambda: vm_o.gate_nand(cs[0], cs[1], dest=out2))
+        ok = bool((ctx_o.decrypt(sk_o, out2) == ~(ms[0] & ms[1])).all())
+        other["gate_nand_%s" % other_tr] = {
+            "ms_per_step_per_gpu": 1e3 * dt, "ms_per_bit": 1e3 * dt / B, "gates_per_s_per_gpu": B / dt, "correct": ok}
+        del vm_o, ck_o
+
     # correctness of what was timed: every decrypted bit equals the truth table
     dec = ctx.decrypt(secret_key, out)
     expect = numpy.where(ms[0], ms[1], ms[2]) if args.gate == "mux" else ~(ms[0] & ms[1])
@@ -197,6 +235,8 @@ def main():
                 "gate_streaming_model_GBs": a_gate / (ms_per_step * 1e-3) / 1e9,
             },
         }
+        if other:
+            result["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:
             nthreads = os.cpu_count() or 1
             sample = args.cpu_sample_bits or max(16, min(256, 4 * nthreads))
