@@ -64,22 +64,23 @@ int nufhe_h2d(nufhe_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);   /
 int nufhe_d2h(nufhe_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);   /* synchronous */
 
 /* ---- cloud key (BootstrapKey bootstrap.py:44-92, LweKeyswitchKey lwe.py:254-308) ---- */
-/* transform: NUFHE_TRANSFORM_NTT or NUFHE_TRANSFORM_FFT (NuFHEParameters(transform_type=...),
- * api_low_level.py:44-47): fixes the domain the bootstrapping key is stored in. */
-int nufhe_cloudkey_create(nufhe_ctx *ctx, int lwe_size, int transform, nufhe_cloudkey **key);
+/* transform: NUFHE_TRANSFORM_NTT or NUFHE_TRANSFORM_FFT; mask_size: tlwe_mask_size k, 1 or (NTT only) 2
+ * (NuFHEParameters(transform_type=..., tlwe_mask_size=...), api_low_level.py:44-47).  They fix the
+ * domain and the shape [n][k+1][2][k+1][...] of the bootstrapping key and the keyswitch input size k*1024. */
+int nufhe_cloudkey_create(nufhe_ctx *ctx, int lwe_size, int transform, int mask_size, nufhe_cloudkey **key);
 int nufhe_cloudkey_destroy(nufhe_cloudkey *key);
 /* Bootstrapping key in the REFERENCE's storage format, as produced by TLweTransformSamples
  * (tlwe_gpu.py:199-236) and pickled by BootstrapKey.dump (bootstrap.py:78-80).  Host pointer.
- *   NTT key: uint64 [n][2][2][2][1024], natural-order NTT, Montgomery-prepared (x * 2^64)
+ *   NTT key: uint64 [n][k+1][2][k+1][1024], natural-order NTT, Montgomery-prepared (x * 2^64)
  *   FFT key: complex128 [n][2][2][2][512], natural-order folded FFT (fft_transform_ref) */
 int nufhe_bk_upload_reference(nufhe_cloudkey *key, const void *h_bk);
 /* Inverse of the above (for BootstrapKey.dump): writes the same format to the host. */
 int nufhe_bk_download_reference(nufhe_cloudkey *key, void *h_bk);
-/* Bootstrapping key from coefficient-domain TGSW samples, int32 [n][2][2][2][1024] on the DEVICE
+/* Bootstrapping key from coefficient-domain TGSW samples, int32 [n][k+1][2][k+1][1024] on the DEVICE
  * (replaces tgsw_transform_samples, tgsw.py:135-138). */
 int nufhe_bk_from_coeffs(nufhe_cloudkey *key, const int32_t *d_tgsw);
-/* Keyswitch key, reference layout: a int32 [1024][8][4][n], b int32 [1024][8][4],
- * cv float [1024][8][4] (lwe_gpu.py:139-141).  Host pointers.  The base-0 slice must be zero
+/* Keyswitch key, reference layout: a int32 [k*1024][8][4][n], b int32 [k*1024][8][4],
+ * cv float [k*1024][8][4] (lwe_gpu.py:139-141).  Host pointers.  The base-0 slice must be zero
  * (lwe_cpu.py:30-33); it is checked and NUFHE_EINVAL is returned otherwise. */
 int nufhe_ks_upload(nufhe_cloudkey *key, const int32_t *h_ks_a, const int32_t *h_ks_b,
                     const float *h_ks_cv);
@@ -103,10 +104,10 @@ int nufhe_lwe_linear(nufhe_ctx *ctx, nufhe_lwe res, nufhe_lwe src, int32_t p, in
 int nufhe_lwe_trivial_const(nufhe_ctx *ctx, nufhe_lwe res, int32_t mu, long nbits, int size);
 
 /* bootstrap (bootstrap.py:206-229) = mod-switch + blind rotate + extract [+ keyswitch].
- * x: LWE(n) input.  no_keyswitch != 0: result is LWE(1024) (extracted); else LWE(n). */
+ * x: LWE(n) input.  no_keyswitch != 0: result is LWE(k*1024) (extracted); else LWE(n). */
 int nufhe_bootstrap(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe_lwe x,
                     int32_t mu, long nbits, int no_keyswitch);
-/* lwe_keyswitch (lwe.py:311-322, lwe_gpu.mako:59-120): LWE(1024) -> LWE(n) */
+/* lwe_keyswitch (lwe.py:311-322, lwe_gpu.mako:59-120): LWE(k*1024) -> LWE(n) */
 int nufhe_keyswitch(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe_lwe src,
                     long nbits);
 
@@ -137,9 +138,9 @@ int nufhe_t32_to_phase(nufhe_ctx *ctx, int32_t *d_result, const int32_t *d_phase
 int nufhe_shift_torus_polynomial(nufhe_ctx *ctx, int32_t *d_result, const int32_t *d_source,
                                  const int32_t *d_powers, long powers_stride, long powers_idx,
                                  long batch, int polys, int minus_one, int invert_powers);
-/* tlwe_extract_lwe_samples (tlwe_gpu.mako:54-84), k = 1: tlwe [batch][2][1024] */
+/* tlwe_extract_lwe_samples (tlwe_gpu.mako:54-84): tlwe [batch][k+1][1024] -> a [batch][k*1024], b */
 int nufhe_tlwe_extract(nufhe_ctx *ctx, int32_t *d_result_a, int32_t *d_result_b,
-                       const int32_t *d_tlwe, long batch);
+                       const int32_t *d_tlwe, long batch, int mask_size);
 /* Transform (transform/computation.py:28-99): batched negacyclic NTT-1024, natural order,
  * identical values to ntt_transform_ref (transform/ntt.py:30-44). */
 int nufhe_ntt_forward_i32(nufhe_ctx *ctx, uint64_t *d_out, const int32_t *d_in, long batch);
@@ -153,20 +154,21 @@ int nufhe_fft_inverse_i32(nufhe_ctx *ctx, int32_t *d_out, const double *d_in, lo
 /* Negacyclic product mod 2^32 of int32 polynomials through the NTT: out[b] = x[b] * y[b % y_batch] */
 int nufhe_poly_mul_i32(nufhe_ctx *ctx, int32_t *d_out, const int32_t *d_x, const int32_t *d_y,
                        long batch, long y_batch);
-/* TGswTransformedExternalMul (tgsw_gpu.py:110-169): accum int32 [batch][2][1024] in place,
+/* TGswTransformedExternalMul (tgsw_gpu.py:110-169): accum int32 [batch][k+1][1024] in place,
  * against row bk_row of the uploaded bootstrapping key */
 int nufhe_external_mul(nufhe_ctx *ctx, nufhe_cloudkey *key, int32_t *d_accum, int bk_row,
                        long batch);
-/* blind_rotate (bootstrap.py:119-142): accum int32 [batch][2][1024] in place,
+/* blind_rotate (bootstrap.py:119-142): accum int32 [batch][k+1][1024] in place,
  * bara int32 [batch][bara_stride] in [0, 2N), rows [0, n_rows) of the key */
 int nufhe_blind_rotate(nufhe_ctx *ctx, nufhe_cloudkey *key, int32_t *d_accum,
                        const int32_t *d_bara, long bara_stride, int n_rows, long batch);
 
 /* ---- key generation helpers ("next" row f1; device side of TLweEncryptZero) ---- */
-/* TLweEncryptZero (tlwe_gpu.py:111-196), k = 1: result_a [batch][2][1024] =
- * (noises1, noises2 + noises1 * key);  key int32 [1024], noises1/noises2 [batch][1024] */
+/* TLweEncryptZero (tlwe_gpu.py:111-196): result_a [batch][k+1][1024] =
+ * (noises1, noises2 + sum_i noises1[:, i] * key[i]);  key int32 [k][1024], noises1 [batch][k][1024],
+ * noises2 [batch][1024] */
 int nufhe_tlwe_encrypt_zero(nufhe_ctx *ctx, int32_t *d_result_a, const int32_t *d_key,
-                            const int32_t *d_noises1, const int32_t *d_noises2, long batch);
+                            const int32_t *d_noises1, const int32_t *d_noises2, long batch, int mask_size);
 
 /* ---- measurement: time of the last fused gate / bootstrap kernels, from HIP events on the
  * context's stream (milliseconds; blind-rotate kernel and keyswitch kernels separately) ---- */

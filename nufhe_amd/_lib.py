@@ -45,7 +45,7 @@ PROTOTYPES = {
     "nufhe_free": [_vp, _vp],
     "nufhe_h2d": [_vp, _vp, _vp, ctypes.c_size_t],
     "nufhe_d2h": [_vp, _vp, _vp, ctypes.c_size_t],
-    "nufhe_cloudkey_create": [_vp, _int, _int, _pp],
+    "nufhe_cloudkey_create": [_vp, _int, _int, _int, _pp],
     "nufhe_cloudkey_destroy": [_vp],
     "nufhe_bk_upload_reference": [_vp, _vp],
     "nufhe_bk_download_reference": [_vp, _vp],
@@ -60,7 +60,7 @@ PROTOTYPES = {
     "nufhe_lwe_phase": [_vp, _vp, _long, _vp, _long, _vp, _long, _vp, _i32, _long, _int],
     "nufhe_t32_to_phase": [_vp, _vp, _vp, _long, ctypes.c_uint32],
     "nufhe_shift_torus_polynomial": [_vp, _vp, _vp, _vp, _long, _long, _long, _int, _int, _int],
-    "nufhe_tlwe_extract": [_vp, _vp, _vp, _vp, _long],
+    "nufhe_tlwe_extract": [_vp, _vp, _vp, _vp, _long, _int],
     "nufhe_ntt_forward_i32": [_vp, _vp, _vp, _long],
     "nufhe_ntt_forward_u64": [_vp, _vp, _vp, _long],
     "nufhe_ntt_inverse_i32": [_vp, _vp, _vp, _long],
@@ -70,7 +70,7 @@ PROTOTYPES = {
     "nufhe_fft_inverse_i32": [_vp, _vp, _vp, _long],
     "nufhe_external_mul": [_vp, _vp, _vp, _int, _long],
     "nufhe_blind_rotate": [_vp, _vp, _vp, _vp, _long, _int, _long],
-    "nufhe_tlwe_encrypt_zero": [_vp, _vp, _vp, _vp, _vp, _long],
+    "nufhe_tlwe_encrypt_zero": [_vp, _vp, _vp, _vp, _vp, _long, _int],
     "nufhe_profile_enable": [_vp, _int],
     "nufhe_profile_last": [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)],
 }

@@ -28,8 +28,9 @@ class NuFHEParameters:
     def __init__(self, transform_type='NTT', tlwe_mask_size=1):
         assert transform_type in ('FFT', 'NTT')
         assert tlwe_mask_size >= 1
-        if tlwe_mask_size != 1:
-            raise NotImplementedError("only tlwe_mask_size=1 is implemented on gfx950 so far")
+        if tlwe_mask_size > 2 or (tlwe_mask_size == 2 and transform_type != 'NTT'):
+            raise NotImplementedError(
+                "gfx950 kernels exist for tlwe_mask_size=1 (NTT, FFT) and tlwe_mask_size=2 (NTT)")
 
         tlwe_polynomial_degree = 1024
         lwe_size = 500
@@ -130,7 +131,7 @@ class NuFHECloudKey:
     def from_rng(cls, thr, params: NuFHEParameters, rng, secret_key: NuFHESecretKey, perf_params=None):
         """Generates a cloud key in the reference's RNG order (api_low_level.py:174-196):
         TGSW key, bootstrapping key, keyswitch key."""
-        native = NativeCloudKey(thr, params.in_out_params.size, params._transform_type)
+        native = NativeCloudKey(thr, params.in_out_params.size, params._transform_type, params._tlwe_mask_size)
         tgsw_key = TGswKey.from_rng(thr, params.tgsw_params, rng)
         bk = BootstrapKey.from_rng(thr, rng, secret_key.lwe_key, tgsw_key, native, perf_params)
         ks = LweKeyswitchKey.from_tgsw_key(
@@ -151,7 +152,7 @@ class NuFHECloudKey:
     @classmethod
     def load(cls, file_obj, thr):
         params = pickle.load(file_obj)
-        native = NativeCloudKey(thr, params.in_out_params.size, params._transform_type)
+        native = NativeCloudKey(thr, params.in_out_params.size, params._transform_type, params._tlwe_mask_size)
         bootstrap_key = BootstrapKey.load(file_obj, thr, native)
         keyswitch_key = LweKeyswitchKey.load(file_obj, thr)
         cls._attach_keyswitch(native, keyswitch_key)

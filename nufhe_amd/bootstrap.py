@@ -25,12 +25,13 @@ class NativeCloudKey:
 
     TRANSFORMS = {'NTT': 0, 'FFT': 1}
 
-    def __init__(self, thr, lwe_size, transform_type='NTT'):
+    def __init__(self, thr, lwe_size, transform_type='NTT', mask_size=1):
         self.thr = thr
         self.transform_type = transform_type
+        self.mask_size = mask_size
         handle = ctypes.c_void_p()
         _lib.call("nufhe_cloudkey_create", thr.handle, int(lwe_size), self.TRANSFORMS[transform_type],
-                  ctypes.byref(handle))
+                  int(mask_size), ctypes.byref(handle))
         self.handle = handle
 
     def __del__(self):
@@ -91,7 +92,8 @@ class BootstrapKey:
         in_out_params, bk_params, coeffs, _ = serialization.read_bootstrap_key(file_obj)
         fft = bk_params.tlwe_params.transform_type == 'FFT'
         arr = numpy.ascontiguousarray(coeffs, numpy.complex128 if fft else numpy.uint64)
-        expected = (in_out_params.size, 2, bk_params.decomp_length, 2,
+        k1 = bk_params.tlwe_params.mask_size + 1
+        expected = (in_out_params.size, k1, bk_params.decomp_length, k1,
                     bk_params.tlwe_params.polynomial_degree // (2 if fft else 1))
         if tuple(arr.shape) != expected:
             raise ValueError("bootstrap key array has shape %s, expected %s" % (arr.shape, expected))

@@ -61,10 +61,13 @@ struct nufhe_cloudkey {
     nufhe_ctx *ctx = nullptr;
     int n = 0;
     int transform = 0;        // 0 = NTT (u64 residues), 1 = FFT (complex128)
+    int mask_size = 1;        // tlwe_mask_size k: TGSW rows have (k+1) * 2 * (k+1) polynomials
+    long bk_polys() const { return (long)n * (mask_size + 1) * 2 * (mask_size + 1); }
+    int ext_size() const { return mask_size * 1024; }
     void *d_bk = nullptr;     // wave layout: u64 [n][8][1024] or complex128 [n][8][512] (same bytes)
-    i32 *d_ks_a3 = nullptr;   // [1024][8][3][n]
-    i32 *d_ks_b = nullptr;    // [1024][8][4]
-    float *d_ks_cv = nullptr; // [1024][8][4]
+    i32 *d_ks_a3 = nullptr;   // [k*1024][8][3][n]
+    i32 *d_ks_b = nullptr;    // [k*1024][8][4]
+    float *d_ks_cv = nullptr; // [k*1024][8][4]
 };
 
 namespace {
@@ -106,12 +109,12 @@ int check_key(nufhe_ctx *ctx, nufhe_cloudkey *key, bool need_bk, bool need_ks)
     return NUFHE_OK;
 }
 
-int pick_j_per_block(long nbits)
+int pick_j_per_block(long nbits, int input_size)
 {
     const long tiles = (nbits + KS_TILE_BITS - 1) / KS_TILE_BITS;
     int jsplit = 1;
     while (jsplit < 64 && tiles * jsplit < 1024) jsplit *= 2;
-    return 1024 / jsplit;
+    return input_size / jsplit;
 }
 
 // keyswitch of LWE(1024) src1 (+ src2) (+ constant on b) into `result`
@@ -128,7 +131,8 @@ int run_keyswitch(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result, 
     P.src1_stride = s1as; P.src2_stride = s2as;
     P.nbits = nbits;
     P.n = key->n;
-    P.j_per_block = pick_j_per_block(nbits);
+    P.input_size = key->ext_size();
+    P.j_per_block = pick_j_per_block(nbits, P.input_size);
     KsFinal F;
     F.acc = P.acc;
     F.ks_b = key->d_ks_b; F.ks_cv = key->d_ks_cv;
@@ -138,6 +142,7 @@ int run_keyswitch(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result, 
     F.out_a = result.a; F.out_b = result.b; F.out_cv = result.cv;
     F.out_a_stride = result.a_stride; F.out_b_stride = result.b_stride;
     F.n = key->n;
+    F.input_size = key->ext_size();
     HIP_TRY(launch_keyswitch(P, F, ctx->stream));
     return NUFHE_OK;
 }
@@ -285,19 +290,22 @@ int nufhe_d2h(nufhe_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
 
 // ---- cloud key ---------------------------------------------------------------------------
 
-int nufhe_cloudkey_create(nufhe_ctx *ctx, int lwe_size, int transform, nufhe_cloudkey **key)
+int nufhe_cloudkey_create(nufhe_ctx *ctx, int lwe_size, int transform, int mask_size, nufhe_cloudkey **key)
 {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (!key) return fail(NUFHE_EINVAL, "null argument");
     if (transform != NUFHE_TRANSFORM_NTT && transform != NUFHE_TRANSFORM_FFT)
         return fail(NUFHE_EINVAL, "unknown transform %d", transform);
+    if (mask_size < 1 || mask_size > 2 || (mask_size == 2 && transform != NUFHE_TRANSFORM_NTT))
+        return fail(NUFHE_EINVAL, "unsupported tlwe_mask_size %d for transform %d (1, or 2 with NTT)", mask_size, transform);
     if (lwe_size < 1 || lwe_size > BR_MAX_LWE)
         return fail(NUFHE_EINVAL, "lwe_size %d out of range [1, %d]", lwe_size, BR_MAX_LWE);
     nufhe_cloudkey *k = new nufhe_cloudkey();
     k->ctx = ctx;
     k->n = lwe_size;
     k->transform = transform;
+    k->mask_size = mask_size;
     *key = k;
     return NUFHE_OK;
 }
@@ -317,7 +325,7 @@ int nufhe_cloudkey_destroy(nufhe_cloudkey *key)
 
 static int alloc_bk(nufhe_cloudkey *key)
 {
-    if (!key->d_bk) HIP_TRY(hipMalloc((void **)&key->d_bk, (size_t)key->n * BK_ROW_ELEMS * sizeof(u64)));
+    if (!key->d_bk) HIP_TRY(hipMalloc((void **)&key->d_bk, (size_t)key->bk_polys() * BK_POLY_ELEMS * sizeof(u64)));
     return NUFHE_OK;
 }
 
@@ -329,14 +337,14 @@ int nufhe_bk_upload_reference(nufhe_cloudkey *key, const void *h_bk)
     if (rc) return rc;
     rc = alloc_bk(key);
     if (rc) return rc;
-    const size_t bytes = (size_t)key->n * BK_ROW_ELEMS * sizeof(u64);
+    const size_t bytes = (size_t)key->bk_polys() * BK_POLY_ELEMS * sizeof(u64);
     u64 *tmp = nullptr;
     HIP_TRY(hipMalloc((void **)&tmp, bytes));
     hipError_t e = hipMemcpyAsync(tmp, h_bk, bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess)
         e = key->transform == NUFHE_TRANSFORM_NTT
-                ? launch_bk_from_reference((u64 *)key->d_bk, tmp, (long)key->n * 8, ctx->stream)
-                : launch_bkf_permute((cplx *)key->d_bk, (const cplx *)tmp, (long)key->n * 8, 0, ctx->stream);
+                ? launch_bk_from_reference((u64 *)key->d_bk, tmp, key->bk_polys(), ctx->stream)
+                : launch_bkf_permute((cplx *)key->d_bk, (const cplx *)tmp, key->bk_polys(), 0, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     hipFree(tmp);
     if (e != hipSuccess) return fail(NUFHE_EHIP, "bk upload: %s", hipGetErrorString(e));
@@ -349,12 +357,12 @@ int nufhe_bk_download_reference(nufhe_cloudkey *key, void *h_bk)
     nufhe_ctx *ctx = key->ctx;
     int rc = check_key(ctx, key, true, false);
     if (rc) return rc;
-    const size_t bytes = (size_t)key->n * BK_ROW_ELEMS * sizeof(u64);
+    const size_t bytes = (size_t)key->bk_polys() * BK_POLY_ELEMS * sizeof(u64);
     u64 *tmp = nullptr;
     HIP_TRY(hipMalloc((void **)&tmp, bytes));
     hipError_t e = key->transform == NUFHE_TRANSFORM_NTT
-                       ? launch_bk_to_reference(tmp, (const u64 *)key->d_bk, (long)key->n * 8, ctx->stream)
-                       : launch_bkf_permute((cplx *)tmp, (const cplx *)key->d_bk, (long)key->n * 8, 1, ctx->stream);
+                       ? launch_bk_to_reference(tmp, (const u64 *)key->d_bk, key->bk_polys(), ctx->stream)
+                       : launch_bkf_permute((cplx *)tmp, (const cplx *)key->d_bk, key->bk_polys(), 1, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(h_bk, tmp, bytes, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     hipFree(tmp);
@@ -371,9 +379,9 @@ int nufhe_bk_from_coeffs(nufhe_cloudkey *key, const int32_t *d_tgsw)
     rc = alloc_bk(key);
     if (rc) return rc;
     if (key->transform == NUFHE_TRANSFORM_NTT)
-        HIP_TRY(launch_bk_from_coeffs((u64 *)key->d_bk, d_tgsw, (long)key->n * 8, ctx->d_tw1f, ctx->d_tw1i, ctx->stream));
+        HIP_TRY(launch_bk_from_coeffs((u64 *)key->d_bk, d_tgsw, key->bk_polys(), ctx->d_tw1f, ctx->d_tw1i, ctx->stream));
     else
-        HIP_TRY(launch_bkf_from_coeffs((cplx *)key->d_bk, d_tgsw, (long)key->n * 8, ctx->d_ftw1, ctx->d_ftw2, ctx->stream));
+        HIP_TRY(launch_bkf_from_coeffs((cplx *)key->d_bk, d_tgsw, key->bk_polys(), ctx->d_ftw1, ctx->d_ftw2, ctx->stream));
     return NUFHE_OK;
 }
 
@@ -384,7 +392,7 @@ int nufhe_ks_upload(nufhe_cloudkey *key, const int32_t *h_ks_a, const int32_t *h
     int rc = check_ctx(ctx);
     if (rc) return rc;
     const int n = key->n;
-    const long rows = 1024L * NUFHE_KS_T;
+    const long rows = (long)key->ext_size() * NUFHE_KS_T;
     // base-0 slice must be zero (lwe_cpu.py:30-33): the kernels never read it
     for (long r = 0; r < rows; r++) {
         const int32_t *row0 = h_ks_a + (r * 4) * n;
@@ -445,22 +453,24 @@ static int run_gate(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result
     P.tw_a = fft ? (const void *)ctx->d_ftw1 : (const void *)ctx->d_tw1f;
     P.tw_b = fft ? (const void *)ctx->d_ftw2 : (const void *)ctx->d_tw1i;
     if (keyswitch) {
-        int rc = ensure(ctx, ctx->ext_a, (size_t)total * 1024 * sizeof(i32));
+        const int ext = key->ext_size();
+        int rc = ensure(ctx, ctx->ext_a, (size_t)total * ext * sizeof(i32));
         if (rc) return rc;
         rc = ensure(ctx, ctx->ext_b, (size_t)total * sizeof(i32));
         if (rc) return rc;
-        P.out_a = (i32 *)ctx->ext_a.ptr; P.out_a_stride = 1024;
+        P.out_a = (i32 *)ctx->ext_a.ptr; P.out_a_stride = ext;
         P.out_b = (i32 *)ctx->ext_b.ptr; P.out_b_stride = 1;
     } else {
         P.out_a = result.a; P.out_a_stride = result.a_stride;
         P.out_b = result.b; P.out_b_stride = result.b_stride;
     }
     if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-    HIP_TRY(launch_bootstrap(P, key->transform, ctx->stream));
+    HIP_TRY(launch_bootstrap(P, key->transform, key->mask_size, ctx->stream));
     if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     if (keyswitch) {
         const i32 *ea = (const i32 *)ctx->ext_a.ptr, *eb = (const i32 *)ctx->ext_b.ptr;
-        int rc = run_keyswitch(ctx, key, result, ea, 1024, eb, 1, njobs == 2 ? ea + nbits * 1024 : nullptr, 1024,
+        const int ext = key->ext_size();
+        int rc = run_keyswitch(ctx, key, result, ea, ext, eb, 1, njobs == 2 ? ea + nbits * ext : nullptr, ext,
                                njobs == 2 ? eb + nbits : nullptr, 1, ks_c0, nbits);
         if (rc) return rc;
     }
@@ -559,11 +569,13 @@ int nufhe_shift_torus_polynomial(nufhe_ctx *ctx, int32_t *d_result, const int32_
     return NUFHE_OK;
 }
 
-int nufhe_tlwe_extract(nufhe_ctx *ctx, int32_t *d_result_a, int32_t *d_result_b, const int32_t *d_tlwe, long batch)
+int nufhe_tlwe_extract(nufhe_ctx *ctx, int32_t *d_result_a, int32_t *d_result_b, const int32_t *d_tlwe, long batch,
+                       int mask_size)
 {
     int rc = check_ctx(ctx);
     if (rc) return rc;
-    HIP_TRY(launch_tlwe_extract(d_result_a, d_result_b, d_tlwe, batch, ctx->stream));
+    if (mask_size < 1) return fail(NUFHE_EINVAL, "mask_size must be positive");
+    HIP_TRY(launch_tlwe_extract(d_result_a, d_result_b, d_tlwe, batch, mask_size, ctx->stream));
     return NUFHE_OK;
 }
 
@@ -633,7 +645,7 @@ int nufhe_external_mul(nufhe_ctx *ctx, nufhe_cloudkey *key, int32_t *d_accum, in
     HIP_TRY(launch_blind_rotate_accum(d_accum, key->d_bk, nullptr, 0, bk_row, 1, 1, batch,
                                       fft ? (const void *)ctx->d_ftw1 : (const void *)ctx->d_tw1f,
                                       fft ? (const void *)ctx->d_ftw2 : (const void *)ctx->d_tw1i, key->transform,
-                                      ctx->stream));
+                                      key->mask_size, ctx->stream));
     return NUFHE_OK;
 }
 
@@ -647,21 +659,26 @@ int nufhe_blind_rotate(nufhe_ctx *ctx, nufhe_cloudkey *key, int32_t *d_accum, co
     HIP_TRY(launch_blind_rotate_accum(d_accum, key->d_bk, d_bara, bara_stride, 0, n_rows, 0, batch,
                                       fft ? (const void *)ctx->d_ftw1 : (const void *)ctx->d_tw1f,
                                       fft ? (const void *)ctx->d_ftw2 : (const void *)ctx->d_tw1i, key->transform,
-                                      ctx->stream));
+                                      key->mask_size, ctx->stream));
     return NUFHE_OK;
 }
 
 int nufhe_tlwe_encrypt_zero(nufhe_ctx *ctx, int32_t *d_result_a, const int32_t *d_key, const int32_t *d_noises1,
-                            const int32_t *d_noises2, long batch)
+                            const int32_t *d_noises2, long batch, int mask_size)
 {
     int rc = check_ctx(ctx);
     if (rc) return rc;
-    // mask polynomial: result[:, 0, :] = noises1 (tlwe_cpu.py:81)
-    HIP_TRY(hipMemcpy2DAsync(d_result_a, 2048 * sizeof(i32), d_noises1, 1024 * sizeof(i32), 1024 * sizeof(i32),
-                             (size_t)batch, hipMemcpyDeviceToDevice, ctx->stream));
-    // body: result[:, 1, :] = noises2 + noises1 * key (tlwe_cpu.py:76-84)
-    HIP_TRY(launch_poly_mul(d_result_a + 1024, d_noises1, d_key, d_noises2, 2048, batch, 1, ctx->d_tw1f, ctx->d_tw1i,
-                            ctx->stream));
+    if (mask_size < 1) return fail(NUFHE_EINVAL, "mask_size must be positive");
+    const int k = mask_size, k1 = mask_size + 1;
+    // mask polynomials: result[:, i, :] = noises1[:, i, :] (tlwe_cpu.py:81)
+    HIP_TRY(hipMemcpy2DAsync(d_result_a, (size_t)k1 * 1024 * sizeof(i32), d_noises1, (size_t)k * 1024 * sizeof(i32),
+                             (size_t)k * 1024 * sizeof(i32), (size_t)batch, hipMemcpyDeviceToDevice, ctx->stream));
+    // body: result[:, k, :] = noises2 + sum_i noises1[:, i, :] * key[i] (tlwe_cpu.py:76-84)
+    i32 *body = d_result_a + (size_t)k * 1024;
+    for (int i = 0; i < k; i++)
+        HIP_TRY(launch_poly_mul_strided(body, (long)k1 * 1024, d_noises1 + (size_t)i * 1024, (long)k * 1024,
+                                        d_key + (size_t)i * 1024, i == 0 ? d_noises2 : body,
+                                        i == 0 ? 1024L : (long)k1 * 1024, batch, ctx->d_tw1f, ctx->d_tw1i, ctx->stream));
     return NUFHE_OK;
 }
 

@@ -1,6 +1,6 @@
-// blind_rotate.h -- fused bootstrap body: mod-switch + test-vector init + 500 x (rotate, gadget
-// decomposition, 4 forward NTTs, multiply-accumulate against one bootstrapping-key row, 2 inverse
-// NTTs) + sample extraction, for ONE ciphertext bit executed by ONE wavefront.
+// blind_rotate.h -- fused bootstrap body: mod-switch + test-vector init + n x (rotate, gadget
+// decomposition, (k+1) l forward NTTs, multiply-accumulate against one bootstrapping-key row,
+// (k+1) inverse NTTs) + sample extraction, for ONE ciphertext bit executed by ONE wavefront.
 //
 // Replaces the reference's fused kernel (nufhe/blind_rotate.mako:18-226, launched from
 // nufhe/blind_rotate.py:156-180: one 512+-thread work-group per bit with 3 barriers per transform)
@@ -8,11 +8,15 @@
 //   bara_i = round(a_i * 2N / 2^32), barb likewise          (numeric_functions_cpu.py:23-37)
 //   ACC = (0, X^(2N - barb) * [mu, ..., mu])                (bootstrap.py:176-182)
 //   for i < n: ACC += BK_i (.) ((X^bara_i - 1) * ACC)       (bootstrap.py:96-109, tgsw_cpu.py:82-106)
-//   extract: a'_0 = A_0, a'_j = -A_(N-j), b' = B_0          (tlwe_cpu.py:41-60)
+//   extract: a'_(mN) = A_m,0, a'_(mN+j) = -A_m,(N-j), b' = B_0   (tlwe_cpu.py:41-60)
 //
-// CDNA4 mapping: a wave owns its bit completely -- the accumulator lives in 32 VGPRs per lane
+// Templated on K = tlwe_mask_size (1 = the default parameters; 2 = the reference's second tested
+// setting, test/test_gates.py:96-100, for which the reference's own fused kernel is unavailable,
+// blind_rotate.py:53-58).  l = 2, Bg = 2^10, N = 1024 are fixed.
+//
+// CDNA4 mapping: a wave owns its bit completely -- the accumulator lives in 16 (K+1) VGPRs per lane
 // (coefficient j = lane + 64 r) with an LDS mirror that is only used for the data-dependent
-// rotation; the four digit polynomials are transformed one after the other by the same wave and
+// rotation; the digit polynomials are transformed one after the other by the same wave and
 // multiplied straight out of registers against the key row (stored in the wave layout, read with
 // 16-byte loads, 1 KiB per wave instruction); no s_barrier anywhere in the loop.
 #pragma once
@@ -22,7 +26,9 @@
 #define BR_N 1024
 #define BR_MAX_LWE 512                    /* capacity of the per-wave bara buffer (u16 each) */
 #define BK_POLY_ELEMS 1024
-#define BK_ROW_ELEMS (8 * BK_POLY_ELEMS)  /* one TGSW row: (k+1) l (k+1) = 8 polynomials */
+#define BK_ROW_POLYS(K) (((K) + 1) * 2 * ((K) + 1))           /* (k+1) l (k+1) polynomials per TGSW row */
+#define BK_ROW_ELEMS_K(K) (BK_ROW_POLYS(K) * BK_POLY_ELEMS)
+#define BK_ROW_ELEMS BK_ROW_ELEMS_K(1)
 
 #define TGSW_OFFSET 0x80200000u           /* 2^31 + 2^21: tgsw.py:49-52 with l=2, Bg=2^10 */
 
@@ -48,7 +54,7 @@ struct BrSource {
 
 struct BrLds {
     u64 *xbuf;         // NTT exchange buffer, NTT_XBUF_ELEMS u64
-    i32 *acc;          // [2][1024] accumulator mirror for rotated reads
+    i32 *acc;          // [K+1][1024] accumulator mirror for rotated reads
     uint16_t *bara;    // [BR_MAX_LWE]
     const u64 *tw1f;   // [1024]
     const u64 *tw1i;   // [1024]
@@ -82,72 +88,105 @@ FF_FN i32 br_digit(u32 t)
 }
 
 // External product of one TGSW row with a TLWE sample given coefficient-wise by `tsrc`:
-//   sum[mo] (canonical field elements of the coefficient-domain result, coefficient lane + 64 r)
-//     = sum_{m, d} digit_d(T_m) (*) BK_row[m][d][mo]                      (tgsw_cpu.py:82-106)
+//   sum[mo] (field elements of the coefficient-domain result, coefficient lane + 64 r; for r >= 1
+//   NEGATED, see br_coeff_to_u32) = sum_{m, d} digit_d(T_m) (*) BK_row[m][d][mo]   (tgsw_cpu.py:82-106)
 // tsrc(m, T) must fill T[r] = coefficient lane + 64 r of polynomial m (as uint32 torus values).
-template <class TSource>
-FF_FN void br_external_product(u64 (&sum)[2][16], TSource &&tsrc, const u64 *row, const BrLds &lds,
+// K = 1: everything unrolled (tsrc may index registers with m).  K > 1: the (m, d) loops stay
+// rolled -- one forward transform + (K+1) multiply-accumulates of code -- so tsrc gets a run-time m
+// and must read its polynomial from memory (the LDS mirror), never from a register array.
+template <int K, class TSource>
+FF_FN void br_external_product(u64 (&sum)[K + 1][16], TSource &&tsrc, const u64 *row, const BrLds &lds,
                                const NttLane &L)
 {
     const int lane = L.lane;
 #pragma unroll
-    for (int r = 0; r < 16; r++) { sum[0][r] = 0; sum[1][r] = 0; }
+    for (int mo = 0; mo <= K; mo++)
 #pragma unroll
-    for (int m = 0; m < 2; m++) {
-        u32 T[16];
-        tsrc(m, T);
+        for (int r = 0; r < 16; r++) sum[mo][r] = 0;
+    auto mac = [&](const u64 (&x)[16], const u64 *poly) {
+        // multiply-accumulate against BK[i][m][d][:] (tgsw_cpu.py:63-77)
 #pragma unroll
-        for (int d = 0; d < 2; d++) {
-            u64 x[16];
-            i32 dg[16];
+        for (int mo = 0; mo <= K; mo++) {
+            const u64 *p = poly + mo * BK_POLY_ELEMS + lane * 2;
 #pragma unroll
-            for (int r = 0; r < 16; r++) dg[r] = d == 0 ? br_digit<0>(T[r]) : br_digit<1>(T[r]);
-            ntt_forward_small(x, dg, lds.xbuf, lds.tw1f, L);
-            // multiply-accumulate against BK[i][m][d][mo] (tgsw_cpu.py:63-77)
-            const u64 *poly = row + (m * 2 + d) * 2 * BK_POLY_ELEMS;
-#pragma unroll
-            for (int mo = 0; mo < 2; mo++) {
-                const u64 *p = poly + mo * BK_POLY_ELEMS + lane * 2;
-#pragma unroll
-                for (int h = 0; h < 8; h++) {
-                    const u64 k0 = p[h * 128], k1 = p[h * 128 + 1];
-                    sum[mo][2 * h] = ff_add(sum[mo][2 * h], ff_mul(x[2 * h], k0));
-                    sum[mo][2 * h + 1] = ff_add(sum[mo][2 * h + 1], ff_mul(x[2 * h + 1], k1));
-                }
+            for (int h = 0; h < 8; h++) {
+                const u64 k0 = p[h * 128], k1 = p[h * 128 + 1];
+                sum[mo][2 * h] = ff_add(sum[mo][2 * h], ff_mul(x[2 * h], k0));
+                sum[mo][2 * h + 1] = ff_add(sum[mo][2 * h + 1], ff_mul(x[2 * h + 1], k1));
             }
         }
-    }
-    // NEG_OUT: coefficients j2 >= 1 come back negated (callers use br_coeff_to_u32)
+    };
+    if constexpr (K == 1) {
 #pragma unroll
-    for (int mo = 0; mo < 2; mo++) ntt_inverse_t<true>(sum[mo], lds.xbuf, lds.tw1i, L);
+        for (int m = 0; m <= K; m++) {
+            u32 T[16];
+            tsrc(m, T);
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                u64 x[16];
+                i32 dg[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) dg[r] = d == 0 ? br_digit<0>(T[r]) : br_digit<1>(T[r]);
+                ntt_forward_small(x, dg, lds.xbuf, lds.tw1f, L);
+                mac(x, row + (m * 2 + d) * (K + 1) * BK_POLY_ELEMS);
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int md = 0; md < 2 * (K + 1); md++) {
+            u32 T[16];
+            tsrc(md >> 1, T);
+            u64 x[16];
+            i32 dg[16];
+            const int sh = (md & 1) ? 12 : 22;     // 32 - 10 (d + 1)
+#pragma unroll
+            for (int r = 0; r < 16; r++) dg[r] = (((i32)(T[r] + TGSW_OFFSET) >> sh) & 1023) - 512;
+            ntt_forward_small(x, dg, lds.xbuf, lds.tw1f, L);
+            mac(x, row + (long)md * (K + 1) * BK_POLY_ELEMS);
+        }
+    }
+    // NEG_OUT: coefficients j2 >= 1 come back negated (callers use br_coeff_to_u32).  Explicitly
+    // sequenced (not a `#pragma unroll` loop: for K = 2 the three inverse transforms exceed the
+    // unroller's size threshold and a rolled loop would put `sum` into scratch memory).
+    ntt_inverse_t<true>(sum[0], lds.xbuf, lds.tw1i, L);
+    ntt_inverse_t<true>(sum[1], lds.xbuf, lds.tw1i, L);
+    if constexpr (K >= 2) ntt_inverse_t<true>(sum[2], lds.xbuf, lds.tw1i, L);
+    static_assert(K <= 2, "add the further inverse transforms");
 }
 
 // int32 value of coefficient register r of br_external_product's result
 FF_FN u32 br_coeff_to_u32(u64 v, int r) { return r == 0 ? (u32)ff_to_i32(v) : 0u - (u32)ff_to_i32(v); }
 
-// ACC = (0, X^(2N - barb) * mu) (bootstrap.py:176-182): body coefficient j is +mu if
+// ACC = (0, ..., 0, X^(2N - barb) * mu) (bootstrap.py:176-182): body coefficient j is +mu if
 // (j + barb) mod 2N < N, else -mu.  Fills the registers and the LDS mirror.
-FF_FN void br_init_acc(u32 (&acc)[2][16], u32 barb, i32 mu, const BrLds &lds, int lane)
+template <int K>
+FF_FN void br_init_acc(u32 (&acc)[K + 1][16], u32 barb, i32 mu, const BrLds &lds, int lane)
 {
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const u32 j = (u32)(lane + 64 * r);
         const u32 t = (j + barb) & 2047u;
-        acc[0][r] = 0;
-        acc[1][r] = (t < 1024u) ? (u32)mu : 0u - (u32)mu;
-        lds.acc[j] = 0;
-        lds.acc[1024 + j] = (i32)acc[1][r];
+#pragma unroll
+        for (int m = 0; m < K; m++) {
+            acc[m][r] = 0;
+            lds.acc[m * 1024 + j] = 0;
+        }
+        acc[K][r] = (t < 1024u) ? (u32)mu : 0u - (u32)mu;
+        lds.acc[K * 1024 + j] = (i32)acc[K][r];
     }
     WAVE_SYNC();
 }
 
 // One blind-rotate step with rotation amount a in [0, 2N) (bootstrap.py:96-109):
-// ACC += BK_row (.) ((X^a - 1) ACC).  acc registers and the LDS mirror are both updated.
-FF_FN void br_step(u32 (&acc)[2][16], u32 a, const u64 *row, const BrLds &lds, const NttLane &L)
+// ACC += BK_row (.) ((X^a - 1) ACC).  K = 1: acc registers and the LDS mirror are both updated.
+// K > 1: the accumulator lives in the LDS mirror only during the loop (the registers are needed
+// for the (K+1) x 16 field-element sums); br_blind_rotate reloads acc at the end.
+template <int K>
+FF_FN void br_step(u32 (&acc)[K + 1][16], u32 a, const u64 *row, const BrLds &lds, const NttLane &L)
 {
     const int lane = L.lane;
-    u64 sum[2][16];
-    br_external_product(
+    u64 sum[K + 1][16];
+    br_external_product<K>(
         sum,
         [&](int m, u32 (&T)[16]) {
             // T = (X^a - 1) ACC_m  (polynomials_cpu.py:46-58 with minus_one)
@@ -156,39 +195,56 @@ FF_FN void br_step(u32 (&acc)[2][16], u32 a, const u64 *row, const BrLds &lds, c
                 const u32 j = (u32)(lane + 64 * r);
                 const u32 t = (j - a) & 2047u;
                 const u32 v = (u32)lds.acc[m * 1024 + (t & 1023u)];
-                T[r] = ((t & 1024u) ? 0u - v : v) - acc[m][r];
+                u32 self;
+                if constexpr (K == 1) self = acc[m][r];
+                else self = (u32)lds.acc[m * 1024 + j];
+                T[r] = ((t & 1024u) ? 0u - v : v) - self;
             }
         },
         row, lds, L);
 #pragma unroll
-    for (int mo = 0; mo < 2; mo++)
+    for (int mo = 0; mo <= K; mo++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            acc[mo][r] += br_coeff_to_u32(sum[mo][r], r);
-            lds.acc[mo * 1024 + lane + 64 * r] = (i32)acc[mo][r];
+            if constexpr (K == 1) {
+                acc[mo][r] += br_coeff_to_u32(sum[mo][r], r);
+                lds.acc[mo * 1024 + lane + 64 * r] = (i32)acc[mo][r];
+            } else {
+                lds.acc[mo * 1024 + lane + 64 * r] += (i32)br_coeff_to_u32(sum[mo][r], r);
+            }
         }
     WAVE_SYNC();
 }
 
 // The whole blind rotation for one bit; bara comes from the per-wave LDS buffer.
-FF_FN void br_blind_rotate(u32 (&acc)[2][16], const u64 *bk, int n, u32 barb, i32 mu, const BrLds &lds,
+template <int K>
+FF_FN void br_blind_rotate(u32 (&acc)[K + 1][16], const u64 *bk, int n, u32 barb, i32 mu, const BrLds &lds,
                            const NttLane &L)
 {
-    br_init_acc(acc, barb, mu, lds, L.lane);
+    br_init_acc<K>(acc, barb, mu, lds, L.lane);
     for (int i = 0; i < n; i++) {
         const u32 a = WAVE_UNIFORM((u32)lds.bara[i]);
         if (a == 0) continue;   // (X^0 - 1) ACC = 0: the external product adds nothing
-        br_step(acc, a, bk + (long)i * BK_ROW_ELEMS, lds, L);
+        br_step<K>(acc, a, bk + (long)i * BK_ROW_ELEMS_K(K), lds, L);
+    }
+    if constexpr (K > 1) {
+#pragma unroll
+        for (int m = 0; m <= K; m++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][r] = (u32)lds.acc[m * 1024 + L.lane + 64 * r];
     }
 }
 
-// Sample extraction straight from registers (tlwe_cpu.py:55-58); out_a has 1024 entries
-FF_FN void br_extract(i32 *out_a, i32 *out_b, const u32 (&acc)[2][16], int lane)
+// Sample extraction straight from registers (tlwe_cpu.py:55-58); out_a has K * 1024 entries
+template <int K>
+FF_FN void br_extract(i32 *out_a, i32 *out_b, const u32 (&acc)[K + 1][16], int lane)
 {
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int j = lane + 64 * r;
-        out_a[(1024 - j) & 1023] = (i32)(j == 0 ? acc[0][r] : 0u - acc[0][r]);
-    }
-    if (lane == 0) *out_b = (i32)acc[1][0];
+    for (int m = 0; m < K; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int j = lane + 64 * r;
+            out_a[m * 1024 + ((1024 - j) & 1023)] = (i32)(j == 0 ? acc[m][r] : 0u - acc[m][r]);
+        }
+    if (lane == 0) *out_b = (i32)acc[K][0];
 }

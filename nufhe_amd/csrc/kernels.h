@@ -34,13 +34,14 @@ struct BrLaunch {
 
 struct KsLaunch {
     u32 *acc;             // [nbits][n] zero-initialised accumulator
-    const i32 *ks_a3;     // [1024][8][3][n] (digits 1..3)
+    const i32 *ks_a3;     // [input_size][8][3][n] (digits 1..3)
     const i32 *src1_a;    // LWE(1024) source, plus optional second source added on the fly (MUX)
     const i32 *src2_a;
     long src1_stride, src2_stride;
     long nbits;
     int n;
     int j_per_block;
+    int input_size;       // mask_size * 1024
 };
 
 struct KsFinal {
@@ -54,6 +55,7 @@ struct KsFinal {
     float *out_cv;
     long out_a_stride, out_b_stride;
     int n;
+    int input_size;       // mask_size * 1024
 };
 
 struct LweView {
@@ -65,10 +67,10 @@ struct LweView {
 
 hipError_t kernels_init_device();
 // transform: 0 = NTT, 1 = FFT
-hipError_t launch_bootstrap(const BrLaunch &P, int transform, hipStream_t stream);
+hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, hipStream_t stream);
 hipError_t launch_blind_rotate_accum(i32 *accum, const void *bk, const i32 *bara, long bara_stride, int row0,
                                      int n_rows, int external_mul_only, long batch, const void *tw_a,
-                                     const void *tw_b, int transform, hipStream_t stream);
+                                     const void *tw_b, int transform, int mask_size, hipStream_t stream);
 hipError_t launch_fft_forward(cplx *out, const i32 *in, long batch, const cplx *tw1, const cplx *tw2,
                               hipStream_t stream);
 hipError_t launch_fft_inverse(i32 *out, const cplx *in, long batch, const cplx *tw1, const cplx *tw2,
@@ -82,6 +84,9 @@ hipError_t launch_ntt_inverse(void *out, const u64 *in, int mode, long batch, co
                               hipStream_t stream);
 hipError_t launch_poly_mul(i32 *out, const i32 *x, const i32 *y, const i32 *base, long out_stride, long batch,
                            long y_batch, const u64 *tw1f, const u64 *tw1i, hipStream_t stream);
+hipError_t launch_poly_mul_strided(i32 *out, long out_stride, const i32 *x, long x_stride, const i32 *y,
+                                   const i32 *base, long base_stride, long batch, const u64 *tw1f, const u64 *tw1i,
+                                   hipStream_t stream);
 hipError_t launch_bk_from_reference(u64 *out, const u64 *in, long polys, hipStream_t stream);
 hipError_t launch_bk_to_reference(u64 *out, const u64 *in, long polys, hipStream_t stream);
 hipError_t launch_bk_from_coeffs(u64 *out, const i32 *in, long polys, const u64 *tw1f, const u64 *tw1i,
@@ -95,4 +100,4 @@ hipError_t launch_lwe_phase(i32 *out, long out_stride, const i32 *a, long a_stri
 hipError_t launch_t32_to_phase(i32 *result, const i32 *phase, long count, u32 mspace, hipStream_t stream);
 hipError_t launch_shift_tp(i32 *result, const i32 *source, const i32 *powers, long powers_stride, long powers_idx,
                            long batch, int polys, int minus_one, int invert_powers, hipStream_t stream);
-hipError_t launch_tlwe_extract(i32 *ra, i32 *rb, const i32 *tlwe, long batch, hipStream_t stream);
+hipError_t launch_tlwe_extract(i32 *ra, i32 *rb, const i32 *tlwe, long batch, int mask_size, hipStream_t stream);

@@ -15,9 +15,13 @@
 //   xbuf (8704 B) | acc mirror (8192 B) | bara (1024 B)            = 17920 B
 #define TABLE_LDS_BYTES (2 * 1024 * 8)
 #define WAVE_XBUF_BYTES (NTT_XBUF_ELEMS * 8)
-#define WAVE_ACC_BYTES (2 * 1024 * 4)
+#define WAVE_ACC_BYTES_K(K) (((K) + 1) * 1024 * 4)
+#define WAVE_ACC_BYTES WAVE_ACC_BYTES_K(1)
 #define WAVE_BARA_BYTES (BR_MAX_LWE * 2)
-#define WAVE_BR_LDS_BYTES (WAVE_XBUF_BYTES + WAVE_ACC_BYTES + WAVE_BARA_BYTES)
+#define WAVE_BR_LDS_BYTES_K(K) (WAVE_XBUF_BYTES + WAVE_ACC_BYTES_K(K) + WAVE_BARA_BYTES)
+// waves (= bits) per work-group, one work-group per CU: mask size 1 runs 2 waves/SIMD (<= 256 VGPRs,
+// ~19 KiB of LDS each); mask size 2 has a 12 KiB accumulator mirror per wave, 6 waves fill the LDS
+#define BR_WAVES_K(K) ((K) == 1 ? 8 : 6)
 
 extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
 
@@ -31,13 +35,14 @@ __device__ __forceinline__ void load_tables(const u64 *__restrict__ g_tw1f, cons
     __syncthreads();
 }
 
+template <int K>
 __device__ __forceinline__ BrLds carve_br_lds(int wave)
 {
-    unsigned char *base = g_smem + TABLE_LDS_BYTES + wave * WAVE_BR_LDS_BYTES;
+    unsigned char *base = g_smem + TABLE_LDS_BYTES + wave * WAVE_BR_LDS_BYTES_K(K);
     BrLds lds;
     lds.xbuf = (u64 *)base;
     lds.acc = (i32 *)(base + WAVE_XBUF_BYTES);
-    lds.bara = (uint16_t *)(base + WAVE_XBUF_BYTES + WAVE_ACC_BYTES);
+    lds.bara = (uint16_t *)(base + WAVE_XBUF_BYTES + WAVE_ACC_BYTES_K(K));
     lds.tw1f = (const u64 *)g_smem;
     lds.tw1i = (const u64 *)g_smem + 1024;
     return lds;
@@ -46,41 +51,43 @@ __device__ __forceinline__ BrLds carve_br_lds(int wave)
 // ------------------------------------------------------------------------------------------
 // K1: fused bootstrap (prologue + blind rotate + extract), one wave per bit
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_bootstrap(BrLaunch P)
+template <int K>
+__global__ __launch_bounds__(64 * BR_WAVES_K(K), 2) void k_bootstrap(BrLaunch P)
 {
     load_tables((const u64 *)P.tw_a, (const u64 *)P.tw_b);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long gbit = (long)blockIdx.x * BR_WAVES_PER_BLOCK + wave;
+    const long gbit = (long)blockIdx.x * BR_WAVES_K(K) + wave;
     if (gbit >= P.nbits_total) return;
     const int job = gbit >= P.bits_per_job ? 1 : 0;
     const long bit = gbit - (job ? P.bits_per_job : 0);
 
-    const BrLds lds = carve_br_lds(wave);
+    const BrLds lds = carve_br_lds<K>(wave);
     const NttLane L = ntt_lane_init(lane);
     const u32 barb = br_prologue(P.job[job].s0, P.job[job].s1, P.job[job].c0, bit, P.n, lds, lane);
     WAVE_SYNC();
-    u32 acc[2][16];
-    br_blind_rotate(acc, (const u64 *)P.bk, P.n, barb, P.mu, lds, L);
-    br_extract(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, acc, lane);
+    u32 acc[K + 1][16];
+    br_blind_rotate<K>(acc, (const u64 *)P.bk, P.n, barb, P.mu, lds, L);
+    br_extract<K>(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, acc, lane);
 }
 
 // Test hook / multi-kernel-style entry: blind rotate (or a single external product) on
 // accumulators held in global memory: accum int32 [batch][2][1024]
-__global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_blind_rotate_accum(
+template <int K>
+__global__ __launch_bounds__(64 * BR_WAVES_K(K), K == 1 ? 2 : 1) void k_blind_rotate_accum(
     i32 *__restrict__ accum, const u64 *__restrict__ bk, const i32 *__restrict__ bara, long bara_stride,
     int row0, int n_rows, int external_mul_only, long batch, const u64 *__restrict__ tw1f,
     const u64 *__restrict__ tw1i)
 {
     load_tables(tw1f, tw1i);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long bit = (long)blockIdx.x * BR_WAVES_PER_BLOCK + wave;
+    const long bit = (long)blockIdx.x * BR_WAVES_K(K) + wave;
     if (bit >= batch) return;
-    const BrLds lds = carve_br_lds(wave);
+    const BrLds lds = carve_br_lds<K>(wave);
     const NttLane L = ntt_lane_init(lane);
-    i32 *my = accum + bit * 2048;
-    u32 acc[2][16];
+    i32 *my = accum + bit * (K + 1) * 1024;
+    u32 acc[K + 1][16];
 #pragma unroll
-    for (int m = 0; m < 2; m++)
+    for (int m = 0; m <= K; m++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             acc[m][r] = (u32)my[m * 1024 + lane + 64 * r];
@@ -88,27 +95,36 @@ __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_blind_rotate_accum(
         }
     WAVE_SYNC();
     if (external_mul_only) {
-        u64 sum[2][16];
-        br_external_product(
+        u64 sum[K + 1][16];
+        br_external_product<K>(
             sum,
             [&](int m, u32(&T)[16]) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) T[r] = acc[m][r];
+                for (int r = 0; r < 16; r++) {
+                    if constexpr (K == 1) T[r] = acc[m][r];
+                    else T[r] = (u32)lds.acc[m * 1024 + lane + 64 * r];   // run-time m: see blind_rotate.h
+                }
             },
-            bk + (long)row0 * BK_ROW_ELEMS, lds, L);
+            bk + (long)row0 * BK_ROW_ELEMS_K(K), lds, L);
 #pragma unroll
-        for (int m = 0; m < 2; m++)
+        for (int m = 0; m <= K; m++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[m][r] = br_coeff_to_u32(sum[m][r], r);
     } else {
         for (int i = 0; i < n_rows; i++) {
             const u32 a = WAVE_UNIFORM((u32)bara[bit * bara_stride + i]) & 2047u;
             if (a == 0) continue;
-            br_step(acc, a, bk + (long)(row0 + i) * BK_ROW_ELEMS, lds, L);
+            br_step<K>(acc, a, bk + (long)(row0 + i) * BK_ROW_ELEMS_K(K), lds, L);
+        }
+        if constexpr (K > 1) {   // the accumulator lived in the LDS mirror during the steps
+#pragma unroll
+            for (int m = 0; m <= K; m++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[m][r] = (u32)lds.acc[m * 1024 + lane + 64 * r];
         }
     }
 #pragma unroll
-    for (int m = 0; m < 2; m++)
+    for (int m = 0; m <= K; m++)
 #pragma unroll
         for (int r = 0; r < 16; r++) my[m * 1024 + lane + 64 * r] = (i32)acc[m][r];
 }
@@ -155,7 +171,7 @@ __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_bootstrap_fft(BrLaunch 
     WAVE_SYNC();
     u32 acc[2][16];
     brf_blind_rotate(acc, (const cplx *)P.bk, P.n, barb, P.mu, lds, L);
-    br_extract(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, acc, lane);
+    br_extract<1>(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, acc, lane);
 }
 
 __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_blind_rotate_accum_fft(
@@ -316,12 +332,13 @@ __global__ __launch_bounds__(NTT_BLOCK_THREADS) void k_ntt_inverse(void *__restr
     }
 }
 
-// Negacyclic product of int32 polynomials mod 2^32: out[b] = x[b] * y[b % y_batch]
-// ADD_TO: out = base + product (used by TLweEncryptZero: b = noise + a * s, tlwe_cpu.py:76-84)
-__global__ __launch_bounds__(NTT_BLOCK_THREADS) void k_poly_mul(i32 *__restrict__ out, const i32 *__restrict__ x,
-                                                                const i32 *__restrict__ y, const i32 *__restrict__ base,
-                                                                long out_stride, long batch, long y_batch,
-                                                                const u64 *__restrict__ tw1f,
+// Negacyclic product of int32 polynomials mod 2^32: out[b] = [base[b] +] x[b] * y[b % y_batch]
+// (strides in elements; base may alias out: TLweEncryptZero accumulates b = noise + sum_i a_i * s_i,
+// tlwe_cpu.py:76-84)
+__global__ __launch_bounds__(NTT_BLOCK_THREADS) void k_poly_mul(i32 *out, long out_stride, const i32 *__restrict__ x,
+                                                                long x_stride, const i32 *__restrict__ y,
+                                                                const i32 *base, long base_stride, long batch,
+                                                                long y_batch, const u64 *__restrict__ tw1f,
                                                                 const u64 *__restrict__ tw1i)
 {
     load_tables(tw1f, tw1i);
@@ -333,7 +350,7 @@ __global__ __launch_bounds__(NTT_BLOCK_THREADS) void k_poly_mul(i32 *__restrict_
     u64 fx[16], fy[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        fx[r] = ff_from_i32(x[p * 1024 + ntt_coef_index(lane, r)]);
+        fx[r] = ff_from_i32(x[p * x_stride + ntt_coef_index(lane, r)]);
         fy[r] = ff_from_i32(y[(p % y_batch) * 1024 + ntt_coef_index(lane, r)]);
     }
     ntt_forward(fx, xbuf, (const u64 *)g_smem, L);
@@ -345,7 +362,7 @@ __global__ __launch_bounds__(NTT_BLOCK_THREADS) void k_poly_mul(i32 *__restrict_
     for (int r = 0; r < 16; r++) {
         const int j = ntt_coef_index(lane, r);
         u32 v = (u32)ff_to_i32(fx[r]);
-        if (base) v += (u32)base[p * 1024 + j];
+        if (base) v += (u32)base[p * base_stride + j];
         out[p * out_stride + j] = (i32)v;
     }
 }
@@ -429,7 +446,7 @@ __global__ __launch_bounds__(KS_BLOCK_THREADS) void k_keyswitch_a(KsLaunch P)
             pb[h] = v1 ? (u32)rows[h * P.n + c1] : 0u;
         }
     }
-    const int steps = P.j_per_block * 8;
+    const int steps = P.j_per_block * 8;   // P.j_per_block divides the input size (mask_size * 1024)
     u32 aj[KS_TILE_BITS];
     for (int s = 0; s < steps; s++) {
         const int j = j0 + (s >> 3), k = s & 7;
@@ -481,8 +498,8 @@ __global__ __launch_bounds__(KS_BLOCK_THREADS) void k_keyswitch_a(KsLaunch P)
 
 // finalize: copy the accumulated mask into the result view, and compute b and the variance.
 // The float32 variance must be summed in the reference's sequential (j, k) order to be
-// bit-identical (lwe_cpu.py:80-92): the block gathers the 8192 selected terms into LDS in
-// parallel, then one lane adds them in order.
+// bit-identical (lwe_cpu.py:80-92): the block gathers the selected terms into LDS in parallel
+// (1024 input coefficients = 8192 terms at a time), then one lane adds them in order.
 __global__ __launch_bounds__(256) void k_keyswitch_finalize(KsFinal P)
 {
     __shared__ float cv_terms[8192];
@@ -493,17 +510,25 @@ __global__ __launch_bounds__(256) void k_keyswitch_finalize(KsFinal P)
     for (int c = threadIdx.x; c < P.n; c += blockDim.x)
         P.out_a[bit * P.out_a_stride + c] = (i32)P.acc[bit * P.n + c];
     u32 bpart = 0;
-    for (int j = threadIdx.x; j < 1024; j += blockDim.x) {
-        u32 a = (u32)P.src1_a[bit * P.src1_stride + j];
-        if (P.src2_a) a += (u32)P.src2_a[bit * P.src2_stride + j];
-        a += 1u << 15;
+    float cv = 0.0f;
+    for (int j0 = 0; j0 < P.input_size; j0 += 1024) {
+        for (int jj = threadIdx.x; jj < 1024; jj += blockDim.x) {
+            const int j = j0 + jj;
+            u32 a = (u32)P.src1_a[bit * P.src1_stride + j];
+            if (P.src2_a) a += (u32)P.src2_a[bit * P.src2_stride + j];
+            a += 1u << 15;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const u32 dg = (a >> (30 - 2 * k)) & 3u;
-            const int idx = (j * 8 + k) * 4 + (int)dg;
-            bpart += (u32)P.ks_b[idx];
-            cv_terms[j * 8 + k] = P.ks_cv[idx];
+            for (int k = 0; k < 8; k++) {
+                const u32 dg = (a >> (30 - 2 * k)) & 3u;
+                const long idx = ((long)j * 8 + k) * 4 + (long)dg;
+                bpart += (u32)P.ks_b[idx];
+                cv_terms[jj * 8 + k] = P.ks_cv[idx];
+            }
         }
+        __syncthreads();
+        if (threadIdx.x == 0 && P.out_cv)
+            for (int i = 0; i < 8192; i++) cv += cv_terms[i];
+        __syncthreads();
     }
     atomicAdd(&b_sum, bpart);
     __syncthreads();
@@ -511,11 +536,7 @@ __global__ __launch_bounds__(256) void k_keyswitch_finalize(KsFinal P)
         u32 b = (u32)P.c0 + (u32)P.src1_b[bit * P.src1_bstride];
         if (P.src2_b) b += (u32)P.src2_b[bit * P.src2_bstride];
         P.out_b[bit * P.out_b_stride] = (i32)(b - b_sum);
-        if (P.out_cv) {
-            float cv = 0.0f;
-            for (int i = 0; i < 8192; i++) cv += cv_terms[i];
-            P.out_cv[bit * P.out_b_stride] = cv;
-        }
+        if (P.out_cv) P.out_cv[bit * P.out_b_stride] = cv;
     }
 }
 
@@ -603,16 +624,17 @@ __global__ void k_shift_tp(i32 *__restrict__ result, const i32 *__restrict__ sou
     result[t] = (i32)r;
 }
 
-// tlwe_extract_lwe_samples (k = 1), tlwe_cpu.py:41-60
-__global__ void k_tlwe_extract(i32 *__restrict__ ra, i32 *__restrict__ rb, const i32 *__restrict__ tlwe, long batch)
+// tlwe_extract_lwe_samples, tlwe_cpu.py:41-60: tlwe [batch][k+1][1024] -> a [batch][k*1024], b [batch]
+__global__ void k_tlwe_extract(i32 *__restrict__ ra, i32 *__restrict__ rb, const i32 *__restrict__ tlwe, long batch,
+                               int mask_size)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= batch * 1024) return;
-    const long b = t >> 10;
-    const int j = (int)(t & 1023);
-    const i32 *A = tlwe + b * 2048;
+    if (t >= batch * mask_size * 1024) return;
+    const long b = t / (mask_size * 1024);
+    const int mj = (int)(t - b * mask_size * 1024), m = mj >> 10, j = mj & 1023;
+    const i32 *A = tlwe + (b * (mask_size + 1) + m) * 1024;
     ra[t] = j == 0 ? A[0] : (i32)(0u - (u32)A[1024 - j]);
-    if (j == 0) rb[b] = A[1024];
+    if (mj == 0) rb[b] = tlwe[(b * (mask_size + 1) + mask_size) * 1024];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -620,43 +642,62 @@ __global__ void k_tlwe_extract(i32 *__restrict__ ra, i32 *__restrict__ rb, const
 // ------------------------------------------------------------------------------------------
 static inline unsigned blocks_for(long n, int per) { return (unsigned)((n + per - 1) / per); }
 
-static const size_t kBrLds = TABLE_LDS_BYTES + (size_t)BR_WAVES_PER_BLOCK * WAVE_BR_LDS_BYTES;
+static constexpr size_t br_lds_bytes(int K) { return TABLE_LDS_BYTES + (size_t)BR_WAVES_K(K) * WAVE_BR_LDS_BYTES_K(K); }
 static const size_t kBrfLds = FTABLE_LDS_BYTES + (size_t)BR_WAVES_PER_BLOCK * WAVE_BRF_LDS_BYTES;
 static const size_t kFftLds = FTABLE_LDS_BYTES + (size_t)FFT_WAVES_PER_BLOCK * WAVE_FXBUF_BYTES;
 
-// per-device one-time setup: the fused kernels use ~156 KiB of dynamic LDS (> the 64 KiB default cap)
+// per-device one-time setup: the fused kernels use up to ~156 KiB of dynamic LDS (> the 64 KiB default cap)
 hipError_t kernels_init_device()
 {
-    hipError_t e = hipFuncSetAttribute((const void *)k_bootstrap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrLds);
+    hipError_t e = hipFuncSetAttribute((const void *)k_bootstrap<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(1));
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void *)k_blind_rotate_accum, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrLds);
+    e = hipFuncSetAttribute((const void *)k_bootstrap<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(2));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_blind_rotate_accum<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(1));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_blind_rotate_accum<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(2));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap_fft, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrfLds);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void *)k_blind_rotate_accum_fft, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrfLds);
 }
 
-hipError_t launch_bootstrap(const BrLaunch &P, int transform, hipStream_t stream)
+hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, hipStream_t stream)
 {
     if (P.nbits_total == 0) return hipSuccess;
-    const dim3 grid(blocks_for(P.nbits_total, BR_WAVES_PER_BLOCK)), block(BR_BLOCK_THREADS);
-    if (transform == 0) hipLaunchKernelGGL(k_bootstrap, grid, block, kBrLds, stream, P);
-    else hipLaunchKernelGGL(k_bootstrap_fft, grid, block, kBrfLds, stream, P);
+    if (transform == 0 && mask_size == 1)
+        hipLaunchKernelGGL(k_bootstrap<1>, dim3(blocks_for(P.nbits_total, BR_WAVES_K(1))), dim3(64 * BR_WAVES_K(1)),
+                           br_lds_bytes(1), stream, P);
+    else if (transform == 0 && mask_size == 2)
+        hipLaunchKernelGGL(k_bootstrap<2>, dim3(blocks_for(P.nbits_total, BR_WAVES_K(2))), dim3(64 * BR_WAVES_K(2)),
+                           br_lds_bytes(2), stream, P);
+    else if (transform == 1 && mask_size == 1)
+        hipLaunchKernelGGL(k_bootstrap_fft, dim3(blocks_for(P.nbits_total, BR_WAVES_PER_BLOCK)), dim3(BR_BLOCK_THREADS),
+                           kBrfLds, stream, P);
+    else
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
 hipError_t launch_blind_rotate_accum(i32 *accum, const void *bk, const i32 *bara, long bara_stride, int row0,
                                      int n_rows, int external_mul_only, long batch, const void *tw_a,
-                                     const void *tw_b, int transform, hipStream_t stream)
+                                     const void *tw_b, int transform, int mask_size, hipStream_t stream)
 {
     if (batch == 0) return hipSuccess;
-    const dim3 grid(blocks_for(batch, BR_WAVES_PER_BLOCK)), block(BR_BLOCK_THREADS);
-    if (transform == 0)
-        hipLaunchKernelGGL(k_blind_rotate_accum, grid, block, kBrLds, stream, accum, (const u64 *)bk, bara, bara_stride,
-                           row0, n_rows, external_mul_only, batch, (const u64 *)tw_a, (const u64 *)tw_b);
+    if (transform == 0 && mask_size == 1)
+        hipLaunchKernelGGL(k_blind_rotate_accum<1>, dim3(blocks_for(batch, BR_WAVES_K(1))), dim3(64 * BR_WAVES_K(1)),
+                           br_lds_bytes(1), stream, accum, (const u64 *)bk, bara, bara_stride, row0, n_rows,
+                           external_mul_only, batch, (const u64 *)tw_a, (const u64 *)tw_b);
+    else if (transform == 0 && mask_size == 2)
+        hipLaunchKernelGGL(k_blind_rotate_accum<2>, dim3(blocks_for(batch, BR_WAVES_K(2))), dim3(64 * BR_WAVES_K(2)),
+                           br_lds_bytes(2), stream, accum, (const u64 *)bk, bara, bara_stride, row0, n_rows,
+                           external_mul_only, batch, (const u64 *)tw_a, (const u64 *)tw_b);
+    else if (transform == 1 && mask_size == 1)
+        hipLaunchKernelGGL(k_blind_rotate_accum_fft, dim3(blocks_for(batch, BR_WAVES_PER_BLOCK)), dim3(BR_BLOCK_THREADS),
+                           kBrfLds, stream, accum, (const cplx *)bk, bara, bara_stride, row0, n_rows,
+                           external_mul_only, batch, (const cplx *)tw_a, (const cplx *)tw_b);
     else
-        hipLaunchKernelGGL(k_blind_rotate_accum_fft, grid, block, kBrfLds, stream, accum, (const cplx *)bk, bara,
-                           bara_stride, row0, n_rows, external_mul_only, batch, (const cplx *)tw_a, (const cplx *)tw_b);
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
@@ -715,12 +756,22 @@ hipError_t launch_ntt_inverse(void *out, const u64 *in, int mode, long batch, co
     return hipGetLastError();
 }
 
+hipError_t launch_poly_mul_strided(i32 *out, long out_stride, const i32 *x, long x_stride, const i32 *y,
+                                   const i32 *base, long base_stride, long batch, const u64 *tw1f, const u64 *tw1i,
+                                   hipStream_t stream)
+{
+    if (batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_poly_mul, dim3(blocks_for(batch, NTT_WAVES_PER_BLOCK)), dim3(NTT_BLOCK_THREADS), kNttLds,
+                       stream, out, out_stride, x, x_stride, y, base, base_stride, batch, 1L, tw1f, tw1i);
+    return hipGetLastError();
+}
+
 hipError_t launch_poly_mul(i32 *out, const i32 *x, const i32 *y, const i32 *base, long out_stride, long batch,
                            long y_batch, const u64 *tw1f, const u64 *tw1i, hipStream_t stream)
 {
     if (batch == 0) return hipSuccess;
     hipLaunchKernelGGL(k_poly_mul, dim3(blocks_for(batch, NTT_WAVES_PER_BLOCK)), dim3(NTT_BLOCK_THREADS), kNttLds,
-                       stream, out, x, y, base, out_stride, batch, y_batch, tw1f, tw1i);
+                       stream, out, out_stride, x, 1024L, y, base, 1024L, batch, y_batch, tw1f, tw1i);
     return hipGetLastError();
 }
 
@@ -749,7 +800,7 @@ hipError_t launch_keyswitch(const KsLaunch &P, const KsFinal &F, hipStream_t str
     if (P.nbits == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(P.acc, 0, (size_t)P.nbits * P.n * sizeof(u32), stream);
     if (e != hipSuccess) return e;
-    const dim3 grid(blocks_for(P.nbits, KS_TILE_BITS), 1024 / P.j_per_block);
+    const dim3 grid(blocks_for(P.nbits, KS_TILE_BITS), P.input_size / P.j_per_block);
     hipLaunchKernelGGL(k_keyswitch_a, grid, dim3(KS_BLOCK_THREADS), 0, stream, P);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -800,9 +851,10 @@ hipError_t launch_shift_tp(i32 *result, const i32 *source, const i32 *powers, lo
     return hipGetLastError();
 }
 
-hipError_t launch_tlwe_extract(i32 *ra, i32 *rb, const i32 *tlwe, long batch, hipStream_t stream)
+hipError_t launch_tlwe_extract(i32 *ra, i32 *rb, const i32 *tlwe, long batch, int mask_size, hipStream_t stream)
 {
     if (batch == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_tlwe_extract, dim3(blocks_for(batch * 1024, 256)), dim3(256), 0, stream, ra, rb, tlwe, batch);
+    hipLaunchKernelGGL(k_tlwe_extract, dim3(blocks_for(batch * mask_size * 1024, 256)), dim3(256), 0, stream, ra, rb,
+                       tlwe, batch, mask_size);
     return hipGetLastError();
 }

@@ -74,13 +74,14 @@ def tlwe_encrypt_zero(thr, rng, shape, noise: float, key: TLweKey):
     run on the GPU (forward NTT x forward NTT -> pointwise product -> inverse NTT).
     """
     params = key.params
-    if params.mask_size != 1 or params.polynomial_degree != 1024:
-        raise ValueError("the gfx950 kernels support tlwe_mask_size=1, N=1024")
+    if params.polynomial_degree != 1024:
+        raise ValueError("the gfx950 kernels support N=1024")
+    k = params.mask_size
     shape = tuple(shape)
-    noises1 = rand_uniform_torus32(thr, rng, shape + (1, 1024))
+    noises1 = rand_uniform_torus32(thr, rng, shape + (k, 1024))
     noises2 = rand_gaussian_torus32(thr, rng, 0, noise, shape + (1024,))
     batch = int(numpy.prod(shape))
-    result = thr.array(shape + (2, 1024), Torus32)
+    result = thr.array(shape + (k + 1, 1024), Torus32)
     _lib.call("nufhe_tlwe_encrypt_zero", thr.handle, ptr(result), ptr(key.key.coeffs.contiguous()),
-              ptr(noises1), ptr(noises2), batch)
+              ptr(noises1), ptr(noises2), batch, k)
     return result

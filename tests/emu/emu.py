@@ -67,12 +67,13 @@ def bk_from_reference(bk):
     return out
 
 
-def bootstrap_bit(bk_internal, n, src0, p0, src1, p1, c0, mu):
-    """src = (a [n], b scalar array [1]); returns (ext_a [1024], ext_b)."""
+def bootstrap_bit(bk_internal, n, src0, p0, src1, p1, c0, mu, mask_size=1):
+    """src = (a [n], b scalar array [1]); returns (ext_a [1024 * mask_size], ext_b)."""
     a0 = numpy.ascontiguousarray(src0[0], numpy.int32); b0 = numpy.ascontiguousarray(src0[1], numpy.int32).reshape(1)
     a1 = numpy.ascontiguousarray(src1[0], numpy.int32); b1 = numpy.ascontiguousarray(src1[1], numpy.int32).reshape(1)
-    out_a = numpy.empty(1024, numpy.int32); out_b = numpy.empty(1, numpy.int32)
-    lib().emu_bootstrap_bit(_p(out_a, c_i32p), _p(out_b, c_i32p), _p(bk_internal, c_u64p), ctypes.c_int(n),
+    out_a = numpy.empty(1024 * mask_size, numpy.int32); out_b = numpy.empty(1, numpy.int32)
+    fn = lib().emu_bootstrap_bit if mask_size == 1 else lib().emu_bootstrap_bit_k2
+    fn(_p(out_a, c_i32p), _p(out_b, c_i32p), _p(bk_internal, c_u64p), ctypes.c_int(n),
                             _p(a0, c_i32p), _p(b0, c_i32p), ctypes.c_int32(p0),
                             _p(a1, c_i32p), _p(b1, c_i32p), ctypes.c_int32(p1),
                             ctypes.c_int32(c0), ctypes.c_int32(mu))

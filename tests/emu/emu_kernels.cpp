@@ -80,14 +80,17 @@ void emu_bk_from_reference(u64 *out, const u64 *in, long polys)
                 out[p * 1024 + bk_elem_offset(lane, r)] = ff_mul_pow2<128>(in[p * 1024 + ntt_freq_index(lane, r)]);
 }
 
-// one bit: tmp = (0, c0) + p0 * src0 + p1 * src1 -> bootstrap without keyswitch
-void emu_bootstrap_bit(i32 *out_a, i32 *out_b, const u64 *bk_internal, int n,
-                       const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,
-                       i32 c0, i32 mu)
+}  // extern "C" (templates need C++ linkage)
+
+// one bit: tmp = (0, c0) + p0 * src0 + p1 * src1 -> bootstrap without keyswitch (mask size K)
+template <int K>
+static void bootstrap_bit(i32 *out_a, i32 *out_b, const u64 *bk_internal, int n,
+                          const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,
+                          i32 c0, i32 mu)
 {
     tables();
     std::vector<u64> xbuf(NTT_XBUF_ELEMS);
-    std::vector<i32> accbuf(2048);
+    std::vector<i32> accbuf((K + 1) * 1024);
     std::vector<uint16_t> bara(BR_MAX_LWE);
     BrLds lds{xbuf.data(), accbuf.data(), bara.data(), g_tw1f, g_tw1i};
     BrSource s0{a0, b0, 0, 0, p0}, s1{a1, b1, 0, 0, p1};
@@ -95,12 +98,27 @@ void emu_bootstrap_bit(i32 *out_a, i32 *out_b, const u64 *bk_internal, int n,
         NttLane L = ntt_lane_init(lane);
         u32 barb = br_prologue(s0, s1, c0, 0, n, lds, lane);
         WAVE_SYNC();
-        u32 acc[2][16];
-        br_blind_rotate(acc, bk_internal, n, barb, mu, lds, L);
-        br_extract(out_a, out_b, acc, lane);
+        u32 acc[K + 1][16];
+        br_blind_rotate<K>(acc, bk_internal, n, barb, mu, lds, L);
+        br_extract<K>(out_a, out_b, acc, lane);
     });
 }
 
+extern "C" void emu_bootstrap_bit(i32 *out_a, i32 *out_b, const u64 *bk_internal, int n,
+                                  const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,
+                                  i32 c0, i32 mu)
+{
+    bootstrap_bit<1>(out_a, out_b, bk_internal, n, a0, b0, p0, a1, b1, p1, c0, mu);
+}
+
+extern "C" void emu_bootstrap_bit_k2(i32 *out_a, i32 *out_b, const u64 *bk_internal, int n,
+                                     const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,
+                                     i32 c0, i32 mu)
+{
+    bootstrap_bit<2>(out_a, out_b, bk_internal, n, a0, b0, p0, a1, b1, p1, c0, mu);
+}
+
+extern "C" {
 
 static cplx g_ftw1[FFT_TW1_ELEMS], g_ftw2[FFT_TW2_ELEMS];
 static bool g_ftables = false;
@@ -162,7 +180,7 @@ void emu_bootstrap_bit_fft(i32 *out_a, i32 *out_b, const double *bk_internal, in
         WAVE_SYNC();
         u32 acc[2][16];
         brf_blind_rotate(acc, (const cplx *)bk_internal, n, barb, mu, lds, L);
-        br_extract(out_a, out_b, acc, lane);
+        br_extract<1>(out_a, out_b, acc, lane);
     });
 }
 

@@ -193,3 +193,22 @@ def fft_extmul_inputs():
     tgsw = rs.randint(-2**31, 2**31, size=(3, 2, 2, 2, 1024), dtype=numpy.int32)
     accum = rs.randint(-2**31, 2**31, size=(2, 3, 2, 1024), dtype=numpy.int32)
     return accum, tgsw, 1
+
+
+def extmul_inputs_k2(full_range=False):
+    """extmul_inputs with tlwe_mask_size = 2: BK rows are [3][2][3][1024], accumulators [3][1024]."""
+    rs = _rs(1030 + int(full_range))
+    bk = rs.randint(0, P, size=(3, 3, 2, 3, 1024), dtype=numpy.uint64)
+    if full_range:
+        accum = rs.randint(-2**31, 2**31, size=(2, 2, 3, 1024), dtype=numpy.int32)
+    else:
+        accum = rs.randint(-1000, 1000, size=(2, 2, 3, 1024)).astype(numpy.int32)
+    return accum, bk, 1
+
+
+def encrypt_zero_inputs_k2():
+    rs = _rs(1032)
+    key = rs.randint(0, 2, size=(2, 1024)).astype(numpy.int32)
+    n1 = rs.randint(-2**31, 2**31, size=(2, 3, 2, 1024), dtype=numpy.int32)
+    n2 = rs.randint(-1000, 1000, size=(2, 3, 1024)).astype(numpy.int32)
+    return key, n1, n2

@@ -30,7 +30,7 @@ def host_u64(t):
 def cloud_key_from_arrays(thr, ck, params=None):
     """Builds a device cloud key from the oracle's host arrays (reference formats)."""
     params = params or NuFHEParameters()
-    native = NativeCloudKey(thr, params.in_out_params.size, params._transform_type)
+    native = NativeCloudKey(thr, params.in_out_params.size, params._transform_type, params._tlwe_mask_size)
     bk = numpy.ascontiguousarray(ck.bk, numpy.complex128 if params._transform_type == 'FFT' else numpy.uint64)
     _lib.call("nufhe_bk_upload_reference", native.handle, bk.ctypes.data_as(ctypes.c_void_p))
     bkey = BootstrapKey(params.in_out_params, params.tgsw_params, native)

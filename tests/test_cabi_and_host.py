@@ -104,8 +104,10 @@ def test_parameters_match_reference_defaults():
     assert p.tgsw_params.tlwe_params.extracted_lweparams.size == 1024
     assert p == NuFHEParameters() and hash(p) == hash(NuFHEParameters())
     assert NuFHEParameters(transform_type='FFT') != p
+    p2 = NuFHEParameters(tlwe_mask_size=2)
+    assert p2.tgsw_params.tlwe_params.extracted_lweparams.size == 2048 and p2 != p
     with pytest.raises(NotImplementedError):
-        NuFHEParameters(tlwe_mask_size=2)
+        NuFHEParameters(transform_type='FFT', tlwe_mask_size=2)
 
 
 def test_rng_order_matches_oracle(orc):

@@ -141,3 +141,22 @@ def test_bootstrap_wave_body_fft_full_key(orc, oracle_keys):
     bkf = of.bk_from_coeffs(of.tgsw_coeffs_from_reference_bk(ck.bk))
     ga, gb = emu.bootstrap_bit_fft(emu.bkf_from_reference(bkf), 500, (c1[0][0], c1[1]), -1, (c2[0][0], c2[1]), -1, MU, MU)
     assert (ga == ea[0]).all() and gb == eb[0]
+
+
+def test_bootstrap_wave_body_mask_size_2(orc):
+    """tlwe_mask_size = 2 (test/test_gates.py:96-100 of the reference): the K = 2 instantiation of
+    the fused body == oracle, reduced number of rows, random transformed-domain key."""
+    rs = numpy.random.RandomState(61)
+    n = 5
+    bk = rs.randint(0, P, size=(n, 3, 2, 3, 1024), dtype=numpy.uint64)
+    bki = emu.bk_from_reference(bk)
+    MU = 2**29
+    a0 = rs.randint(-2**31, 2**31, size=n, dtype=numpy.int32)
+    a1 = rs.randint(-2**31, 2**31, size=n, dtype=numpy.int32)
+    b0 = rs.randint(-2**31, 2**31, size=1, dtype=numpy.int32)
+    b1 = rs.randint(-2**31, 2**31, size=1, dtype=numpy.int32)
+    ta = (a0 + a1).astype(numpy.int32); tb = (numpy.int32(-MU) + b0 + b1).astype(numpy.int32)
+    ea, eb = orc.bootstrap_extract(bk, ta[None, :], tb, MU)
+    ga, gb = emu.bootstrap_bit(bki, n, (a0, b0), 1, (a1, b1), 1, -MU, MU, mask_size=2)
+    assert ea.shape == (1, 2048)
+    assert (ga == ea[0]).all() and gb == eb[0]

@@ -100,7 +100,7 @@ def test_extract(thr, H, golden):
     tl = gi.tlwe_extract_inputs()
     ra = thr.array((2, 3, 1024), numpy.int32); rb = thr.array((2, 3), numpy.int32)
     d_tl = H.dev(thr, tl)
-    call("nufhe_tlwe_extract", thr.handle, ptr(ra), ptr(rb), ptr(d_tl), 6)
+    call("nufhe_tlwe_extract", thr.handle, ptr(ra), ptr(rb), ptr(d_tl), 6, 1)
     assert (H.host(ra) == golden['tlwe_extract_a']).all() and (H.host(rb) == golden['tlwe_extract_b']).all()
 
 
@@ -164,7 +164,7 @@ def test_blind_rotate_vs_reference_golden(thr, H, golden):
          bk.shape[0], acc0.shape[0])
     assert (H.host(acc) == golden['blind_rotate_acc']).all()
     ra = thr.array((2, 1024), numpy.int32); rb = thr.array((2,), numpy.int32)
-    call("nufhe_tlwe_extract", thr.handle, ptr(ra), ptr(rb), ptr(acc), 2)
+    call("nufhe_tlwe_extract", thr.handle, ptr(ra), ptr(rb), ptr(acc), 2, 1)
     assert (H.host(ra) == golden['blind_rotate_ext_a']).all() and (H.host(rb) == golden['blind_rotate_ext_b']).all()
 
 

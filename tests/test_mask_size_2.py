@@ -1,0 +1,185 @@
+"""
+tlwe_mask_size = 2 (reference: test/test_gates.py:96-100 runs every gate with
+NuFHEParameters(tlwe_mask_size=2), where the reference falls back to its multi-kernel blind rotate,
+blind_rotate.py:53-58).  CPU part: the oracle vs the reference's k = 2 outputs
+(tests/golden/make_golden_k2.py).  GPU part: the fused gfx950 kernel k_bootstrap<2>, the k = 2
+keyswitch (input size 2048) and key generation through the C ABI / the public API.
+"""
+
+import ctypes
+import os
+
+import numpy
+import pytest
+
+import golden_inputs as gi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope='module')
+def golden_k2():
+    return numpy.load(os.path.join(HERE, 'golden', 'reference_outputs_k2.npz'))
+
+
+@pytest.fixture(scope='module')
+def k2_inputs(orc):
+    params = orc.Params(mask_size=2)
+    lwe_key, tlwe_key, ck = orc.make_key_pair(orc.DeterministicRNG(123), params)
+    rng = orc.DeterministicRNG(456)
+    ms = [numpy.array([True, False]), numpy.array([True, True])]
+    cts = [orc.encrypt(rng, lwe_key, m, params) for m in ms]
+    return params, lwe_key, tlwe_key, ck, cts, ms
+
+
+# ---- CPU: oracle pinned to the reference for k = 2 ----------------------------------------------
+
+def test_oracle_k2_pieces_vs_reference(orc, golden_k2):
+    for full in (False, True):
+        accum, bk, row = gi.extmul_inputs_k2(full_range=full)
+        assert (orc.tgsw_external_mul(accum, bk, row) == golden_k2['tgsw_extmul_k2' + ('_full' if full else '')]).all()
+    key, n1, n2 = gi.encrypt_zero_inputs_k2()
+    ra, rcv = orc.tlwe_encrypt_zero(key, n1, n2, 9e-9)
+    assert (ra == golden_k2['encrypt_zero_k2_a']).all() and (rcv == golden_k2['encrypt_zero_k2_cv']).all()
+
+
+def test_oracle_k2_nand_vs_reference_full_size(orc, golden_k2, k2_inputs):
+    params, lwe_key, tlwe_key, ck, cts, ms = k2_inputs
+    assert ck.bk.shape == (500, 3, 2, 3, 1024) and ck.ks_a.shape == (2048, 8, 4, 500)
+    MU = 2**29
+    ta = (-cts[0][0] - cts[1][0]).astype(numpy.int32)
+    tb = (numpy.int32(MU) - cts[0][1] - cts[1][1]).astype(numpy.int32)
+    ea, eb = orc.bootstrap_extract(ck.bk, ta, tb, MU)
+    assert (ea == golden_k2['nand_k2_ext_a']).all() and (eb == golden_k2['nand_k2_ext_b']).all()
+    ra, rb, rcv = orc.gate('gate_nand', ck, cts[0], cts[1])
+    assert (ra == golden_k2['nand_k2_a']).all() and (rb == golden_k2['nand_k2_b']).all()
+    assert (rcv == golden_k2['nand_k2_cv']).all()
+    assert (orc.decrypt(lwe_key, (ra, rb, rcv)) == ~(ms[0] & ms[1])).all()
+
+
+def test_parameters_k2_host_side():
+    import nufhe_amd
+    p = nufhe_amd.NuFHEParameters(tlwe_mask_size=2)
+    assert p.tgsw_params.tlwe_params.mask_size == 2
+    assert p.tgsw_params.tlwe_params.extracted_lweparams.size == 2048
+    with pytest.raises(NotImplementedError):
+        nufhe_amd.NuFHEParameters(transform_type='FFT', tlwe_mask_size=2)
+    with pytest.raises(NotImplementedError):
+        nufhe_amd.NuFHEParameters(tlwe_mask_size=3)
+
+
+# ---- GPU ------------------------------------------------------------------------------------------
+
+@pytest.fixture(scope='module')
+def thr():
+    from nufhe_amd.device import DeviceThread
+    return DeviceThread(0)
+
+
+@pytest.fixture(scope='module')
+def H():
+    import gpu_helpers
+    return gpu_helpers
+
+
+def _call(name, *args):
+    from nufhe_amd import _lib
+    _lib.call(name, *args)
+
+
+@pytest.mark.gpu
+def test_gpu_k2_external_mul_and_encrypt_zero_vs_reference(thr, H, golden_k2):
+    from nufhe_amd.bootstrap import NativeCloudKey
+    from nufhe_amd.device import ptr
+    for full in (False, True):
+        accum, bk, row = gi.extmul_inputs_k2(full_range=full)
+        native = NativeCloudKey(thr, bk.shape[0], 'NTT', 2)
+        _call("nufhe_bk_upload_reference", native.handle, bk.ctypes.data_as(ctypes.c_void_p))
+        back = numpy.empty_like(bk)
+        _call("nufhe_bk_download_reference", native.handle, back.ctypes.data_as(ctypes.c_void_p))
+        assert (back == bk).all()
+        acc = H.dev(thr, accum)
+        _call("nufhe_external_mul", thr.handle, native.handle, ptr(acc), row, accum.size // (3 * 1024))
+        assert (H.host(acc) == golden_k2['tgsw_extmul_k2' + ('_full' if full else '')]).all()
+    key, n1, n2 = gi.encrypt_zero_inputs_k2()
+    dk, d1, d2 = H.dev(thr, key), H.dev(thr, n1), H.dev(thr, n2)
+    res = thr.array(n2.shape[:-1] + (3, 1024), numpy.int32)
+    _call("nufhe_tlwe_encrypt_zero", thr.handle, ptr(res), ptr(dk), ptr(d1), ptr(d2), 6, 2)
+    assert (H.host(res) == golden_k2['encrypt_zero_k2_a']).all()
+
+
+@pytest.fixture(scope='module')
+def k2_env(thr, H, orc, k2_inputs):
+    import nufhe_amd
+    oparams, lwe_key, tlwe_key, ck, cts, ms = k2_inputs
+    params = nufhe_amd.NuFHEParameters(tlwe_mask_size=2)
+    cloud_key = H.cloud_key_from_arrays(thr, ck, params)
+    secret_key = H.secret_key_from_array(thr, lwe_key, params)
+    ctx = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(789), thread=thr)
+    return dict(ctx=ctx, vm=ctx.make_virtual_machine(cloud_key), sk=secret_key, params=params, ck=ck,
+                lwe_key=lwe_key, oparams=oparams, cloud_key=cloud_key)
+
+
+@pytest.mark.gpu
+def test_gpu_k2_nand_vs_reference_golden(k2_env, thr, H, golden_k2, k2_inputs):
+    """The reference's own k = 2 NAND outputs (extracted LWE(2048) and keyswitched LWE(500))."""
+    from nufhe_amd.bootstrap import bootstrap
+    from nufhe_amd.lwe import LweSampleArray
+    _, lwe_key, _, ck, cts, ms = k2_inputs
+    vm = k2_env['vm']; params = k2_env['params']
+    d = [H.ciphertext_from_arrays(thr, c, params) for c in cts]
+    r = vm.gate_nand(d[0], d[1])
+    ra, rb, rcv = H.ct_arrays(r)
+    assert (ra == golden_k2['nand_k2_a']).all() and (rb == golden_k2['nand_k2_b']).all()
+    assert (rcv == golden_k2['nand_k2_cv']).all()
+    # the bootstrap without the keyswitch: LWE(2048)
+    MU = 2**29
+    ta = (-cts[0][0] - cts[1][0]).astype(numpy.int32)
+    tb = (numpy.int32(MU) - cts[0][1] - cts[1][1]).astype(numpy.int32)
+    src = LweSampleArray(params.in_out_params, H.dev(thr, ta), H.dev(thr, tb), H.dev(thr, numpy.zeros(2, numpy.float32)))
+    ext = LweSampleArray.empty(thr, params.tgsw_params.tlwe_params.extracted_lweparams, (2,))
+    ck_dev = k2_env['cloud_key']
+    bootstrap(thr, ext, ck_dev.bootstrap_key, ck_dev.keyswitch_key, MU, src, no_keyswitch=True)
+    ea, eb, _ = H.ct_arrays(ext)
+    assert ea.shape == (2, 2048)
+    assert (ea == golden_k2['nand_k2_ext_a']).all() and (eb == golden_k2['nand_k2_ext_b']).all()
+
+
+@pytest.mark.gpu
+def test_gpu_k2_gates_vs_oracle_ragged(k2_env, thr, H, orc):
+    """NAND/XOR/MUX on a ragged 37-bit batch: bit-exact vs the oracle run with the same k = 2 keys."""
+    vm = k2_env['vm']; ck = k2_env['ck']; lwe_key = k2_env['lwe_key']; params = k2_env['params']
+    rng = orc.DeterministicRNG(4567)
+    B = 37
+    ms = [rng.uniform_bool((B,)).astype(bool) for _ in range(3)]
+    cs = [orc.encrypt(rng, lwe_key, m, k2_env['oparams']) for m in ms]
+    ds = [H.ciphertext_from_arrays(thr, c, params) for c in cs]
+    for name, got, exp, truth in (
+            ('nand', vm.gate_nand(ds[0], ds[1]), orc.gate('gate_nand', ck, cs[0], cs[1]), ~(ms[0] & ms[1])),
+            ('xor', vm.gate_xor(ds[0], ds[1]), orc.gate('gate_xor', ck, cs[0], cs[1]), ms[0] ^ ms[1]),
+            ('mux', vm.gate_mux(ds[0], ds[1], ds[2]), orc.gate_mux(ck, cs[0], cs[1], cs[2]),
+             numpy.where(ms[0], ms[1], ms[2]))):
+        ra, rb, rcv = H.ct_arrays(got)
+        assert (ra == exp[0]).all() and (rb == exp[1]).all() and (rcv == exp[2]).all(), name
+        assert (k2_env['ctx'].decrypt(k2_env['sk'], got) == truth).all(), name
+
+
+@pytest.mark.gpu
+def test_gpu_k2_context_end_to_end(thr):
+    """Public API with tlwe_mask_size=2 (test/test_gates.py:96-100): GPU key generation, all binary
+    gates + MUX on 64 bits, serialization round trip of the k = 2 cloud key."""
+    import nufhe_amd
+    ctx = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(31), thread=thr)
+    sk, cloud = ctx.make_key_pair(tlwe_mask_size=2)
+    vm = ctx.make_virtual_machine(cloud)
+    rs = numpy.random.RandomState(2)
+    m = [rs.randint(0, 2, size=64).astype(bool) for _ in range(3)]
+    c = [ctx.encrypt(sk, x) for x in m]
+    assert (ctx.decrypt(sk, vm.gate_nand(c[0], c[1])) == ~(m[0] & m[1])).all()
+    assert (ctx.decrypt(sk, vm.gate_or(c[0], c[1])) == (m[0] | m[1])).all()
+    assert (ctx.decrypt(sk, vm.gate_xnor(c[0], c[1])) == ~(m[0] ^ m[1])).all()
+    assert (ctx.decrypt(sk, vm.gate_mux(c[0], c[1], c[2])) == numpy.where(m[0], m[1], m[2])).all()
+    cloud2 = ctx.load_cloud_key(cloud.dumps())
+    assert cloud2 == cloud
+    vm2 = ctx.make_virtual_machine(cloud2)
+    assert (ctx.decrypt(sk, vm2.gate_and(c[0], c[1])) == (m[0] & m[1])).all()
