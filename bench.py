@@ -189,6 +189,31 @@ def main():
         other["gate_nand_%s" % other_tr] = {
             "ms_per_step_per_gpu": 1e3 * dt, "ms_per_bit": 1e3 * dt / B, "gates_per_s_per_gpu": B / dt, "correct": ok}
         del vm_o, ck_o
+        if world == 1:
+            # the reference's own report (test/test_gates.py:62-75,252-314): 1 warm-up + 10 calls, each
+            # bracketed by a synchronize, at sizes B and B/2 -> overall / scaled ms per bit, fixed overhead
+            def ten_calls(nbits):
+                a, b, c = cs[0][:nbits], cs[1][:nbits], cs[2][:nbits]
+                dest = vm.empty_ciphertext((nbits,))
+                fn = ((lambda: vm.gate_mux(a, b, c, dest=dest)) if args.gate == "mux"
+                      else (lambda: vm.gate_nand(a, b, dest=dest)))
+                fn()
+                ts = []
+                for _ in range(10):
+                    thr.synchronize()
+                    t1 = time.perf_counter()
+                    fn()
+                    thr.synchronize()
+                    ts.append(time.perf_counter() - t1)
+                ts = numpy.array(ts)
+                return ts.mean(), ts.std(ddof=1) / numpy.sqrt(ts.size)
+            (m1, e1), (m2, e2) = ten_calls(B), ten_calls(B // 2)
+            other["reference_style_report"] = {
+                "gate": args.gate, "transform": args.transform, "sizes": [B, B // 2], "calls": 10,
+                "mean_ms": [1e3 * m1, 1e3 * m2], "stderr_ms": [1e3 * e1, 1e3 * e2],
+                "overall_ms_per_bit": 1e3 * m1 / B,
+                "scaled_ms_per_bit": 1e3 * (m1 - m2) / (B - B // 2),
+                "fixed_overhead_ms": 1e3 * (m1 - (m1 - m2) / (B - B // 2) * B)}
 
     # correctness of what was timed: every decrypted bit equals the truth table
     dec = ctx.decrypt(secret_key, out)

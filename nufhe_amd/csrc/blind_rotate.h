@@ -34,8 +34,10 @@
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#define BR_ISSUE_FENCE() asm volatile("" ::: "memory")   /* keeps a prefetch load above the arithmetic */
 #else
 #define WAVE_UNIFORM(x) (x)
+#define BR_ISSUE_FENCE() ((void)0)
 #endif
 
 // element offset of (lane, reg) inside one key polynomial in the wave layout:
@@ -104,16 +106,25 @@ FF_FN void br_external_product(u64 (&sum)[K + 1][16], TSource &&tsrc, const u64 
 #pragma unroll
         for (int r = 0; r < 16; r++) sum[mo][r] = 0;
     auto mac = [&](const u64 (&x)[16], const u64 *poly) {
-        // multiply-accumulate against BK[i][m][d][:] (tgsw_cpu.py:63-77)
+        // multiply-accumulate against BK[i][m][d][:] (tgsw_cpu.py:63-77).  The 16-byte key loads are
+        // software-pipelined one step ahead: the load of pair t+1 is in flight while pair t is
+        // multiplied (the key row comes out of L2, ~2 us of latency per wave-iteration otherwise).
+        const u64 *p = poly + lane * 2;
+        u64 k0 = p[0], k1 = p[1];
 #pragma unroll
-        for (int mo = 0; mo <= K; mo++) {
-            const u64 *p = poly + mo * BK_POLY_ELEMS + lane * 2;
-#pragma unroll
-            for (int h = 0; h < 8; h++) {
-                const u64 k0 = p[h * 128], k1 = p[h * 128 + 1];
-                sum[mo][2 * h] = ff_add(sum[mo][2 * h], ff_mul(x[2 * h], k0));
-                sum[mo][2 * h + 1] = ff_add(sum[mo][2 * h + 1], ff_mul(x[2 * h + 1], k1));
+        for (int t = 0; t < 8 * (K + 1); t++) {
+            const int mo = t >> 3, h = t & 7;
+            u64 n0 = 0, n1 = 0;
+            if (t + 1 < 8 * (K + 1)) {
+                const u64 *q = p + ((t + 1) >> 3) * BK_POLY_ELEMS + ((t + 1) & 7) * 128;
+                n0 = q[0];
+                n1 = q[1];
+                BR_ISSUE_FENCE();
             }
+            sum[mo][2 * h] = ff_add(sum[mo][2 * h], ff_mul(x[2 * h], k0));
+            sum[mo][2 * h + 1] = ff_add(sum[mo][2 * h + 1], ff_mul(x[2 * h + 1], k1));
+            k0 = n0;
+            k1 = n1;
         }
     };
     if constexpr (K == 1) {

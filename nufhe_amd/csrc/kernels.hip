@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64 * BR_WAVES_K(K), 2) void k_bootstrap(BrLaunch P)
 {
     load_tables((const u64 *)P.tw_a, (const u64 *)P.tw_b);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long gbit = (long)blockIdx.x * BR_WAVES_K(K) + wave;
+    const long gbit = (long)blockIdx.x * (blockDim.x >> 6) + wave;   // waves per group chosen at launch
     if (gbit >= P.nbits_total) return;
     const int job = gbit >= P.bits_per_job ? 1 : 0;
     const long bit = gbit - (job ? P.bits_per_job : 0);
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_bootstrap_fft(BrLaunch 
 {
     load_ftables((const cplx *)P.tw_a, (const cplx *)P.tw_b);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long gbit = (long)blockIdx.x * BR_WAVES_PER_BLOCK + wave;
+    const long gbit = (long)blockIdx.x * (blockDim.x >> 6) + wave;   // waves per group chosen at launch
     if (gbit >= P.nbits_total) return;
     const int job = gbit >= P.bits_per_job ? 1 : 0;
     const long bit = gbit - (job ? P.bits_per_job : 0);
@@ -642,13 +642,35 @@ __global__ void k_tlwe_extract(i32 *__restrict__ ra, i32 *__restrict__ rb, const
 // ------------------------------------------------------------------------------------------
 static inline unsigned blocks_for(long n, int per) { return (unsigned)((n + per - 1) / per); }
 
-static constexpr size_t br_lds_bytes(int K) { return TABLE_LDS_BYTES + (size_t)BR_WAVES_K(K) * WAVE_BR_LDS_BYTES_K(K); }
-static const size_t kBrfLds = FTABLE_LDS_BYTES + (size_t)BR_WAVES_PER_BLOCK * WAVE_BRF_LDS_BYTES;
+static constexpr size_t br_lds_bytes(int K, int waves) { return TABLE_LDS_BYTES + (size_t)waves * WAVE_BR_LDS_BYTES_K(K); }
+static constexpr size_t br_lds_bytes(int K) { return br_lds_bytes(K, BR_WAVES_K(K)); }
+static constexpr size_t brf_lds_bytes(int waves) { return FTABLE_LDS_BYTES + (size_t)waves * WAVE_BRF_LDS_BYTES; }
+static const size_t kBrfLds = brf_lds_bytes(BR_WAVES_PER_BLOCK);
+
+// Waves (= bits) per work-group for a batch of nbits: one work-group per CU and `max_waves` waves
+// fill a CU, so a batch that does not fill the chip is spread over as many CUs as possible (a wave
+// that has a SIMD to itself runs its 500 iterations ~1.7x sooner than two waves sharing one) and a
+// batch needing r rounds uses the smallest group size that still needs r rounds.
+static int g_num_cus = 256;
+static int br_pick_waves(long nbits, int max_waves)
+{
+    const long per_round = (long)g_num_cus * max_waves;
+    const long rounds = (nbits + per_round - 1) / per_round;
+    const long groups = (long)g_num_cus * rounds;
+    long w = (nbits + groups - 1) / groups;
+    if (w < 1) w = 1;
+    if (w > max_waves) w = max_waves;
+    return (int)w;
+}
 static const size_t kFftLds = FTABLE_LDS_BYTES + (size_t)FFT_WAVES_PER_BLOCK * WAVE_FXBUF_BYTES;
 
 // per-device one-time setup: the fused kernels use up to ~156 KiB of dynamic LDS (> the 64 KiB default cap)
 hipError_t kernels_init_device()
 {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+        g_num_cus = cus;
     hipError_t e = hipFuncSetAttribute((const void *)k_bootstrap<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(1));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(2));
@@ -665,16 +687,16 @@ hipError_t kernels_init_device()
 hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, hipStream_t stream)
 {
     if (P.nbits_total == 0) return hipSuccess;
-    if (transform == 0 && mask_size == 1)
-        hipLaunchKernelGGL(k_bootstrap<1>, dim3(blocks_for(P.nbits_total, BR_WAVES_K(1))), dim3(64 * BR_WAVES_K(1)),
-                           br_lds_bytes(1), stream, P);
-    else if (transform == 0 && mask_size == 2)
-        hipLaunchKernelGGL(k_bootstrap<2>, dim3(blocks_for(P.nbits_total, BR_WAVES_K(2))), dim3(64 * BR_WAVES_K(2)),
-                           br_lds_bytes(2), stream, P);
-    else if (transform == 1 && mask_size == 1)
-        hipLaunchKernelGGL(k_bootstrap_fft, dim3(blocks_for(P.nbits_total, BR_WAVES_PER_BLOCK)), dim3(BR_BLOCK_THREADS),
-                           kBrfLds, stream, P);
-    else
+    if (transform == 0 && mask_size == 1) {
+        const int w = br_pick_waves(P.nbits_total, BR_WAVES_K(1));
+        hipLaunchKernelGGL(k_bootstrap<1>, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), br_lds_bytes(1, w), stream, P);
+    } else if (transform == 0 && mask_size == 2) {
+        const int w = br_pick_waves(P.nbits_total, BR_WAVES_K(2));
+        hipLaunchKernelGGL(k_bootstrap<2>, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), br_lds_bytes(2, w), stream, P);
+    } else if (transform == 1 && mask_size == 1) {
+        const int w = br_pick_waves(P.nbits_total, BR_WAVES_PER_BLOCK);
+        hipLaunchKernelGGL(k_bootstrap_fft, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), brf_lds_bytes(w), stream, P);
+    } else
         return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -126,15 +126,25 @@ class LweSampleArray:
     def shape(self):
         return self.shape_info.shape
 
+    @staticmethod
+    def _mask_index(index):
+        # the mask array has one more (trailing) axis than the message: an Ellipsis in the index
+        # must not swallow it
+        if isinstance(index, tuple) and any(i is Ellipsis for i in index):
+            return index + (slice(None),)
+        if index is Ellipsis:
+            return (Ellipsis, slice(None))
+        return index
+
     def __getitem__(self, index):
         """A view over the ciphertext, indexed like a numpy array of shape ``shape``."""
         return LweSampleArray(
-            self.params, self.a[index], self.b[index], self.current_variances[index])
+            self.params, self.a[self._mask_index(index)], self.b[index], self.current_variances[index])
 
     def __setitem__(self, index, value):
         if not isinstance(value, LweSampleArray):
             raise ValueError("Only assignment of ciphertexts is supported")
-        self.a[index] = value.a
+        self.a[self._mask_index(index)] = value.a
         self.b[index] = value.b
         self.current_variances[index] = value.current_variances
 

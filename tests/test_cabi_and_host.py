@@ -128,3 +128,18 @@ def test_secure_rng_shapes():
     assert r.uniform_torus32((4,)).dtype == numpy.int32
     g = r.gauss((1001,), 2.0)
     assert g.shape == (1001,) and 1.0 < g.std() < 3.0
+
+
+def test_ciphertext_view_indexing_with_ellipsis():
+    """Views are indexed like the plaintext array (lwe.py:163-172): an Ellipsis addresses the
+    message axes only, never the trailing mask axis."""
+    import torch
+    from nufhe_amd.lwe import LweSampleArray, LweParams
+    p = LweParams(500, 0., 1.)
+    a = torch.arange(4 * 16 * 500, dtype=torch.int32).reshape(4, 16, 500)
+    ct = LweSampleArray(p, a, torch.zeros(4, 16, dtype=torch.int32), torch.zeros(4, 16))
+    v = ct[..., 3:4]
+    assert v.shape == (4, 1) and tuple(v.a.shape) == (4, 1, 500) and (v.a == a[:, 3:4, :]).all()
+    assert ct[:, 3:4].shape == (4, 1) and ct[...].shape == (4, 16) and ct[1].shape == (16,)
+    ct[..., 0:1] = ct[..., 5:6]
+    assert (ct.a[:, 0] == a[:, 5]).all()
