@@ -67,16 +67,16 @@ FF_FN u64 ff_reduce128(u64 lo, u32 h0, u32 h1)
     return ff_reduce96(t, h0);
 }
 
+// 64 x 64 -> 128 as one chain of four 32 x 32 + 64 multiply-adds (v_mad_u64_u32); the low word is
+// assembled from the chain's partial sums instead of a second, separate 64-bit multiply
 FF_FN void ff_mul_wide(u64 a, u64 b, u64 &lo, u64 &hi)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
-    lo = a * b;
-    hi = __umul64hi(a, b);
-#else
-    unsigned __int128 p = (unsigned __int128)a * b;
-    lo = (u64)p;
-    hi = (u64)(p >> 64);
-#endif
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 u = (u64)a0 * b0;
+    const u64 v = (u64)a1 * b0 + (u >> 32);
+    const u64 w = (u64)a0 * b1 + (u32)v;
+    hi = (u64)a1 * b1 + (v >> 32) + (w >> 32);
+    lo = (w << 32) | (u32)u;
 }
 
 // canonical * canonical -> canonical
