@@ -170,6 +170,13 @@ int nufhe_blind_rotate(nufhe_ctx *ctx, nufhe_cloudkey *key, int32_t *d_accum,
 int nufhe_tlwe_encrypt_zero(nufhe_ctx *ctx, int32_t *d_result_a, const int32_t *d_key,
                             const int32_t *d_noises1, const int32_t *d_noises2, long batch, int mask_size);
 
+/* Batch-size switch of the NTT k=1 bootstrap: a bootstrap of up to `bits` ciphertext bits runs the
+ * small-batch kernel (4 wavefronts share a bit; ~2.7x shorter latency, one bit per CU at a time),
+ * larger batches the throughput kernel (one wavefront per bit).  bits < 0 restores the default
+ * (2 x the CU count); 0 disables the small-batch kernel.  Results are bit-identical either way.
+ * No reference counterpart (the reference always splits a bit over 512+ threads, blind_rotate.py:89-187). */
+int nufhe_ctx_set_team_max_bits(nufhe_ctx *ctx, long bits);
+
 /* ---- measurement: time of the last fused gate / bootstrap kernels, from HIP events on the
  * context's stream (milliseconds; blind-rotate kernel and keyswitch kernels separately) ---- */
 int nufhe_profile_enable(nufhe_ctx *ctx, int enable);

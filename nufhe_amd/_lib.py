@@ -46,6 +46,7 @@ PROTOTYPES = {
     "nufhe_h2d": [_vp, _vp, _vp, ctypes.c_size_t],
     "nufhe_d2h": [_vp, _vp, _vp, ctypes.c_size_t],
     "nufhe_cloudkey_create": [_vp, _int, _int, _int, _pp],
+    "nufhe_ctx_set_team_max_bits": [_vp, _long],
     "nufhe_cloudkey_destroy": [_vp],
     "nufhe_bk_upload_reference": [_vp, _vp],
     "nufhe_bk_download_reference": [_vp, _vp],

@@ -52,6 +52,7 @@ struct nufhe_ctx {
     cplx *d_ftw1 = nullptr;
     cplx *d_ftw2 = nullptr;
     Scratch ext_a, ext_b, ks_acc;
+    long team_max_bits = -1;   // batches up to this size use the 4-waves-per-bit kernel; -1 = 2 x CUs
     bool profile = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
@@ -465,7 +466,8 @@ static int run_gate(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result
         P.out_b = result.b; P.out_b_stride = result.b_stride;
     }
     if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-    HIP_TRY(launch_bootstrap(P, key->transform, key->mask_size, ctx->stream));
+    HIP_TRY(launch_bootstrap(P, key->transform, key->mask_size,
+                             ctx->team_max_bits >= 0 ? ctx->team_max_bits : 2L * kernels_num_cus(), ctx->stream));
     if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     if (keyswitch) {
         const i32 *ea = (const i32 *)ctx->ext_a.ptr, *eb = (const i32 *)ctx->ext_b.ptr;
@@ -679,6 +681,14 @@ int nufhe_tlwe_encrypt_zero(nufhe_ctx *ctx, int32_t *d_result_a, const int32_t *
         HIP_TRY(launch_poly_mul_strided(body, (long)k1 * 1024, d_noises1 + (size_t)i * 1024, (long)k * 1024,
                                         d_key + (size_t)i * 1024, i == 0 ? d_noises2 : body,
                                         i == 0 ? 1024L : (long)k1 * 1024, batch, ctx->d_tw1f, ctx->d_tw1i, ctx->stream));
+    return NUFHE_OK;
+}
+
+int nufhe_ctx_set_team_max_bits(nufhe_ctx *ctx, long bits)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    ctx->team_max_bits = bits;
     return NUFHE_OK;
 }
 

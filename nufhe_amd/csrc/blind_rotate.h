@@ -89,6 +89,32 @@ FF_FN i32 br_digit(u32 t)
     return ((x >> (32 - 10 * (DIGIT + 1))) & 1023) - 512;
 }
 
+// sum[mo] += x (*) poly[mo], mo = 0..K: multiply-accumulate of one transformed digit polynomial
+// against the K+1 key polynomials BK[i][m][d][:] (tgsw_cpu.py:63-77).  The 16-byte key loads are
+// software-pipelined one step ahead: the load of pair t+1 is in flight while pair t is multiplied
+// (the key row comes out of L2, ~2 us of exposed latency per wave-iteration otherwise).
+template <int K>
+FF_FN void br_mac(u64 (&sum)[K + 1][16], const u64 (&x)[16], const u64 *poly, int lane)
+{
+    const u64 *p = poly + lane * 2;
+    u64 k0 = p[0], k1 = p[1];
+#pragma unroll
+    for (int t = 0; t < 8 * (K + 1); t++) {
+        const int mo = t >> 3, h = t & 7;
+        u64 n0 = 0, n1 = 0;
+        if (t + 1 < 8 * (K + 1)) {
+            const u64 *q = p + ((t + 1) >> 3) * BK_POLY_ELEMS + ((t + 1) & 7) * 128;
+            n0 = q[0];
+            n1 = q[1];
+            BR_ISSUE_FENCE();
+        }
+        sum[mo][2 * h] = ff_add(sum[mo][2 * h], ff_mul(x[2 * h], k0));
+        sum[mo][2 * h + 1] = ff_add(sum[mo][2 * h + 1], ff_mul(x[2 * h + 1], k1));
+        k0 = n0;
+        k1 = n1;
+    }
+}
+
 // External product of one TGSW row with a TLWE sample given coefficient-wise by `tsrc`:
 //   sum[mo] (field elements of the coefficient-domain result, coefficient lane + 64 r; for r >= 1
 //   NEGATED, see br_coeff_to_u32) = sum_{m, d} digit_d(T_m) (*) BK_row[m][d][mo]   (tgsw_cpu.py:82-106)
@@ -105,28 +131,7 @@ FF_FN void br_external_product(u64 (&sum)[K + 1][16], TSource &&tsrc, const u64 
     for (int mo = 0; mo <= K; mo++)
 #pragma unroll
         for (int r = 0; r < 16; r++) sum[mo][r] = 0;
-    auto mac = [&](const u64 (&x)[16], const u64 *poly) {
-        // multiply-accumulate against BK[i][m][d][:] (tgsw_cpu.py:63-77).  The 16-byte key loads are
-        // software-pipelined one step ahead: the load of pair t+1 is in flight while pair t is
-        // multiplied (the key row comes out of L2, ~2 us of latency per wave-iteration otherwise).
-        const u64 *p = poly + lane * 2;
-        u64 k0 = p[0], k1 = p[1];
-#pragma unroll
-        for (int t = 0; t < 8 * (K + 1); t++) {
-            const int mo = t >> 3, h = t & 7;
-            u64 n0 = 0, n1 = 0;
-            if (t + 1 < 8 * (K + 1)) {
-                const u64 *q = p + ((t + 1) >> 3) * BK_POLY_ELEMS + ((t + 1) & 7) * 128;
-                n0 = q[0];
-                n1 = q[1];
-                BR_ISSUE_FENCE();
-            }
-            sum[mo][2 * h] = ff_add(sum[mo][2 * h], ff_mul(x[2 * h], k0));
-            sum[mo][2 * h + 1] = ff_add(sum[mo][2 * h + 1], ff_mul(x[2 * h + 1], k1));
-            k0 = n0;
-            k1 = n1;
-        }
-    };
+    auto mac = [&](const u64 (&x)[16], const u64 *poly) { br_mac<K>(sum, x, poly, lane); };
     if constexpr (K == 1) {
 #pragma unroll
         for (int m = 0; m <= K; m++) {
@@ -258,4 +263,116 @@ FF_FN void br_extract(i32 *out_a, i32 *out_b, const u32 (&acc)[K + 1][16], int l
             out_a[m * 1024 + ((1024 - j) & 1023)] = (i32)(j == 0 ? acc[m][r] : 0u - acc[m][r]);
         }
     if (lane == 0) *out_b = (i32)acc[K][0];
+}
+
+// ------------------------------------------------------------------------------------------
+// Team variant (k = 1): FOUR wavefronts of one work-group share one ciphertext bit.  For batches
+// that cannot fill the chip with one wave per bit (circuits: the slices of an adder / comparator
+// chain are a few hundred bits wide) the latency of a gate is the 500-step dependent chain of ONE
+// wave; splitting the step cuts that chain:
+//   wave w = 2 m + d   decomposes digit d of polynomial m of (X^a - 1) ACC, transforms it and
+//                      multiplies it with BK_i[m][d][0..1]               (1 forward transform, 2 MACs)
+//   all waves          leave their two partial sums in LDS, work-group barrier
+//   wave mo = 0, 1     adds the four partial sums of output polynomial mo, transforms back and
+//                      updates ACC[mo] in the shared LDS mirror          (1 inverse transform)
+//   work-group barrier
+// i.e. 1 forward + 1 inverse transform on the critical path instead of 4 + 2.  The four partial
+// sums are canonical field elements and field addition is exact, so regrouping them does not change
+// a single bit of the result with respect to the one-wave path.
+// ------------------------------------------------------------------------------------------
+#define BRT_WAVES 4
+#define BRT_PART_ELEMS (BRT_WAVES * 2 * 1024)   /* u64: partial sums [wave][mo][reg][lane] */
+
+struct BrTeamLds {
+    u64 *xbuf;         // this wave's NTT exchange buffer
+    i32 *acc;          // [2][1024] accumulator, shared by the team (the only copy during the loop)
+    uint16_t *bara;    // [BR_MAX_LWE], shared
+    u64 *part;         // [BRT_PART_ELEMS], shared
+    const u64 *tw1f;
+    const u64 *tw1i;
+};
+
+// One blind-rotate step by the team; `w` is this wave's index (wave-uniform), team_sync() a barrier
+// over the 4 waves.  All 4 waves must call it with the same a != 0.
+template <class TeamSync>
+FF_FN void brt_step(u32 a, const u64 *row, const BrTeamLds &lds, const NttLane &L, int w, TeamSync &&team_sync)
+{
+    const int lane = L.lane;
+    const int m = w >> 1;
+    const int sh = (w & 1) ? 12 : 22;      // digit d = w & 1: shift 32 - 10 (d + 1)
+    i32 dg[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const u32 j = (u32)(lane + 64 * r);
+        const u32 t = (j - a) & 2047u;
+        const u32 v = (u32)lds.acc[m * 1024 + (t & 1023u)];
+        const u32 T = ((t & 1024u) ? 0u - v : v) - (u32)lds.acc[m * 1024 + j];
+        dg[r] = (((i32)(T + TGSW_OFFSET) >> sh) & 1023) - 512;
+    }
+    u64 x[16];
+    ntt_forward_small(x, dg, lds.xbuf, lds.tw1f, L);
+    u64 ps[2][16];
+#pragma unroll
+    for (int mo = 0; mo < 2; mo++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) ps[mo][r] = 0;
+    br_mac<1>(ps, x, row + (long)w * 2 * BK_POLY_ELEMS, lane);
+#pragma unroll
+    for (int mo = 0; mo < 2; mo++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) lds.part[((w * 2 + mo) * 16 + r) * 64 + lane] = ps[mo][r];
+    team_sync();
+    if (w < 2) {
+        u64 sum[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            u64 acc = lds.part[((0 * 2 + w) * 16 + r) * 64 + lane];
+#pragma unroll
+            for (int src = 1; src < BRT_WAVES; src++)
+                acc = ff_add(acc, lds.part[((src * 2 + w) * 16 + r) * 64 + lane]);
+            sum[r] = acc;
+        }
+        ntt_inverse_t<true>(sum, lds.xbuf, lds.tw1i, L);
+#pragma unroll
+        for (int r = 0; r < 16; r++) lds.acc[w * 1024 + lane + 64 * r] += (i32)br_coeff_to_u32(sum[r], r);
+    }
+    team_sync();
+}
+
+// Whole bootstrap body of the team for one bit: tid = 64 w + lane in [0, 256).  The prologue and
+// the extraction are spread over all 256 threads; out_a has 1024 entries.
+template <class TeamSync>
+FF_FN void brt_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSource &s1, i32 c0, long bit,
+                         const u64 *bk, int n, i32 mu, const BrTeamLds &lds, const NttLane &L, int w,
+                         TeamSync &&team_sync)
+{
+    const int tid = 64 * w + L.lane;
+    for (int i = tid; i < n; i += 64 * BRT_WAVES) {
+        u32 v = 0;
+        if (s0.p) v += (u32)s0.p * (u32)s0.a[bit * s0.a_stride + i];
+        if (s1.p) v += (u32)s1.p * (u32)s1.a[bit * s1.a_stride + i];
+        lds.bara[i] = (uint16_t)br_modswitch(v);
+    }
+    u32 vb = (u32)c0;
+    if (s0.p) vb += (u32)s0.p * (u32)s0.b[bit * s0.b_stride];
+    if (s1.p) vb += (u32)s1.p * (u32)s1.b[bit * s1.b_stride];
+    const u32 barb = br_modswitch(vb);
+    // ACC = (0, X^(2N - barb) * mu)  (bootstrap.py:176-182)
+    for (int j = tid; j < 1024; j += 64 * BRT_WAVES) {
+        const u32 t = ((u32)j + barb) & 2047u;
+        lds.acc[j] = 0;
+        lds.acc[1024 + j] = (t < 1024u) ? mu : (i32)(0u - (u32)mu);
+    }
+    team_sync();
+    for (int i = 0; i < n; i++) {
+        const u32 a = WAVE_UNIFORM((u32)lds.bara[i]);
+        if (a == 0) continue;
+        brt_step(a, bk + (long)i * BK_ROW_ELEMS, lds, L, w, team_sync);
+    }
+    // sample extraction (tlwe_cpu.py:55-58)
+    for (int j = tid; j < 1024; j += 64 * BRT_WAVES) {
+        const u32 v = (u32)lds.acc[j];
+        out_a[(1024 - j) & 1023] = (i32)(j == 0 ? v : 0u - v);
+    }
+    if (tid == 0) *out_b = lds.acc[1024];
 }

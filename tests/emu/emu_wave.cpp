@@ -3,10 +3,14 @@
 
 namespace {
 constexpr int kLanes = 64;
+constexpr int kMaxFibres = 256;
+int g_nfibres = kLanes;
+int g_arrived = 0;
+long g_generation = 0;
 constexpr size_t kStack = 1 << 20;
 ucontext_t g_sched;
-ucontext_t g_fibre[kLanes];
-bool g_done[kLanes];
+ucontext_t g_fibre[kMaxFibres];
+bool g_done[kMaxFibres];
 int g_cur = -1;
 const std::function<void(int)> *g_body = nullptr;
 
@@ -26,9 +30,30 @@ void emu_yield()
     swapcontext(&g_fibre[lane], &g_sched);
 }
 
+void emu_team_sync()
+{
+    const long gen = g_generation;
+    if (++g_arrived == g_nfibres) {
+        g_arrived = 0;
+        g_generation++;
+        return;
+    }
+    while (g_generation == gen) emu_yield();
+}
+
+void emu_run_team(int waves, const std::function<void(int, int)> &body)
+{
+    std::function<void(int)> flat = [&](int f) { body(f / kLanes, f % kLanes); };
+    g_nfibres = waves * kLanes;
+    g_arrived = 0;
+    emu_run_wave(flat);
+    g_nfibres = kLanes;
+}
+
 void emu_run_wave(const std::function<void(int)> &body)
 {
     g_body = &body;
+    const int kLanes = g_nfibres;
     std::vector<char *> stacks(kLanes);
     for (int l = 0; l < kLanes; l++) {
         stacks[l] = (char *)malloc(kStack);

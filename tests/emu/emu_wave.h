@@ -11,3 +11,9 @@ void emu_yield();
 int emu_lane();
 // run body(lane) for lane = 0..63 as one wavefront
 void emu_run_wave(const std::function<void(int)> &body);
+// run body(wave, lane) for `waves` wavefronts of one work-group; emu_team_sync() is the work-group
+// barrier (every fibre of the team must reach it), emu_yield() stays the per-wave barrier: the
+// scheduler is round-robin over all fibres, so the lanes of a wave (which execute the same sequence
+// of sync points) advance in lock step, and a fibre waiting at the team barrier simply keeps yielding.
+void emu_run_team(int waves, const std::function<void(int, int)> &body);
+void emu_team_sync();

@@ -85,6 +85,10 @@ def test_bootstrap_wave_body_reduced(orc):
         ga, gb = emu.bootstrap_bit(bki, n, (a0, b0), -1, (a1, b1), -1, MU, MU)
         assert (ga == ea[0]).all()
         assert gb == eb[0]
+        # the 4-wave team variant of the same body (small-batch path): identical bits
+        ga, gb = emu.bootstrap_bit(bki, n, (a0, b0), -1, (a1, b1), -1, MU, MU, team=True)
+        assert (ga == ea[0]).all()
+        assert gb == eb[0]
 
 
 @pytest.mark.slow

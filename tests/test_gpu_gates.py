@@ -214,3 +214,26 @@ def test_error_behaviour(env):
         L.LweSampleArray(c1.params, c1.a, c2.b, c1.current_variances)         # lwe.py:113-117
     with pytest.raises(AttributeError):
         vm.not_a_gate
+
+
+def test_small_batch_team_kernel_equals_wave_kernel(env, orc):
+    """The 4-waves-per-bit kernel (batches <= 2 x CUs by default) and the wave-per-bit kernel give
+    bit-identical ciphertexts, both equal to the oracle; the switch is exercised on both sides of
+    its boundary (nufhe_ctx_set_team_max_bits)."""
+    from nufhe_amd import _lib
+    H = env['H']; thr = env['thr']; vm = env['vm']; ck = env['ck']; lwe_key = env['lwe_key']
+    rng = orc.DeterministicRNG(2024)
+    B = 70
+    ms = [rng.uniform_bool((B,)).astype(bool) for _ in range(3)]
+    cs = [orc.encrypt(rng, lwe_key, m) for m in ms]
+    ds = [H.ciphertext_from_arrays(thr, c) for c in cs]
+    exp_nand = orc.gate('gate_nand', ck, cs[0], cs[1])
+    exp_mux = orc.gate_mux(ck, cs[0], cs[1], cs[2])
+    try:
+        for limit in (0, 69, 70, 139, 140, -1):      # MUX launches 2 B = 140 bits in one bootstrap
+            _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, limit)
+            for got, exp in ((vm.gate_nand(ds[0], ds[1]), exp_nand), (vm.gate_mux(ds[0], ds[1], ds[2]), exp_mux)):
+                ra, rb, rcv = H.ct_arrays(got)
+                assert (ra == exp[0]).all() and (rb == exp[1]).all() and (rcv == exp[2]).all(), limit
+    finally:
+        _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, -1)
