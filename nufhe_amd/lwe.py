@@ -3,9 +3,9 @@ LWE ciphertext containers and operations (reference: nufhe/lwe.py:53-447).
 
 Same classes, function names and argument meaning as the reference; ``thr`` is a
 :class:`nufhe_amd.device.DeviceThread`.  Arrays are torch tensors in GPU memory; every kernel is a
-C-ABI call into libnufhe_hip.so (LweLinear, LweNoiselessTrivial*, LweKeyswitch), except the
-client-side encrypt/decrypt dot products, which stay on the host in NumPy for now (SURVEY §8f
-row 2: "next", not on the hot path).
+C-ABI call into libnufhe_hip.so (LweLinear, LweNoiselessTrivial*, LweKeyswitch, and the
+encrypt/decrypt dot products via nufhe_lwe_phase); only the random numbers are drawn on the host,
+in the reference's order, so that one seed gives the same ciphertexts as the CPU oracle.
 """
 
 import io
