@@ -27,8 +27,19 @@ typedef int32_t i32;
 // a, b canonical (< P) -> canonical
 FF_FN u64 ff_sub(u64 a, u64 b)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // 32-bit borrow chain: the borrow of the subtraction itself selects the correction
+    unsigned c1, c2, c3, c4;
+    const u32 d0 = __builtin_subc((u32)a, (u32)b, 0u, &c1);
+    const u32 d1 = __builtin_subc((u32)(a >> 32), (u32)(b >> 32), c1, &c2);
+    const u32 m = 0u - c2;                               // borrow: + P == - EPS (mod 2^64)
+    const u32 r0 = __builtin_subc(d0, m, 0u, &c3);
+    const u32 r1 = __builtin_subc(d1, 0u, c3, &c4);
+    return ((u64)r1 << 32) | r0;
+#else
     u64 d = a - b;
     return (a < b) ? d - FF_EPS : d;   // borrow: + P == - EPS (mod 2^64)
+#endif
 }
 
 // a, b canonical -> canonical: on carry-out or s >= P subtract P, i.e. add EPS modulo 2^64
@@ -54,17 +65,33 @@ FF_FN u64 ff_times_eps(u32 w) { return ((u64)w << 32) - w; }
 // a 64-bit add.
 FF_FN u64 ff_reduce96(u64 lo, u32 h0)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // One v_mad_u64_u32 gives s = lo + h0 * eps AND its carry-out (the compiler neither folds the
+    // addend into the multiply-add nor uses its carry); mask = carry | (s >= P), as 0 / 0xFFFFFFFF.
+    // Hazards (gfx940+: VALU-written SGPR read by a VALU needs 2 wait states) do not arise: the
+    // VALU-written masks are only read by the scalar OR.
+    u64 s, carry;
+    u32 m;
+    asm("v_mad_u64_u32 %0, %1, %3, -1, %4\n\t"
+        "v_cmp_le_u64 vcc, %5, %0\n\t"
+        "s_or_b64 vcc, vcc, %1\n\t"
+        "v_cndmask_b32 %2, 0, -1, vcc"
+        : "=&v"(s), "=&s"(carry), "=v"(m)
+        : "v"(h0), "v"(lo), "s"((u64)FF_P)
+        : "vcc", "scc");
+    return s + (u64)m;
+#else
     const u64 s = lo + (u64)h0 * FF_EPS;
     const u32 m = ((s < lo) | (s >= FF_P)) ? 0xFFFFFFFFu : 0u;
     return s + (u64)m;
+#endif
 }
 
 // lo + 2^64 * (h0 + 2^32 h1) -> canonical    (2^64 = 2^32 - 1, 2^96 = -1)
 FF_FN u64 ff_reduce128(u64 lo, u32 h0, u32 h1)
 {
-    u64 t = lo - h1;
-    if (lo < h1) t -= FF_EPS;              // borrow: + P; cannot underflow again
-    return ff_reduce96(t, h0);
+    // lo - h1 with the borrow fixed by + P; valid for ANY 64-bit lo (h1 < 2^32: cannot underflow again)
+    return ff_reduce96(ff_sub(lo, (u64)h1), h0);
 }
 
 // 64 x 64 -> 128 as one chain of four 32 x 32 + 64 multiply-adds (v_mad_u64_u32); the low word is
