@@ -20,6 +20,7 @@
 // multiplied straight out of registers against the key row (stored in the wave layout, read with
 // 16-byte loads, 1 KiB per wave instruction); no s_barrier anywhere in the loop.
 #pragma once
+#include <type_traits>
 #include "ff.h"
 #include "ntt1024.h"
 
@@ -115,6 +116,34 @@ FF_FN void br_mac(u64 (&sum)[K + 1][16], const u64 (&x)[16], const u64 *poly, in
     }
 }
 
+// K = 1 form of the multiply-accumulate: both digit polynomials x0, x1 of one input polynomial m at
+// once, sum[mo] (+)= x0 (*) BK[m][0][mo] + x1 (*) BK[m][1][mo] with one reduction per pair of products
+// (ff_dot2).  FIRST: the sums are assigned, not accumulated.  poly = BK_row[m][0][0]; the d = 1
+// polynomials follow 2 polynomials later.  Key loads run one step ahead, as in br_mac.
+template <bool FIRST>
+FF_FN void br_mac2(u64 (&sum)[2][16], const u64 (&x0)[16], const u64 (&x1)[16], const u64 *poly, int lane)
+{
+    const u64 *p = poly + lane * 2;
+    const u64 *pd = p + 2 * BK_POLY_ELEMS;
+    u64 k00 = p[0], k01 = p[1], k10 = pd[0], k11 = pd[1];
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        const int mo = t >> 3, h = t & 7;
+        u64 n00 = 0, n01 = 0, n10 = 0, n11 = 0;
+        if (t + 1 < 16) {
+            const int off = ((t + 1) >> 3) * BK_POLY_ELEMS + ((t + 1) & 7) * 128;
+            n00 = p[off];
+            n01 = p[off + 1];
+            n10 = pd[off];
+            n11 = pd[off + 1];
+            BR_ISSUE_FENCE();
+        }
+        sum[mo][2 * h] = ff_dot2<!FIRST>(x0[2 * h], k00, x1[2 * h], k10, sum[mo][2 * h]);
+        sum[mo][2 * h + 1] = ff_dot2<!FIRST>(x0[2 * h + 1], k01, x1[2 * h + 1], k11, sum[mo][2 * h + 1]);
+        k00 = n00; k01 = n01; k10 = n10; k11 = n11;
+    }
+}
+
 // External product of one TGSW row with a TLWE sample given coefficient-wise by `tsrc`:
 //   sum[mo] (field elements of the coefficient-domain result, coefficient lane + 64 r; for r >= 1
 //   NEGATED, see br_coeff_to_u32) = sum_{m, d} digit_d(T_m) (*) BK_row[m][d][mo]   (tgsw_cpu.py:82-106)
@@ -127,27 +156,28 @@ FF_FN void br_external_product(u64 (&sum)[K + 1][16], TSource &&tsrc, const u64 
                                const NttLane &L)
 {
     const int lane = L.lane;
-#pragma unroll
-    for (int mo = 0; mo <= K; mo++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) sum[mo][r] = 0;
-    auto mac = [&](const u64 (&x)[16], const u64 *poly) { br_mac<K>(sum, x, poly, lane); };
     if constexpr (K == 1) {
-#pragma unroll
-        for (int m = 0; m <= K; m++) {
+        auto half = [&](auto first, int m) {
             u32 T[16];
             tsrc(m, T);
+            u64 x0[16], x1[16];
+            i32 dg[16];
 #pragma unroll
-            for (int d = 0; d < 2; d++) {
-                u64 x[16];
-                i32 dg[16];
+            for (int r = 0; r < 16; r++) dg[r] = br_digit<0>(T[r]);
+            ntt_forward_small(x0, dg, lds.xbuf, lds.tw1f, L);
 #pragma unroll
-                for (int r = 0; r < 16; r++) dg[r] = d == 0 ? br_digit<0>(T[r]) : br_digit<1>(T[r]);
-                ntt_forward_small(x, dg, lds.xbuf, lds.tw1f, L);
-                mac(x, row + (m * 2 + d) * (K + 1) * BK_POLY_ELEMS);
-            }
-        }
+            for (int r = 0; r < 16; r++) dg[r] = br_digit<1>(T[r]);
+            ntt_forward_small(x1, dg, lds.xbuf, lds.tw1f, L);
+            br_mac2<decltype(first)::value>(sum, x0, x1, row + m * 4 * BK_POLY_ELEMS, lane);
+        };
+        half(std::true_type{}, 0);
+        half(std::false_type{}, 1);
     } else {
+#pragma unroll
+        for (int mo = 0; mo <= K; mo++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) sum[mo][r] = 0;
+        auto mac = [&](const u64 (&x)[16], const u64 *poly) { br_mac<K>(sum, x, poly, lane); };
 #pragma unroll 1
         for (int md = 0; md < 2 * (K + 1); md++) {
             u32 T[16];

@@ -106,6 +106,46 @@ FF_FN void ff_mul_wide(u64 a, u64 b, u64 &lo, u64 &hi)
     lo = (w << 32) | (u32)u;
 }
 
+// a0 * b0 + a1 * b1 [+ c] for canonical operands with ONE reduction: the two 128-bit products (each
+// < 2^128 - 2^97) and the optional canonical addend c are summed exactly in 129 bits
+// lo + 2^64 (h0 + 2^32 h1) + 2^128 top, and 2^128 = -2^32 (mod P), so the top bit joins h1 as a
+// 33-bit subtrahend.  Saves a reduction and a modular addition per extra product.
+template <bool ADD>
+FF_FN u64 ff_dot2(u64 a0, u64 b0, u64 a1, u64 b1, u64 c)
+{
+    u64 lo0, hi0, lo1, hi1;
+    ff_mul_wide(a0, b0, lo0, hi0);
+    ff_mul_wide(a1, b1, lo1, hi1);
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned cy;
+    u32 l0 = __builtin_addc((u32)lo0, (u32)lo1, 0u, &cy);
+    u32 l1 = __builtin_addc((u32)(lo0 >> 32), (u32)(lo1 >> 32), cy, &cy);
+    u32 h0 = __builtin_addc((u32)hi0, (u32)hi1, cy, &cy);
+    u32 h1 = __builtin_addc((u32)(hi0 >> 32), (u32)(hi1 >> 32), cy, &cy);
+    u32 top = cy;
+    if constexpr (ADD) {
+        l0 = __builtin_addc(l0, (u32)c, 0u, &cy);
+        l1 = __builtin_addc(l1, (u32)(c >> 32), cy, &cy);
+        h0 = __builtin_addc(h0, 0u, cy, &cy);
+        h1 = __builtin_addc(h1, 0u, cy, &cy);
+        top += cy;
+    }
+    const u64 lo = ((u64)l1 << 32) | l0;
+#else
+    unsigned __int128 sum = (((unsigned __int128)hi0 << 64) | lo0);
+    unsigned __int128 t = sum + (((unsigned __int128)hi1 << 64) | lo1);
+    u32 top = t < sum;
+    if constexpr (ADD) {
+        const unsigned __int128 t2 = t + c;
+        top += t2 < t;
+        t = t2;
+    }
+    const u64 lo = (u64)t;
+    const u32 h0 = (u32)(t >> 64), h1 = (u32)(t >> 96);
+#endif
+    return ff_reduce96(ff_sub(lo, ((u64)top << 32) | h1), h0);
+}
+
 // canonical * canonical -> canonical
 FF_FN u64 ff_mul(u64 a, u64 b)
 {
