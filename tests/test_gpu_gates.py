@@ -237,3 +237,15 @@ def test_small_batch_team_kernel_equals_wave_kernel(env, orc):
                 assert (ra == exp[0]).all() and (rb == exp[1]).all() and (rcv == exp[2]).all(), limit
     finally:
         _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, -1)
+
+
+@pytest.mark.parametrize('script', ['gate_nand.py', 'gate_nand_low_level.py', 'serialization.py'])
+def test_examples_run(script):
+    """The counterparts of the reference's examples/ run end to end on the GPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.run([sys.executable, os.path.join(root, 'examples', script), '--bits', '16'],
+                          capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout + proc.stderr
+    assert 'OK' in proc.stdout
