@@ -127,6 +127,16 @@ def test_lwe_linear_and_trivial(thr, H, golden):
     L.lwe_noiseless_trivial_constant(thr, t, -123)
     ta, tb, tcv = H.ct_arrays(t)
     assert (ta == 0).all() and (tb == -123).all() and (tcv == 0).all()
+    # lwe_noiseless_trivial with full-shape, trailing-axis and scalar sources (test_lwe.py:325-385)
+    rs = numpy.random.RandomState(77)
+    for src_shape in ((5, 3), (3,), ()):
+        mus = rs.randint(-2**31, 2**31, size=src_shape, dtype=numpy.int32)
+        t = H.ciphertext_from_arrays(thr, (rs.randint(-9, 9, size=(5, 3, 500), dtype=numpy.int32),
+                                           rs.randint(-9, 9, size=(5, 3), dtype=numpy.int32),
+                                           numpy.ones((5, 3), numpy.float32)))
+        L.lwe_noiseless_trivial(thr, t, mus)
+        ta, tb, tcv = H.ct_arrays(t)
+        assert (ta == 0).all() and (tb == numpy.broadcast_to(mus, (5, 3))).all() and (tcv == 0).all()
 
 
 def _key_with_bk(thr, bk):
