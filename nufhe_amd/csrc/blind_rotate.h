@@ -116,21 +116,21 @@ FF_FN void br_mac(u64 (&sum)[K + 1][16], const u64 (&x)[16], const u64 *poly, in
     }
 }
 
-// K = 1 form of the multiply-accumulate: both digit polynomials x0, x1 of one input polynomial m at
+// Paired form of the multiply-accumulate: both digit polynomials x0, x1 of one input polynomial m at
 // once, sum[mo] (+)= x0 (*) BK[m][0][mo] + x1 (*) BK[m][1][mo] with one reduction per pair of products
 // (ff_dot2).  FIRST: the sums are assigned, not accumulated.  poly = BK_row[m][0][0]; the d = 1
-// polynomials follow 2 polynomials later.  Key loads run one step ahead, as in br_mac.
-template <bool FIRST>
-FF_FN void br_mac2(u64 (&sum)[2][16], const u64 (&x0)[16], const u64 (&x1)[16], const u64 *poly, int lane)
+// polynomials follow K + 1 polynomials later.  Key loads run one step ahead, as in br_mac.
+template <int K, bool FIRST>
+FF_FN void br_mac2(u64 (&sum)[K + 1][16], const u64 (&x0)[16], const u64 (&x1)[16], const u64 *poly, int lane)
 {
     const u64 *p = poly + lane * 2;
-    const u64 *pd = p + 2 * BK_POLY_ELEMS;
+    const u64 *pd = p + (K + 1) * BK_POLY_ELEMS;
     u64 k00 = p[0], k01 = p[1], k10 = pd[0], k11 = pd[1];
 #pragma unroll
-    for (int t = 0; t < 16; t++) {
+    for (int t = 0; t < 8 * (K + 1); t++) {
         const int mo = t >> 3, h = t & 7;
         u64 n00 = 0, n01 = 0, n10 = 0, n11 = 0;
-        if (t + 1 < 16) {
+        if (t + 1 < 8 * (K + 1)) {
             const int off = ((t + 1) >> 3) * BK_POLY_ELEMS + ((t + 1) & 7) * 128;
             n00 = p[off];
             n01 = p[off + 1];
@@ -148,9 +148,9 @@ FF_FN void br_mac2(u64 (&sum)[2][16], const u64 (&x0)[16], const u64 (&x1)[16], 
 //   sum[mo] (field elements of the coefficient-domain result, coefficient lane + 64 r; for r >= 1
 //   NEGATED, see br_coeff_to_u32) = sum_{m, d} digit_d(T_m) (*) BK_row[m][d][mo]   (tgsw_cpu.py:82-106)
 // tsrc(m, T) must fill T[r] = coefficient lane + 64 r of polynomial m (as uint32 torus values).
-// K = 1: everything unrolled (tsrc may index registers with m).  K > 1: the (m, d) loops stay
-// rolled -- one forward transform + (K+1) multiply-accumulates of code -- so tsrc gets a run-time m
-// and must read its polynomial from memory (the LDS mirror), never from a register array.
+// K = 1: everything unrolled (tsrc may index registers with m).  K > 1: the loop over m stays
+// rolled -- two forward transforms + the paired multiply-accumulate of code -- so tsrc gets a
+// run-time m and must read its polynomial from memory (the LDS mirror), never from a register array.
 template <int K, class TSource>
 FF_FN void br_external_product(u64 (&sum)[K + 1][16], TSource &&tsrc, const u64 *row, const BrLds &lds,
                                const NttLane &L)
@@ -168,7 +168,7 @@ FF_FN void br_external_product(u64 (&sum)[K + 1][16], TSource &&tsrc, const u64 
 #pragma unroll
             for (int r = 0; r < 16; r++) dg[r] = br_digit<1>(T[r]);
             ntt_forward_small(x1, dg, lds.xbuf, lds.tw1f, L);
-            br_mac2<decltype(first)::value>(sum, x0, x1, row + m * 4 * BK_POLY_ELEMS, lane);
+            br_mac2<1, decltype(first)::value>(sum, x0, x1, row + m * 4 * BK_POLY_ELEMS, lane);
         };
         half(std::true_type{}, 0);
         half(std::false_type{}, 1);
@@ -177,18 +177,19 @@ FF_FN void br_external_product(u64 (&sum)[K + 1][16], TSource &&tsrc, const u64 
         for (int mo = 0; mo <= K; mo++)
 #pragma unroll
             for (int r = 0; r < 16; r++) sum[mo][r] = 0;
-        auto mac = [&](const u64 (&x)[16], const u64 *poly) { br_mac<K>(sum, x, poly, lane); };
 #pragma unroll 1
-        for (int md = 0; md < 2 * (K + 1); md++) {
+        for (int m = 0; m <= K; m++) {
             u32 T[16];
-            tsrc(md >> 1, T);
-            u64 x[16];
+            tsrc(m, T);
+            u64 x0[16], x1[16];
             i32 dg[16];
-            const int sh = (md & 1) ? 12 : 22;     // 32 - 10 (d + 1)
 #pragma unroll
-            for (int r = 0; r < 16; r++) dg[r] = (((i32)(T[r] + TGSW_OFFSET) >> sh) & 1023) - 512;
-            ntt_forward_small(x, dg, lds.xbuf, lds.tw1f, L);
-            mac(x, row + (long)md * (K + 1) * BK_POLY_ELEMS);
+            for (int r = 0; r < 16; r++) dg[r] = br_digit<0>(T[r]);
+            ntt_forward_small(x0, dg, lds.xbuf, lds.tw1f, L);
+#pragma unroll
+            for (int r = 0; r < 16; r++) dg[r] = br_digit<1>(T[r]);
+            ntt_forward_small(x1, dg, lds.xbuf, lds.tw1f, L);
+            br_mac2<K, false>(sum, x0, x1, row + (long)m * 2 * (K + 1) * BK_POLY_ELEMS, lane);
         }
     }
     // NEG_OUT: coefficients j2 >= 1 come back negated (callers use br_coeff_to_u32).  Explicitly
