@@ -151,6 +151,15 @@ int nufhe_ntt_inverse_u64(nufhe_ctx *ctx, uint64_t *d_out, const uint64_t *d_in,
  * complex128 [batch][512] (re, im interleaved), natural order; inverse rounds to nearest. */
 int nufhe_fft_forward_i32(nufhe_ctx *ctx, double *d_out, const int32_t *d_in, long batch);
 int nufhe_fft_inverse_i32(nufhe_ctx *ctx, int32_t *d_out, const double *d_in, long batch);
+/* Element-wise GF(2^64 - 2^32 + 1) primitives exactly as the device kernels use them (reference test
+ * surface: test/test_transform/test_arithmetic.py over transform/arithmetic.mako).  Inputs must be
+ * canonical (< P) unless stated.  op: 0 a+b, 1 a-b, 2 a*b, 3 a*b+c*d, 4 a*b+c*d+e,
+ * 5 a*2^(b&31), 6 a*2^shift (0 <= shift < 192), 7 reduce(a + 2^64 (uint32)b) for ANY 64-bit a,
+ * 8 int32 conversions: low word = to_i32(from_i32((int32)a)), high word = to_i32(a).
+ * Unused operand pointers may be NULL. */
+int nufhe_ff_op(nufhe_ctx *ctx, uint64_t *d_out, const uint64_t *d_a, const uint64_t *d_b,
+                const uint64_t *d_c, const uint64_t *d_d, const uint64_t *d_e, int op, int shift,
+                long count);
 /* Negacyclic product mod 2^32 of int32 polynomials through the NTT: out[b] = x[b] * y[b % y_batch] */
 int nufhe_poly_mul_i32(nufhe_ctx *ctx, int32_t *d_out, const int32_t *d_x, const int32_t *d_y,
                        long batch, long y_batch);

@@ -629,6 +629,16 @@ int nufhe_fft_inverse_i32(nufhe_ctx *ctx, int32_t *d_out, const double *d_in, lo
     return NUFHE_OK;
 }
 
+int nufhe_ff_op(nufhe_ctx *ctx, uint64_t *d_out, const uint64_t *d_a, const uint64_t *d_b, const uint64_t *d_c,
+                const uint64_t *d_d, const uint64_t *d_e, int op, int shift, long count)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (op < 0 || op > 8 || shift < 0 || shift >= 192) return fail(NUFHE_EINVAL, "bad ff op %d / shift %d", op, shift);
+    HIP_TRY(launch_ff_op(d_out, d_a, d_b, d_c, d_d, d_e, op, shift, count, ctx->stream));
+    return NUFHE_OK;
+}
+
 int nufhe_poly_mul_i32(nufhe_ctx *ctx, int32_t *d_out, const int32_t *d_x, const int32_t *d_y, long batch, long y_batch)
 {
     int rc = check_ctx(ctx);

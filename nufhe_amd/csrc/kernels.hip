@@ -662,6 +662,43 @@ __global__ void k_tlwe_extract(i32 *__restrict__ ra, i32 *__restrict__ rb, const
 }
 
 // ------------------------------------------------------------------------------------------
+// Test hook for the GF(P) primitives as the DEVICE compiles them (ff.h has device-only instruction
+// sequences: borrow chains, v_mad_u64_u32 carry-out); the reference tests its finite-field module the
+// same way (test/test_transform/test_arithmetic.py).  op: 0 add, 1 sub, 2 mul, 3 a*b + c*d,
+// 4 a*b + c*d + e, 5 a * 2^(b & 31) (per-element shift), 6 a * 2^shift (compile-time shift family,
+// any shift in [0, 192)), 7 reduce96(a, (u32)b), 8 from_i32((i32)a) / to_i32 round trip (out = to_i32)
+// ------------------------------------------------------------------------------------------
+template <int S>
+struct FfShiftDispatch {
+    __device__ static u64 run(u64 x, int s) { return s == S ? ff_mul_pow2<S>(x) : FfShiftDispatch<S - 1>::run(x, s); }
+};
+template <>
+struct FfShiftDispatch<-1> {
+    __device__ static u64 run(u64 x, int) { return x; }
+};
+
+__global__ void k_ff_op(u64 *__restrict__ out, const u64 *__restrict__ a, const u64 *__restrict__ b,
+                        const u64 *__restrict__ c, const u64 *__restrict__ d, const u64 *__restrict__ e, int op,
+                        int shift, long count)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    u64 r = 0;
+    switch (op) {
+    case 0: r = ff_add(a[i], b[i]); break;
+    case 1: r = ff_sub(a[i], b[i]); break;
+    case 2: r = ff_mul(a[i], b[i]); break;
+    case 3: r = ff_dot2<false>(a[i], b[i], c[i], d[i], 0); break;
+    case 4: r = ff_dot2<true>(a[i], b[i], c[i], d[i], e[i]); break;
+    case 5: r = ff_mul_pow2_var(a[i], (u32)b[i] & 31u); break;
+    case 6: r = FfShiftDispatch<191>::run(a[i], shift); break;
+    case 7: r = ff_reduce96(a[i], (u32)b[i]); break;
+    case 8: r = (u64)(u32)ff_to_i32(ff_from_i32((i32)a[i])) | ((u64)(u32)ff_to_i32(a[i]) << 32); break;
+    }
+    out[i] = r;
+}
+
+// ------------------------------------------------------------------------------------------
 // Host launchers
 // ------------------------------------------------------------------------------------------
 static inline unsigned blocks_for(long n, int per) { return (unsigned)((n + per - 1) / per); }
@@ -711,6 +748,14 @@ hipError_t kernels_init_device()
 }
 
 int kernels_num_cus() { return g_num_cus; }
+
+hipError_t launch_ff_op(u64 *out, const u64 *a, const u64 *b, const u64 *c, const u64 *d, const u64 *e, int op,
+                        int shift, long count, hipStream_t stream)
+{
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ff_op, dim3(blocks_for(count, 256)), dim3(256), 0, stream, out, a, b, c, d, e, op, shift, count);
+    return hipGetLastError();
+}
 
 hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, long team_max_bits, hipStream_t stream)
 {

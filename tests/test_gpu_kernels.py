@@ -249,3 +249,53 @@ def test_lwe_encrypt_decrypt_vs_reference_golden(thr, H, golden, orc):
     assert (a == exp[0]).all() and (b2 == exp[1]).all() and (cv == exp[2]).all()
     assert (ctx.decrypt(sk, ct) == m).all()
     assert (ctx.decrypt(sk, ct[1:4, ::2]) == m[1:4, ::2]).all()      # strided view
+
+
+def test_ff_primitives_on_device_vs_bigint(thr, H):
+    """GF(P) primitives as compiled for the device (borrow chains, v_mad_u64_u32 carry-out, 129-bit
+    lazy dot product) against Python integers, on the reference's boundary values
+    (test_arithmetic.py:154-157,172,248) plus random canonical elements."""
+    P = 2**64 - 2**32 + 1
+    edge = [0, 1, 2, 2**32 - 2, 2**32 - 1, 2**32, 2**32 + 1, 2**33, 2**63, P // 2, P // 2 + 1,
+            P - 2**32, P - 2**32 - 1, P - 2, P - 1, 0xFFFFFFFE00000001, 0xFFFFFFFF, 0xFFFFFFFF00000000]
+    rs = numpy.random.RandomState(99)
+    rnd = [int(x) % P for x in rs.randint(0, 2**63, size=3000, dtype=numpy.int64).astype(object) * 2 + 1]
+    vals = edge + rnd
+
+    def run(op, cols, shift=0):
+        n = len(cols[0])
+        devs = [H.dev(thr, numpy.array(c, dtype=numpy.uint64)) for c in cols]
+        out = thr.array((n,), numpy.uint64)
+        ptrs = [ptr(d) for d in devs] + [None] * (5 - len(devs))
+        call("nufhe_ff_op", thr.handle, ptr(out), *ptrs, op, shift, n)
+        return [int(x) for x in H.host_u64(out)]
+
+    # all edge x edge pairs + random pairs
+    A = [a for a in edge for _ in edge] + rnd
+    B = [b for _ in edge for b in edge] + rnd[::-1]
+    assert run(0, [A, B]) == [(a + b) % P for a, b in zip(A, B)]
+    assert run(1, [A, B]) == [(a - b) % P for a, b in zip(A, B)]
+    assert run(2, [A, B]) == [(a * b) % P for a, b in zip(A, B)]
+    C = B[3:] + B[:3]; D = A[7:] + A[:7]; E = A[11:] + A[:11]
+    assert run(3, [A, B, C, D]) == [(a * b + c * d) % P for a, b, c, d in zip(A, B, C, D)]
+    assert run(4, [A, B, C, D, E]) == [(a * b + c * d + e) % P for a, b, c, d, e in zip(A, B, C, D, E)]
+    # maximal operands: the 129-bit accumulator's top bit and the addend's carry
+    M = [P - 1] * 4
+    assert run(4, [M, M, M, M, M]) == [((P - 1) * (P - 1) * 2 + P - 1) % P] * 4
+    # per-element shifts 0..31 and every compile-time shift 0..191 (the reference's lsh family)
+    sh = [i % 32 for i in range(len(vals))]
+    assert run(5, [vals, sh]) == [(v << s) % P for v, s in zip(vals, sh)]
+    for shift in range(192):
+        assert run(6, [vals[:64]], shift) == [(v << shift) % P for v in vals[:64]], shift
+    # reduce96 accepts ANY 64-bit low word (not only canonical ones)
+    lo = [2**64 - 1, 2**64 - 2, P, P + 1, 0, 2**64 - 2**32] + rnd[:500]
+    h0 = [2**32 - 1, 2**32 - 1, 1, 0, 2**32 - 1, 2**32 - 1] + [x & 0xFFFFFFFF for x in rnd[500:1000]]
+    assert run(7, [lo, h0]) == [(l + (h << 64)) % P for l, h in zip(lo, h0)]
+    # int32 conversions (ntt.mako:395-408, test_ntt_cpu.py:60-67)
+    ints = [0, 1, -1, 2**31 - 1, -2**31, 12345, -12345]
+    got = run(8, [[i & 0xFFFFFFFFFFFFFFFF for i in ints] + vals[:32]])
+    for i, g in zip(ints, got):
+        assert (g & 0xFFFFFFFF) == (i & 0xFFFFFFFF)
+    for v, g in zip(vals[:32], got[len(ints):]):
+        signed = v - P if v > P // 2 else v
+        assert (g >> 32) == (signed & 0xFFFFFFFF)
