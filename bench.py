@@ -154,6 +154,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the result gather alone (reported separately; it is also part of every timed step)
+    gather_ms = None
+    if world > 1:
+        multi_gpu.gather_ciphertext(out, world * B)
+        torch.cuda.synchronize(); dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            multi_gpu.gather_ciphertext(out, world * B)
+        torch.cuda.synchronize(); dist.barrier()
+        gather_ms = 1e3 * (time.perf_counter() - t1) / 5
+
     # secondary measurements, OUTSIDE the timed region: the other BASELINE configurations on the same
     # ciphertexts (3 steps each after 1 warm-up); reported under "other_configs", never in "value"
     other = {}
@@ -260,6 +271,9 @@ def main():
                 "gate_streaming_model_GBs": a_gate / (ms_per_step * 1e-3) / 1e9,
             },
         }
+        if gather_ms is not None:
+            result["gather_ms"] = gather_ms
+            result["gather_bytes_per_rank"] = B * 2008
         if other:
             result["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:
