@@ -1,0 +1,39 @@
+"""Soak test: repeats gates many times and requires bit-identical ciphertexts every time
+(the kernels synchronise waves with fences only / work-group barriers in the team kernel; any race
+would show up as a run-to-run difference) and correct decryptions."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy, torch, nufhe_amd
+
+def soak(ctx, vm, sk, B, reps, gate):
+    rs = numpy.random.RandomState(B)
+    m = [rs.randint(0, 2, size=B).astype(bool) for _ in range(3)]
+    c = [ctx.encrypt(sk, x) for x in m]
+    fn = (lambda: vm.gate_mux(c[0], c[1], c[2])) if gate == 'mux' else (lambda: vm.gate_nand(c[0], c[1]))
+    ref = fn()
+    truth = numpy.where(m[0], m[1], m[2]) if gate == 'mux' else ~(m[0] & m[1])
+    assert (ctx.decrypt(sk, ref) == truth).all()
+    bad = 0
+    t = time.time()
+    for _ in range(reps):
+        r = fn()
+        same = bool(torch.equal(r.a, ref.a) and torch.equal(r.b, ref.b) and torch.equal(r.current_variances, ref.current_variances))
+        bad += not same
+    print("%s %5d bits x %4d: %d differing runs, %.1f s" % (gate, B, reps, bad, time.time() - t), flush=True)
+    return bad
+
+def main():
+    total = 0
+    for tr in ('NTT', 'FFT'):
+        ctx = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(5))
+        sk, ck = ctx.make_key_pair(transform_type=tr)
+        vm = ctx.make_virtual_machine(ck)
+        print(tr)
+        for B, reps in ((4096, 60 if tr == 'NTT' else 200), (1000, 100), (200, 300), (7, 300)):
+            total += soak(ctx, vm, sk, B, reps, 'nand')
+        total += soak(ctx, vm, sk, 300, 100, 'mux')
+    print("TOTAL differing runs:", total)
+    sys.exit(1 if total else 0)
+
+if __name__ == '__main__':
+    main()
