@@ -271,6 +271,16 @@ def main():
                 "gate_streaming_model_GBs": a_gate / (ms_per_step * 1e-3) / 1e9,
             },
         }
+        if args.transform == "NTT":
+            # what actually binds K1: VALU issue.  Instruction count per bit-iteration from
+            # the ISA of the loop body (confirmed by PMC SQ_INSTS_VALU), 4 cycles per wave64 instruction,
+            # 1024 SIMDs, sustained clock from PMC SQ_WAVE_CYCLES (2.1 GHz).
+            valu_per_iter, simds, clock = 14250, 1024, 2.1e9
+            issued = B * n_rot * 500 * valu_per_iter
+            result["roofline"]["valu_issue"] = {
+                "instructions_per_launch": issued,
+                "frac_of_simd_cycles": issued * 4 / (simds * clock * br_avg * 1e-3),
+                "note": "wave64 VALU instructions x 4 cycles / (1024 SIMDs x 2.1 GHz x kernel time)"}
         if gather_ms is not None:
             result["gather_ms"] = gather_ms
             result["gather_bytes_per_rank"] = B * 2008
