@@ -249,3 +249,24 @@ def test_examples_run(script):
                           capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stdout + proc.stderr
     assert 'OK' in proc.stdout
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N > 1 path end to end (sharded bits, replicated keys, result gather, max-over-ranks
+    timing), with two ranks sharing this box's GPU over the gloo test route; the RCCL route differs
+    only in the backend string."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NUFHE_BENCH_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', '29533', os.path.join(root, 'bench.py'),
+           '--gpus', '2', '--steps', '1', '--warmup', '1', '--bits', '256', '--no-extra']
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+    lines = [l for l in proc.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['correct'] and d['scaling'] == 'weak' and d['gather_ms'] > 0
+    assert abs(d['value'] - 2 * 256 * 1000.0 / d['ms_per_step']) < 1e-6 * d['value']
