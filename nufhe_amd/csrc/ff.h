@@ -217,14 +217,22 @@ FF_FN u64 ff_submul_pow2(u64 a, u64 b)
     else return ff_mul_pow2_lt96<T>(ff_sub(a, b));
 }
 
-// small signed integer d (|d| <= 2^10, e.g. a gadget digit) times 2^S -> canonical, for S <= 53:
-// the product fits a signed 64-bit word, so the residue is t or t + P.
+// small signed integer d in [-2^9, 2^9) (a gadget digit) times 2^S -> canonical.
+// S <= 54: the product fits a signed 64-bit word, so the residue is t or t + P.
+// 64 <= S <= 84: d 2^S = (d 2^(S-64)) 2^64 = u eps with u eps = (u << 32) - u still inside a signed
+// 64-bit word (|u| < 2^(S-55)), again t or t + P.
 template <int S>
 FF_FN u64 ff_small_times_pow2(i32 d)
 {
-    static_assert(S >= 0 && S <= 53, "shift out of range");
-    const u64 t = (u64)((int64_t)d << S);
-    return d < 0 ? t + FF_P : t;
+    static_assert((S >= 0 && S <= 54) || (S >= 64 && S <= 84), "shift out of range");
+    if constexpr (S <= 54) {
+        const u64 t = (u64)((int64_t)d << S);
+        return d < 0 ? t + FF_P : t;
+    } else {
+        const int64_t u = (int64_t)d << (S - 64);
+        const u64 t = (u64)((u << 32) - u);
+        return d < 0 ? t + FF_P : t;
+    }
 }
 
 // canonical x times 2^r, r a run-time (per-lane) amount in [0, 31]

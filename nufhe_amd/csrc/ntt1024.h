@@ -184,15 +184,15 @@ FF_FN void ntt_forward(u64 (&x)[16], u64 *xbuf, const u64 *tw1f, const NttLane &
     ntt_forward_pretwisted(x, xbuf, tw1f, L);
 }
 
-// forward transform of a polynomial with SMALL coefficients (|d| <= 2^10: gadget digits):
-// d[j2] = coefficient lane + 64 j2.  The pre-twist d * 2^(6 j2) needs no modular reduction
-// while 6 j2 + 10 < 64.
+// forward transform of a polynomial with SMALL coefficients (gadget digits, -2^9 <= d < 2^9):
+// d[j2] = coefficient lane + 64 j2.  The pre-twist d * 2^(6 j2) needs no modular reduction while it
+// (or its multiple of eps, for shifts >= 64) fits a signed 64-bit word: ff_small_times_pow2.
 FF_FN void ntt_forward_small(u64 (&x)[16], const i32 (&d)[16], u64 *xbuf, const u64 *tw1f, const NttLane &L)
 {
 #define PRES(j2) x[j2] = ff_small_times_pow2<6 * (j2)>(d[j2])
 #define PREG(j2) x[j2] = ff_mul_pow2<6 * (j2)>(ff_from_i32(d[j2]))
-    PRES(0); PRES(1); PRES(2); PRES(3); PRES(4); PRES(5); PRES(6); PRES(7); PRES(8);
-    PREG(9); PREG(10); PREG(11); PREG(12); PREG(13); PREG(14); PREG(15);
+    PRES(0); PRES(1); PRES(2); PRES(3); PRES(4); PRES(5); PRES(6); PRES(7); PRES(8); PRES(9);
+    PREG(10); PRES(11); PRES(12); PRES(13); PRES(14); PREG(15);     // shifts 60 and 90 take the general route
 #undef PRES
 #undef PREG
     ntt_forward_pretwisted(x, xbuf, tw1f, L);
