@@ -275,7 +275,7 @@ def main():
             # what actually binds K1: VALU issue.  Instruction count per bit-iteration from
             # the ISA of the loop body (confirmed by PMC SQ_INSTS_VALU), 4 cycles per wave64 instruction,
             # 1024 SIMDs, sustained clock from PMC SQ_WAVE_CYCLES (2.1 GHz).
-            valu_per_iter, simds, clock = 14250, 1024, 2.1e9
+            valu_per_iter, simds, clock = 14126, 1024, 2.1e9
             issued = B * n_rot * 500 * valu_per_iter
             result["roofline"]["valu_issue"] = {
                 "instructions_per_launch": issued,
