@@ -441,6 +441,7 @@ __global__ __launch_bounds__(NTT_BLOCK_THREADS) void k_bk_from_coeffs(u64 *__res
 // ------------------------------------------------------------------------------------------
 // LDS: 2 stages x 4 rows (row 0 = zeros for digit 0) x 512 int32
 #define KS_ROW_WORDS 512
+#define KS_READLANE(v, lane) ((u32)__builtin_amdgcn_readlane((int)(v), (lane)))
 #define KS_STAGE_WORDS (4 * KS_ROW_WORDS)
 
 __global__ __launch_bounds__(KS_BLOCK_THREADS) void k_keyswitch_a(KsLaunch P)
@@ -472,6 +473,16 @@ __global__ __launch_bounds__(KS_BLOCK_THREADS) void k_keyswitch_a(KsLaunch P)
     }
     const int steps = P.j_per_block * 8;   // P.j_per_block divides the input size (mask_size * 1024)
     u32 aj[KS_TILE_BITS];
+    const int my_bit = tid & 63;                        // lane index: bit of the tile this lane fetches
+    auto load_aj = [&](int j) -> u32 {
+        u32 v = 0;
+        if (my_bit < nb) {
+            v = (u32)P.src1_a[(bit0 + my_bit) * P.src1_stride + j];
+            if (P.src2_a) v += (u32)P.src2_a[(bit0 + my_bit) * P.src2_stride + j];
+        }
+        return v;
+    };
+    u32 aj_lane = load_aj(j0);
     for (int s = 0; s < steps; s++) {
         const int j = j0 + (s >> 3), k = s & 7;
         u32 *stage = rows_lds + (s & 1) * KS_STAGE_WORDS;
@@ -489,16 +500,14 @@ __global__ __launch_bounds__(KS_BLOCK_THREADS) void k_keyswitch_a(KsLaunch P)
             }
         }
         if (k == 0) {
-            // source coefficients of this tile's bits for input coefficient j: wave-uniform
+            // source coefficients of this tile's bits for input coefficient j: lane t of every wave holds
+            // bit t's value (one load per j, issued one j ahead); the wave-uniform copies come out of it
+            // with constant-lane v_readlane.  (32 separately addressed uniform loads would need 64
+            // SGPRs of row pointers and push the kernel into SGPR spilling.)
 #pragma unroll
-            for (int t = 0; t < KS_TILE_BITS; t++) {
-                u32 v = 0;
-                if (t < nb) {
-                    v = (u32)P.src1_a[(bit0 + t) * P.src1_stride + j];
-                    if (P.src2_a) v += (u32)P.src2_a[(bit0 + t) * P.src2_stride + j];
-                }
-                aj[t] = WAVE_UNIFORM(v) + (1u << 15);   // + prec_offset, lwe_cpu.py:70
-            }
+            for (int t = 0; t < KS_TILE_BITS; t++)
+                aj[t] = KS_READLANE(aj_lane, t) + (1u << 15);   // + prec_offset, lwe_cpu.py:70
+            if (s + 8 < steps) aj_lane = load_aj(j + 1);
         }
         __syncthreads();   // stage (s & 1) is complete; stage ((s + 1) & 1) is free again
         const int sh = 30 - 2 * k;
