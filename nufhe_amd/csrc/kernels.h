@@ -8,7 +8,7 @@
 #define BR_BLOCK_THREADS 512
 #define BR_WAVES_PER_BLOCK 8
 #define KS_BLOCK_THREADS 256
-#define KS_TILE_BITS 32
+#define KS_TILE_BITS 64
 
 struct BrJob {
     BrSource s0, s1;

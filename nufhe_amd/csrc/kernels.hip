@@ -434,46 +434,51 @@ __global__ __launch_bounds__(NTT_BLOCK_THREADS) void k_bk_from_coeffs(u64 *__res
 // ------------------------------------------------------------------------------------------
 // K2: LWE keyswitch (lwe_gpu.mako:59-120, lwe_cpu.py:62-93)
 //   out_a[bit][c] = - sum_{j < 1024, k < 8} KS_a[j][k][digit_jk(src_a[bit][j])][c]
-// A block owns KS_TILE_BITS bits x all columns for one slice of j: the three non-zero key rows of
-// every (j, k) are loaded ONCE per block (coalesced over columns) and each bit picks its row by its
-// wave-uniform digit; per-thread accumulators stay in registers.  j-slices combine with integer
-// atomics (order independent => bit-exact).
+// A block owns KS_TILE_BITS bits x all columns for one slice of j: the non-zero key rows of every
+// (j, k) are loaded ONCE per block (coalesced over columns), staged in LDS, and each bit picks its row
+// by its wave-uniform digit (an LDS address); per-thread accumulators stay in registers.  j-slices
+// combine with integer atomics (order independent => bit-exact).
 // ------------------------------------------------------------------------------------------
-// LDS: 2 stages x 4 rows (row 0 = zeros for digit 0) x 512 int32
 #define KS_ROW_WORDS 512
 #define KS_READLANE(v, lane) ((u32)__builtin_amdgcn_readlane((int)(v), (lane)))
-#define KS_STAGE_WORDS (4 * KS_ROW_WORDS)
 
+// Two digit positions (k, k+1) of an input coefficient are handled at once ("window"): the block
+// pre-adds the 3 + 3 non-zero rows of the pair into the 15 non-zero combinations
+// row[4 d0 + d1] = KS[j][k][d0] + KS[j][k+1][d1] (sums mod 2^32: exact, the result is a sum anyway) in
+// LDS, and every bit then needs ONE row per pair, selected by its 4-bit double digit: half the LDS
+// reads and half the per-bit instructions of a digit-by-digit loop.  LDS: 2 stages x 16 rows x 2 KiB.
+#define KSW_STAGE_WORDS (16 * KS_ROW_WORDS)
+#define KS_LDS_BYTES (2 * KSW_STAGE_WORDS * sizeof(u32))
 __global__ __launch_bounds__(KS_BLOCK_THREADS) void k_keyswitch_a(KsLaunch P)
 {
-    __shared__ __attribute__((aligned(16))) u32 rows_lds[2 * KS_STAGE_WORDS];
+    constexpr int TILE = KS_TILE_BITS;
+    extern __shared__ __attribute__((aligned(16))) u32 ks_lds[];   // 2 * KSW_STAGE_WORDS
     const int tid = threadIdx.x;
-    const long bit0 = (long)blockIdx.x * KS_TILE_BITS;
+    const long bit0 = (long)blockIdx.x * TILE;
     const int j0 = blockIdx.y * P.j_per_block;
-    const int c0 = 2 * tid, c1 = 2 * tid + 1;        // this thread's two adjacent columns
+    const int c0 = 2 * tid, c1 = 2 * tid + 1;
     const bool v0 = c0 < P.n, v1 = c1 < P.n;
-    const int nb = (int)((P.nbits - bit0) < KS_TILE_BITS ? (P.nbits - bit0) : KS_TILE_BITS);
+    const int nb = (int)((P.nbits - bit0) < TILE ? (P.nbits - bit0) : TILE);
 
-    u32 acc0[KS_TILE_BITS], acc1[KS_TILE_BITS];
+    u32 acc0[TILE], acc1[TILE];
 #pragma unroll
-    for (int t = 0; t < KS_TILE_BITS; t++) { acc0[t] = 0; acc1[t] = 0; }
-    // zero rows (digit 0) of both stages
-    rows_lds[c0] = 0; rows_lds[c1] = 0;
-    rows_lds[KS_STAGE_WORDS + c0] = 0; rows_lds[KS_STAGE_WORDS + c1] = 0;
+    for (int t = 0; t < TILE; t++) { acc0[t] = 0; acc1[t] = 0; }
+    *(u64 *)&ks_lds[c0] = 0;
+    *(u64 *)&ks_lds[KSW_STAGE_WORDS + c0] = 0;
 
-    // prefetch the three non-zero rows of the first (j, k)
-    u32 pa[3], pb[3];
-    {
-        const i32 *rows = P.ks_a3 + ((long)(j0 * 8) * 3) * P.n;
+    u32 pa[6], pb[6];
+    auto load_rows = [&](int step) {
+        const i32 *rows = P.ks_a3 + ((long)((j0 * 4 + step) * 2) * 3) * P.n;   // (j, k = 2 kp): 6 consecutive rows
 #pragma unroll
-        for (int h = 0; h < 3; h++) {
+        for (int h = 0; h < 6; h++) {
             pa[h] = v0 ? (u32)rows[h * P.n + c0] : 0u;
             pb[h] = v1 ? (u32)rows[h * P.n + c1] : 0u;
         }
-    }
-    const int steps = P.j_per_block * 8;   // P.j_per_block divides the input size (mask_size * 1024)
-    u32 aj[KS_TILE_BITS];
-    const int my_bit = tid & 63;                        // lane index: bit of the tile this lane fetches
+    };
+    load_rows(0);
+    const int steps = P.j_per_block * 4;
+    u32 aj[TILE];
+    const int my_bit = tid & 63;
     auto load_aj = [&](int j) -> u32 {
         u32 v = 0;
         if (my_bit < nb) {
@@ -484,44 +489,35 @@ __global__ __launch_bounds__(KS_BLOCK_THREADS) void k_keyswitch_a(KsLaunch P)
     };
     u32 aj_lane = load_aj(j0);
     for (int s = 0; s < steps; s++) {
-        const int j = j0 + (s >> 3), k = s & 7;
-        u32 *stage = rows_lds + (s & 1) * KS_STAGE_WORDS;
+        const int j = j0 + (s >> 2), kp = s & 3;
+        u64 *stage = (u64 *)(ks_lds + (s & 1) * KSW_STAGE_WORDS) + tid;
 #pragma unroll
-        for (int h = 0; h < 3; h++) {
-            stage[(h + 1) * KS_ROW_WORDS + c0] = pa[h];
-            stage[(h + 1) * KS_ROW_WORDS + c1] = pb[h];
-        }
-        if (s + 1 < steps) {   // prefetch the next (j, k) while this one is consumed
-            const i32 *rows = P.ks_a3 + ((long)((j0 * 8 + s + 1)) * 3) * P.n;
+        for (int d0 = 0; d0 < 4; d0++)
 #pragma unroll
-            for (int h = 0; h < 3; h++) {
-                pa[h] = v0 ? (u32)rows[h * P.n + c0] : 0u;
-                pb[h] = v1 ? (u32)rows[h * P.n + c1] : 0u;
+            for (int d1 = 0; d1 < 4; d1++) {
+                if (d0 == 0 && d1 == 0) continue;
+                const u32 x0 = (d0 ? pa[d0 - 1] : 0u) + (d1 ? pa[2 + d1] : 0u);
+                const u32 x1 = (d0 ? pb[d0 - 1] : 0u) + (d1 ? pb[2 + d1] : 0u);
+                stage[(4 * d0 + d1) * (KS_ROW_WORDS / 2)] = ((u64)x1 << 32) | x0;
             }
-        }
-        if (k == 0) {
-            // source coefficients of this tile's bits for input coefficient j: lane t of every wave holds
-            // bit t's value (one load per j, issued one j ahead); the wave-uniform copies come out of it
-            // with constant-lane v_readlane.  (32 separately addressed uniform loads would need 64
-            // SGPRs of row pointers and push the kernel into SGPR spilling.)
+        if (s + 1 < steps) load_rows(s + 1);
+        if (kp == 0) {
 #pragma unroll
-            for (int t = 0; t < KS_TILE_BITS; t++)
-                aj[t] = KS_READLANE(aj_lane, t) + (1u << 15);   // + prec_offset, lwe_cpu.py:70
-            if (s + 8 < steps) aj_lane = load_aj(j + 1);
+            for (int t = 0; t < TILE; t++) aj[t] = KS_READLANE(aj_lane, t) + (1u << 15);
+            if (s + 4 < steps) aj_lane = load_aj(j + 1);
         }
-        __syncthreads();   // stage (s & 1) is complete; stage ((s + 1) & 1) is free again
-        const int sh = 30 - 2 * k;
-        const u64 *stage64 = (const u64 *)stage + tid;
+        __syncthreads();
+        const int sh = 28 - 4 * kp;
 #pragma unroll
-        for (int t = 0; t < KS_TILE_BITS; t++) {
-            const u32 dg = (aj[t] >> sh) & 3u;               // lwe_cpu.py:76
-            const u64 v = stage64[dg * (KS_ROW_WORDS / 2)];   // both columns of the selected row
+        for (int t = 0; t < TILE; t++) {
+            const u32 dd = (aj[t] >> sh) & 15u;          // 4 d0 + d1, lwe_cpu.py:76
+            const u64 v = stage[dd * (KS_ROW_WORDS / 2)];
             acc0[t] -= (u32)v;
             acc1[t] -= (u32)(v >> 32);
         }
     }
 #pragma unroll
-    for (int t = 0; t < KS_TILE_BITS; t++) {
+    for (int t = 0; t < TILE; t++) {
         if (t < nb) {
             if (v0) atomicAdd(&P.acc[(bit0 + t) * P.n + c0], acc0[t]);
             if (v1) atomicAdd(&P.acc[(bit0 + t) * P.n + c1], acc1[t]);
@@ -745,6 +741,8 @@ hipError_t kernels_init_device()
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(2));
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_keyswitch_a, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KS_LDS_BYTES);
+    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap_team, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAM_LDS_BYTES);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_blind_rotate_accum<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(1));
@@ -908,7 +906,7 @@ hipError_t launch_keyswitch(const KsLaunch &P, const KsFinal &F, hipStream_t str
     hipError_t e = hipMemsetAsync(P.acc, 0, (size_t)P.nbits * P.n * sizeof(u32), stream);
     if (e != hipSuccess) return e;
     const dim3 grid(blocks_for(P.nbits, KS_TILE_BITS), P.input_size / P.j_per_block);
-    hipLaunchKernelGGL(k_keyswitch_a, grid, dim3(KS_BLOCK_THREADS), 0, stream, P);
+    hipLaunchKernelGGL(k_keyswitch_a, grid, dim3(KS_BLOCK_THREADS), KS_LDS_BYTES, stream, P);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_keyswitch_finalize, dim3((unsigned)P.nbits), dim3(256), 0, stream, F);
