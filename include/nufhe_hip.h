@@ -179,8 +179,8 @@ int nufhe_blind_rotate(nufhe_ctx *ctx, nufhe_cloudkey *key, int32_t *d_accum,
 int nufhe_tlwe_encrypt_zero(nufhe_ctx *ctx, int32_t *d_result_a, const int32_t *d_key,
                             const int32_t *d_noises1, const int32_t *d_noises2, long batch, int mask_size);
 
-/* Batch-size switch of the NTT k=1 bootstrap: a bootstrap of up to `bits` ciphertext bits runs the
- * small-batch kernel (4 wavefronts share a bit; ~2.7x shorter latency, one bit per CU at a time),
+/* Batch-size switch of the k=1 bootstrap: a bootstrap of up to `bits` ciphertext bits (FFT: bits/2) runs the
+ * small-batch kernel (4 wavefronts share a bit; NTT ~2.7x, FFT ~1.4x shorter latency, one bit per CU at a time),
  * larger batches the throughput kernel (one wavefront per bit).  bits < 0 restores the default
  * (2 x the CU count); 0 disables the small-batch kernel.  Results are bit-identical either way.
  * No reference counterpart (the reference always splits a bit over 512+ threads, blind_rotate.py:89-187). */

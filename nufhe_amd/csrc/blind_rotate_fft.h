@@ -156,3 +156,110 @@ FF_FN void brf_blind_rotate(u32 (&acc)[2][16], const cplx *bk, int n, u32 barb, 
         brf_step(acc, a, bk + (long)i * BKF_ROW_ELEMS, lds, L);
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// Team variant of the FFT path (small batches): four wavefronts share one bit exactly as in
+// blind_rotate.h (brt_*): wave w = 2 m + d transforms digit d of polynomial m and multiplies it with
+// BK_row[m][d][0..1]; the partial sums meet in LDS; waves 0/1 add them in the fixed order w = 0..3,
+// transform back, round and update the shared accumulator.  The summation order differs from the
+// one-wave kernel (fp64 addition is not associative), which is covered by the path's stated
+// tolerance; on every tested input the rounded results are identical.
+// ------------------------------------------------------------------------------------------
+#define BRFT_PART_ELEMS (BRT_WAVES * 2 * BKF_POLY_ELEMS)   /* complex: partial sums [wave][mo][reg][lane] */
+
+struct BrFftTeamLds {
+    cplx *xbuf;          // this wave's exchange buffer (FFT_XBUF_ELEMS complex)
+    i32 *acc;            // [2][1024] accumulator shared by the team
+    uint16_t *bara;      // [BR_MAX_LWE]
+    cplx *part;          // [BRFT_PART_ELEMS]
+    const cplx *tw1;
+    const cplx *tw2;
+};
+
+template <class TeamSync>
+FF_FN void brft_step(u32 a, const cplx *row, const BrFftTeamLds &lds, const FftLane &L, int w, TeamSync &&team_sync)
+{
+    const int lane = L.lane;
+    const int m = w >> 1;
+    const int sh = (w & 1) ? 12 : 22;      // digit d = w & 1
+    double dg[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const u32 j = (u32)(lane + 64 * r);
+        const u32 t = (j - a) & 2047u;
+        const u32 v = (u32)lds.acc[m * 1024 + (t & 1023u)];
+        const u32 T = ((t & 1024u) ? 0u - v : v) - (u32)lds.acc[m * 1024 + j];
+        dg[r] = (double)((((i32)(T + TGSW_OFFSET) >> sh) & 1023) - 512);
+    }
+    cplx x[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) x[r] = cplx{dg[r], -dg[r + 8]};                // a_j - i a_{j+512}
+    fft_forward(x, lds.xbuf, lds.tw1, lds.tw2, L);
+    const cplx *poly = row + (long)w * 2 * BKF_POLY_ELEMS + lane;
+#pragma unroll
+    for (int mo = 0; mo < 2; mo++)
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const cplx k = poly[mo * BKF_POLY_ELEMS + r * 64];
+            cplx p;
+            p.re = x[r].re * k.re - x[r].im * k.im;
+            p.im = x[r].re * k.im + x[r].im * k.re;
+            lds.part[((w * 2 + mo) * 8 + r) * 64 + lane] = p;
+        }
+    team_sync();
+    if (w < 2) {
+        cplx sum[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            cplx acc = lds.part[((0 * 2 + w) * 8 + r) * 64 + lane];
+#pragma unroll
+            for (int src = 1; src < BRT_WAVES; src++) {
+                const cplx p = lds.part[((src * 2 + w) * 8 + r) * 64 + lane];
+                acc.re += p.re;
+                acc.im += p.im;
+            }
+            sum[r] = acc;
+        }
+        fft_inverse(sum, lds.xbuf, lds.tw1, lds.tw2, L);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            lds.acc[w * 1024 + lane + 64 * r] += (i32)fft_round_to_u32(sum[r].re);
+            lds.acc[w * 1024 + lane + 64 * (r + 8)] += (i32)fft_round_to_u32(-sum[r].im);
+        }
+    }
+    team_sync();
+}
+
+template <class TeamSync>
+FF_FN void brft_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSource &s1, i32 c0, long bit,
+                          const cplx *bk, int n, i32 mu, const BrFftTeamLds &lds, const FftLane &L, int w,
+                          TeamSync &&team_sync)
+{
+    const int tid = 64 * w + L.lane;
+    for (int i = tid; i < n; i += 64 * BRT_WAVES) {
+        u32 v = 0;
+        if (s0.p) v += (u32)s0.p * (u32)s0.a[bit * s0.a_stride + i];
+        if (s1.p) v += (u32)s1.p * (u32)s1.a[bit * s1.a_stride + i];
+        lds.bara[i] = (uint16_t)br_modswitch(v);
+    }
+    u32 vb = (u32)c0;
+    if (s0.p) vb += (u32)s0.p * (u32)s0.b[bit * s0.b_stride];
+    if (s1.p) vb += (u32)s1.p * (u32)s1.b[bit * s1.b_stride];
+    const u32 barb = br_modswitch(vb);
+    for (int j = tid; j < 1024; j += 64 * BRT_WAVES) {
+        const u32 t = ((u32)j + barb) & 2047u;
+        lds.acc[j] = 0;
+        lds.acc[1024 + j] = (t < 1024u) ? mu : (i32)(0u - (u32)mu);
+    }
+    team_sync();
+    for (int i = 0; i < n; i++) {
+        const u32 a = WAVE_UNIFORM((u32)lds.bara[i]);
+        if (a == 0) continue;
+        brft_step(a, bk + (long)i * BKF_ROW_ELEMS, lds, L, w, team_sync);
+    }
+    for (int j = tid; j < 1024; j += 64 * BRT_WAVES) {
+        const u32 v = (u32)lds.acc[j];
+        out_a[(1024 - j) & 1023] = (i32)(j == 0 ? v : 0u - v);
+    }
+    if (tid == 0) *out_b = lds.acc[1024];
+}

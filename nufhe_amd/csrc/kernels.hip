@@ -198,6 +198,30 @@ __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_bootstrap_fft(BrLaunch 
     br_extract<1>(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, acc, lane);
 }
 
+// Small-batch FFT variant: 4 waves per bit (blind_rotate_fft.h, brft_*).
+// LDS: tables 9 KiB | ACC 8 KiB | bara 1 KiB | partial sums 64 KiB | 4 exchange buffers
+#define TEAMF_LDS_BYTES (FTABLE_LDS_BYTES + 2 * 1024 * 4 + WAVE_BARA_BYTES + BRFT_PART_ELEMS * 16 + BRT_WAVES * WAVE_FXBUF_BYTES)
+__global__ __launch_bounds__(64 * BRT_WAVES, 1) void k_bootstrap_fft_team(BrLaunch P)
+{
+    load_ftables((const cplx *)P.tw_a, (const cplx *)P.tw_b);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long gbit = blockIdx.x;
+    const int job = gbit >= P.bits_per_job ? 1 : 0;
+    const long bit = gbit - (job ? P.bits_per_job : 0);
+    unsigned char *base = g_smem + FTABLE_LDS_BYTES;
+    BrFftTeamLds lds;
+    lds.acc = (i32 *)base;
+    lds.bara = (uint16_t *)(base + 2 * 1024 * 4);
+    lds.part = (cplx *)(base + 2 * 1024 * 4 + WAVE_BARA_BYTES);
+    lds.xbuf = (cplx *)(base + 2 * 1024 * 4 + WAVE_BARA_BYTES + BRFT_PART_ELEMS * 16 + wave * WAVE_FXBUF_BYTES);
+    lds.tw1 = (const cplx *)g_smem;
+    lds.tw2 = (const cplx *)g_smem + FFT_TW1_ELEMS;
+    const FftLane L = fft_lane_init(lane);
+    brft_bootstrap(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, P.job[job].s0, P.job[job].s1,
+                   P.job[job].c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, WAVE_UNIFORM(wave),
+                   [] { __syncthreads(); });
+}
+
 __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_blind_rotate_accum_fft(
     i32 *__restrict__ accum, const cplx *__restrict__ bk, const i32 *__restrict__ bara, long bara_stride,
     int row0, int n_rows, int external_mul_only, long batch, const cplx *__restrict__ tw1,
@@ -743,6 +767,8 @@ hipError_t kernels_init_device()
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_keyswitch_a, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KS_LDS_BYTES);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_bootstrap_fft_team, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAMF_LDS_BYTES);
+    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap_team, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAM_LDS_BYTES);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_blind_rotate_accum<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(1));
@@ -776,6 +802,10 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, lon
     } else if (transform == 0 && mask_size == 2) {
         const int w = br_pick_waves(P.nbits_total, BR_WAVES_K(2));
         hipLaunchKernelGGL(k_bootstrap<2>, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), br_lds_bytes(2, w), stream, P);
+    } else if (transform == 1 && mask_size == 1 && P.nbits_total <= team_max_bits / 2) {
+        // small batch, FFT: 4 waves per bit (one bit per CU; the wave-per-bit kernel is ahead again
+        // once the batch needs a second round of teams)
+        hipLaunchKernelGGL(k_bootstrap_fft_team, dim3((unsigned)P.nbits_total), dim3(64 * BRT_WAVES), TEAMF_LDS_BYTES, stream, P);
     } else if (transform == 1 && mask_size == 1) {
         const int w = br_pick_waves(P.nbits_total, BR_WAVES_PER_BLOCK);
         hipLaunchKernelGGL(k_bootstrap_fft, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), brf_lds_bytes(w), stream, P);

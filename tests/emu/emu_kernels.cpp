@@ -183,6 +183,23 @@ void emu_bkf_from_reference(double *out, const double *in, long polys)
             }
 }
 
+// 4-wave team variant of the FFT body
+void emu_bootstrap_bit_fft_team(i32 *out_a, i32 *out_b, const double *bk_internal, int n,
+                                const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,
+                                i32 c0, i32 mu)
+{
+    ftables();
+    std::vector<cplx> xbuf(BRT_WAVES * FFT_XBUF_ELEMS), part(BRFT_PART_ELEMS);
+    std::vector<i32> accbuf(2 * 1024);
+    std::vector<uint16_t> bara(BR_MAX_LWE);
+    BrSource s0{a0, b0, 0, 0, p0}, s1{a1, b1, 0, 0, p1};
+    emu_run_team(BRT_WAVES, [&](int w, int lane) {
+        BrFftTeamLds lds{xbuf.data() + w * FFT_XBUF_ELEMS, accbuf.data(), bara.data(), part.data(), g_ftw1, g_ftw2};
+        FftLane L = fft_lane_init(lane);
+        brft_bootstrap(out_a, out_b, s0, s1, c0, 0, (const cplx *)bk_internal, n, mu, lds, L, w, [] { emu_team_sync(); });
+    });
+}
+
 void emu_bootstrap_bit_fft(i32 *out_a, i32 *out_b, const double *bk_internal, int n,
                            const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,
                            i32 c0, i32 mu)

@@ -145,6 +145,10 @@ def test_bootstrap_wave_body_fft_full_key(orc, oracle_keys):
     bkf = of.bk_from_coeffs(of.tgsw_coeffs_from_reference_bk(ck.bk))
     ga, gb = emu.bootstrap_bit_fft(emu.bkf_from_reference(bkf), 500, (c1[0][0], c1[1]), -1, (c2[0][0], c2[1]), -1, MU, MU)
     assert (ga == ea[0]).all() and gb == eb[0]
+    # the 4-wave team variant (different fp64 summation order): still equal to the exact result
+    ga, gb = emu.bootstrap_bit_fft(emu.bkf_from_reference(bkf), 500, (c1[0][0], c1[1]), -1, (c2[0][0], c2[1]), -1, MU, MU,
+                                   team=True)
+    assert (ga == ea[0]).all() and gb == eb[0]
 
 
 def test_bootstrap_wave_body_mask_size_2(orc):

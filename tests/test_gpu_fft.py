@@ -169,3 +169,33 @@ def test_config5_fft_context_end_to_end_4096(thr):
     # serialization round trip of an FFT key
     cloud3 = ctx.load_cloud_key(cloud.dumps())
     assert cloud3 == cloud
+
+
+def test_fft_small_batch_team_kernel(fft_env, thr, H, orc):
+    """The 4-waves-per-bit FFT kernel (batches <= CUs bits) vs the wave-per-bit FFT kernel and vs the
+    exact (NTT) oracle: within the path's tolerance; observed: identical words."""
+    from nufhe_amd import _lib
+    vm = fft_env['vm']; ck = fft_env['ck']; lwe_key = fft_env['lwe_key']
+    rng = orc.DeterministicRNG(31337)
+    B = 70
+    ms = [rng.uniform_bool((B,)).astype(bool) for _ in range(3)]
+    cs = [orc.encrypt(rng, lwe_key, m) for m in ms]
+    ds = [H.ciphertext_from_arrays(thr, c, fft_env['params']) for c in cs]
+    exp = {'nand': orc.gate('gate_nand', ck, cs[0], cs[1]), 'mux': orc.gate_mux(ck, cs[0], cs[1], cs[2])}
+    got = {}
+    try:
+        for limit in (0, -1):                       # 0: wave-per-bit kernel, -1: default switch (team kernel here)
+            _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, limit)
+            got[limit] = {'nand': H.ct_arrays(vm.gate_nand(ds[0], ds[1])), 'mux': H.ct_arrays(vm.gate_mux(ds[0], ds[1], ds[2]))}
+    finally:
+        _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, -1)
+    for name in ('nand', 'mux'):
+        for limit in (0, -1):
+            ra, rb, rcv = got[limit][name]
+            da = (ra.astype(numpy.int64) - exp[name][0].astype(numpy.int64) + 2**31) % 2**32 - 2**31
+            db = (rb.astype(numpy.int64) - exp[name][1].astype(numpy.int64) + 2**31) % 2**32 - 2**31
+            assert numpy.abs(da).max() <= 2**16 and numpy.abs(db).max() <= 2**16, (name, limit)
+            assert (rcv == exp[name][2]).all()
+        same = all((x == y).all() for x, y in zip(got[0][name], got[-1][name]))
+        print("FFT %s: team kernel == wave kernel: %s; words differing from the exact path: %d" % (
+            name, same, int((got[-1][name][0] != exp[name][0]).sum())))
