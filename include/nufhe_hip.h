@@ -160,6 +160,12 @@ int nufhe_fft_inverse_i32(nufhe_ctx *ctx, int32_t *d_out, const double *d_in, lo
 int nufhe_ff_op(nufhe_ctx *ctx, uint64_t *d_out, const uint64_t *d_a, const uint64_t *d_b,
                 const uint64_t *d_c, const uint64_t *d_d, const uint64_t *d_e, int op, int shift,
                 long count);
+/* The same field in the redundant 24-bit-limb form used inside the blind-rotation transforms
+ * (csrc/ff24.h; replaces the add/sub/lsh family of transform/arithmetic.mako:78-161,465-1045 on the
+ * hot path).  Arrays are uint32 [count][4] (limbs, or 64-bit words split into 32-bit halves); the op
+ * codes are listed in csrc/l4_hook.h.  d_b / d_c may be NULL for the ops that do not read them. */
+int nufhe_l4_op(nufhe_ctx *ctx, uint32_t *d_out, uint32_t *d_out2, const uint32_t *d_a,
+                const uint32_t *d_b, const uint32_t *d_c, int op, int shift, long count);
 /* Negacyclic product mod 2^32 of int32 polynomials through the NTT: out[b] = x[b] * y[b % y_batch] */
 int nufhe_poly_mul_i32(nufhe_ctx *ctx, int32_t *d_out, const int32_t *d_x, const int32_t *d_y,
                        long batch, long y_batch);

@@ -48,6 +48,7 @@ PROTOTYPES = {
     "nufhe_cloudkey_create": [_vp, _int, _int, _int, _pp],
     "nufhe_ctx_set_team_max_bits": [_vp, _long],
     "nufhe_ff_op": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _long],
+    "nufhe_l4_op": [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _long],
     "nufhe_cloudkey_destroy": [_vp],
     "nufhe_bk_upload_reference": [_vp, _vp],
     "nufhe_bk_download_reference": [_vp, _vp],

@@ -642,6 +642,17 @@ int nufhe_ff_op(nufhe_ctx *ctx, uint64_t *d_out, const uint64_t *d_a, const uint
     return NUFHE_OK;
 }
 
+int nufhe_l4_op(nufhe_ctx *ctx, uint32_t *d_out, uint32_t *d_out2, const uint32_t *d_a, const uint32_t *d_b,
+                const uint32_t *d_c, int op, int shift, long count)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (op < 0 || op > 9 || shift < 0 || shift >= 192) return fail(NUFHE_EINVAL, "bad limb op %d / shift %d", op, shift);
+    if (!d_out || !d_out2 || !d_a) return fail(NUFHE_EINVAL, "null operand");
+    HIP_TRY(launch_l4_op(d_out, d_out2, d_a, d_b, d_c, op, shift, count, ctx->stream));
+    return NUFHE_OK;
+}
+
 int nufhe_poly_mul_i32(nufhe_ctx *ctx, int32_t *d_out, const int32_t *d_x, const int32_t *d_y, long batch, long y_batch)
 {
     int rc = check_ctx(ctx);

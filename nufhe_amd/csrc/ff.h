@@ -13,8 +13,10 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define FF_FN __host__ __device__ __forceinline__
+#define FF_HD __host__ __device__
 #else
 #define FF_FN static inline __attribute__((always_inline))
+#define FF_HD
 #endif
 
 typedef uint64_t u64;

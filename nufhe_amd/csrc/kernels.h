@@ -71,6 +71,8 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, lon
 int kernels_num_cus();
 hipError_t launch_ff_op(u64 *out, const u64 *a, const u64 *b, const u64 *c, const u64 *d, const u64 *e, int op,
                         int shift, long count, hipStream_t stream);
+hipError_t launch_l4_op(u32 *out, u32 *out2, const u32 *a, const u32 *b, const u32 *c, int op, int shift, long count,
+                        hipStream_t stream);
 hipError_t launch_blind_rotate_accum(i32 *accum, const void *bk, const i32 *bara, long bara_stride, int row0,
                                      int n_rows, int external_mul_only, long batch, const void *tw_a,
                                      const void *tw_b, int transform, int mask_size, hipStream_t stream);

@@ -7,6 +7,7 @@
 #include "ff.h"
 #include "kernels.h"
 #include "ntt1024.h"
+#include "l4_hook.h"
 
 // ------------------------------------------------------------------------------------------
 // LDS carving
@@ -727,6 +728,15 @@ __global__ void k_ff_op(u64 *__restrict__ out, const u64 *__restrict__ a, const 
     out[i] = r;
 }
 
+// Test hook for the redundant-limb arithmetic (ff24.h, ntt1024_l4.h): csrc/l4_hook.h, arrays u32[count][4]
+__global__ void k_l4_op(u32 *__restrict__ out, u32 *__restrict__ out2, const u32 *__restrict__ a,
+                        const u32 *__restrict__ b, const u32 *__restrict__ c, int op, int shift, long count)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    l4_hook(out + 4 * i, out2 + 4 * i, a + 4 * i, b ? b + 4 * i : nullptr, c ? c + 4 * i : nullptr, op, shift);
+}
+
 // ------------------------------------------------------------------------------------------
 // Host launchers
 // ------------------------------------------------------------------------------------------
@@ -787,6 +797,14 @@ hipError_t launch_ff_op(u64 *out, const u64 *a, const u64 *b, const u64 *c, cons
 {
     if (count == 0) return hipSuccess;
     hipLaunchKernelGGL(k_ff_op, dim3(blocks_for(count, 256)), dim3(256), 0, stream, out, a, b, c, d, e, op, shift, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_l4_op(u32 *out, u32 *out2, const u32 *a, const u32 *b, const u32 *c, int op, int shift, long count,
+                        hipStream_t stream)
+{
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_l4_op, dim3(blocks_for(count, 64)), dim3(64), 0, stream, out, out2, a, b, c, op, shift, count);
     return hipGetLastError();
 }
 

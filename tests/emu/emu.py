@@ -60,6 +60,33 @@ def ntt_inverse(x):
     return r
 
 
+def l4_op(op, a, b=None, c=None, shift=0):
+    """ff24.h primitives via the shared dispatcher (csrc/l4_hook.h); arrays uint32 [n, 4].
+    Returns (out, out2)."""
+    a = numpy.ascontiguousarray(a, numpy.uint32)
+    n = a.shape[0]
+    out = numpy.zeros((n, 4), numpy.uint32); out2 = numpy.zeros((n, 4), numpy.uint32)
+    b = None if b is None else numpy.ascontiguousarray(b, numpy.uint32)
+    c = None if c is None else numpy.ascontiguousarray(c, numpy.uint32)
+    lib().emu_l4_op(_p(out, c_u32p), _p(out2, c_u32p), _p(a, c_u32p), None if b is None else _p(b, c_u32p),
+                    None if c is None else _p(c, c_u32p), ctypes.c_int(op), ctypes.c_int(shift), ctypes.c_long(n))
+    return out, out2
+
+
+def ntt_forward_small_l4(d):
+    d = numpy.ascontiguousarray(d, numpy.int32)
+    r = numpy.empty(1024, numpy.uint64)
+    lib().emu_ntt_forward_small_l4(_p(r, c_u64p), _p(d, c_i32p))
+    return r
+
+
+def ntt_inverse_l4_i32(x):
+    x = numpy.ascontiguousarray(x, numpy.uint64)
+    r = numpy.empty(1024, numpy.uint32)
+    lib().emu_ntt_inverse_l4_i32(_p(r, c_u32p), _p(x, c_u64p))
+    return r
+
+
 def bk_from_reference(bk):
     bk = numpy.ascontiguousarray(bk, numpy.uint64)
     out = numpy.empty_like(bk)

@@ -9,6 +9,9 @@
 #include "../../nufhe_amd/csrc/ntt1024.h"
 #include "../../nufhe_amd/csrc/ntt_tables.h"
 #include "../../nufhe_amd/csrc/blind_rotate.h"
+#include "../../nufhe_amd/csrc/ff24.h"
+#include "../../nufhe_amd/csrc/ntt1024_l4.h"
+#include "../../nufhe_amd/csrc/l4_hook.h"
 #include "../../nufhe_amd/csrc/fft512.h"
 #include "../../nufhe_amd/csrc/blind_rotate_fft.h"
 #include "emu_wave.h"
@@ -70,6 +73,43 @@ void emu_ntt_inverse(u64 *out, const u64 *in)
     });
 }
 
+
+// limb-form (ff24.h) primitives through the shared test-hook dispatcher; arrays are u32[n][4]
+void emu_l4_op(u32 *out, u32 *out2, const u32 *a, const u32 *b, const u32 *c, int op, int shift, long n)
+{
+    for (long i = 0; i < n; i++)
+        l4_hook(out + 4 * i, out2 + 4 * i, a + 4 * i, b ? b + 4 * i : nullptr, c ? c + 4 * i : nullptr, op, shift);
+}
+
+// limb-form forward transform of a digit polynomial; out: 64-bit representatives, natural frequency order
+void emu_ntt_forward_small_l4(u64 *out, const i32 *in)
+{
+    tables();
+    std::vector<u64> xbuf(NTT_XBUF_ELEMS);
+    emu_run_wave([&](int lane) {
+        NttLane L = ntt_lane_init(lane);
+        i32 d[16];
+        u64 x[16];
+        for (int r = 0; r < 16; r++) d[r] = in[ntt_coef_index(lane, r)];
+        ntt_forward_small_l4(x, d, xbuf.data(), g_tw1f, L);
+        for (int r = 0; r < 16; r++) out[ntt_freq_index(lane, r)] = x[r];
+    });
+}
+
+// limb-form inverse transform down to coefficients mod 2^32 (sign convention undone here)
+void emu_ntt_inverse_l4_i32(u32 *out, const u64 *in)
+{
+    tables();
+    std::vector<u64> xbuf(NTT_XBUF_ELEMS);
+    emu_run_wave([&](int lane) {
+        NttLane L = ntt_lane_init(lane);
+        u64 x[16];
+        u32 c[16];
+        for (int r = 0; r < 16; r++) x[r] = in[ntt_freq_index(lane, r)];
+        ntt_inverse_l4_i32(c, x, xbuf.data(), g_tw1i, L);
+        for (int r = 0; r < 16; r++) out[ntt_coef_index(lane, r)] = r == 0 ? c[r] : 0u - c[r];
+    });
+}
 
 // reference-format key polynomials (natural-order NTT, Montgomery) -> wave layout, plain
 void emu_bk_from_reference(u64 *out, const u64 *in, long polys)

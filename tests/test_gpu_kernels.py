@@ -299,3 +299,24 @@ def test_ff_primitives_on_device_vs_bigint(thr, H):
     for v, g in zip(vals[:32], got[len(ints):]):
         signed = v - P if v > P // 2 else v
         assert (g >> 32) == (signed & 0xFFFFFFFF)
+
+
+def test_l4_primitives_on_device_vs_bigint(thr, H):
+    """The redundant 24-bit-limb arithmetic of the blind-rotation transforms (csrc/ff24.h) as compiled
+    for gfx950 (v_perm_b32 byte selectors, the carry-out of v_mad_u64_u32 in l4_to_u64, per-lane
+    twiddles) against Python integers: the same checks tests/test_emu_l4.py applies to the host build."""
+    import l4_checks
+
+    def run(op, a, b=None, c=None, shift=0):
+        a = numpy.ascontiguousarray(a, numpy.uint32)
+        n = a.shape[0]
+        d_a = H.dev(thr, a.view(numpy.int32))
+        d_b = None if b is None else H.dev(thr, numpy.ascontiguousarray(b, numpy.uint32).view(numpy.int32))
+        d_c = None if c is None else H.dev(thr, numpy.ascontiguousarray(c, numpy.uint32).view(numpy.int32))
+        out = thr.array((n, 4), numpy.int32); out2 = thr.array((n, 4), numpy.int32)
+        out2.zero_()
+        call("nufhe_l4_op", thr.handle, ptr(out), ptr(out2), ptr(d_a), None if d_b is None else ptr(d_b),
+             None if d_c is None else ptr(d_c), op, shift, n)
+        return H.host(out).view(numpy.uint32), H.host(out2).view(numpy.uint32)
+
+    l4_checks.check_all(run, n=1500)
