@@ -23,6 +23,7 @@
 #include <type_traits>
 #include "ff.h"
 #include "ntt1024.h"
+#include "ntt1024_l4.h"
 
 #define BR_N 1024
 #define BR_MAX_LWE 512                    /* capacity of the per-wave bara buffer (u16 each) */
@@ -144,65 +145,124 @@ FF_FN void br_mac2(u64 (&sum)[K + 1][16], const u64 (&x0)[16], const u64 (&x1)[1
     }
 }
 
+// Last half of the paired multiply-accumulate for ONE output polynomial: out = prev + x0 (*) BK[m][0][mo]
+// + x1 (*) BK[m][1][mo], the 130-bit sums split straight into limbs (l4_dot2) -- the input format of
+// the inverse transform, so the 128 -> 64-bit modular reduction is skipped.  poly = BK_row[m][0][mo].
+template <int K>
+FF_FN void br_mac2_l4(L4 (&out)[16], const u64 (&prev)[16], const u64 (&x0)[16], const u64 (&x1)[16],
+                      const u64 *poly, int lane)
+{
+    const u64 *p = poly + lane * 2;
+    const u64 *pd = p + (K + 1) * BK_POLY_ELEMS;
+    u64 k00 = p[0], k01 = p[1], k10 = pd[0], k11 = pd[1];
+#pragma unroll
+    for (int h = 0; h < 8; h++) {
+        u64 n00 = 0, n01 = 0, n10 = 0, n11 = 0;
+        if (h + 1 < 8) {
+            const int off = (h + 1) * 128;
+            n00 = p[off];
+            n01 = p[off + 1];
+            n10 = pd[off];
+            n11 = pd[off + 1];
+            BR_ISSUE_FENCE();
+        }
+        l4_dot2<true>(out[2 * h], x0[2 * h], k00, x1[2 * h], k10, prev[2 * h]);
+        l4_dot2<true>(out[2 * h + 1], x0[2 * h + 1], k01, x1[2 * h + 1], k11, prev[2 * h + 1]);
+        k00 = n00; k01 = n01; k10 = n10; k11 = n11;
+    }
+}
+
 // External product of one TGSW row with a TLWE sample given coefficient-wise by `tsrc`:
-//   sum[mo] (field elements of the coefficient-domain result, coefficient lane + 64 r; for r >= 1
-//   NEGATED, see br_coeff_to_u32) = sum_{m, d} digit_d(T_m) (*) BK_row[m][d][mo]   (tgsw_cpu.py:82-106)
-// tsrc(m, T) must fill T[r] = coefficient lane + 64 r of polynomial m (as uint32 torus values).
-// K = 1: everything unrolled (tsrc may index registers with m).  K > 1: the loop over m stays
-// rolled -- two forward transforms + the paired multiply-accumulate of code -- so tsrc gets a
-// run-time m and must read its polynomial from memory (the LDS mirror), never from a register array.
-template <int K, class TSource>
-FF_FN void br_external_product(u64 (&sum)[K + 1][16], TSource &&tsrc, const u64 *row, const BrLds &lds,
-                               const NttLane &L)
+//   emit(mo, r, v) receives v = coefficient lane + 64 r (mod 2^32) of
+//   sum_{m, d} digit_d(T_m) (*) BK_row[m][d][mo]   (tgsw_cpu.py:82-106), one output polynomial after
+//   the other, as soon as its inverse transform is done.
+// tsrc(m, T) must fill T[r] = coefficient lane + 64 r of polynomial m (as uint32 torus values); all
+// sources are read before the first emit.
+// The transforms run on redundant 24-bit limbs (ntt1024_l4.h); the digit transforms leave 64-bit
+// representatives for the key products.
+// K = 1: everything unrolled (tsrc may index registers with m); the products of the second input
+// polynomial are added to the reduced sums of the first and split straight into limbs for the inverse
+// transforms.  K > 1: the loop over m stays rolled -- two forward transforms + the paired
+// multiply-accumulate of code -- so tsrc gets a run-time m and must read its polynomial from memory
+// (the LDS mirror), never from a register array.
+template <int K, class TSource, class Emit>
+FF_FN void br_external_product(TSource &&tsrc, Emit &&emit, const u64 *row, const BrLds &lds, const NttLane &L)
 {
     const int lane = L.lane;
-    if constexpr (K == 1) {
-        auto half = [&](auto first, int m) {
+    auto digits_forward = [&](int m, u64(&x0)[16], u64(&x1)[16]) {
+        // the source polynomial is fetched once per digit (32 LDS reads) instead of being held in 16
+        // registers across a transform: the kernel sits at the 256-VGPR limit of 2 waves per SIMD
+        i32 dg[16];
+        {
             u32 T[16];
             tsrc(m, T);
-            u64 x0[16], x1[16];
-            i32 dg[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) dg[r] = br_digit<0>(T[r]);
-            ntt_forward_small(x0, dg, lds.xbuf, lds.tw1f, L);
+        }
+        ntt_forward_small_l4(x0, dg, lds.xbuf, lds.tw1f, L);
+        {
+            u32 T[16];
+            tsrc(m, T);
+            BR_ISSUE_FENCE();
 #pragma unroll
             for (int r = 0; r < 16; r++) dg[r] = br_digit<1>(T[r]);
-            ntt_forward_small(x1, dg, lds.xbuf, lds.tw1f, L);
-            br_mac2<1, decltype(first)::value>(sum, x0, x1, row + m * 4 * BK_POLY_ELEMS, lane);
-        };
-        half(std::true_type{}, 0);
-        half(std::false_type{}, 1);
+        }
+        ntt_forward_small_l4(x1, dg, lds.xbuf, lds.tw1f, L);
+    };
+    auto finish = [&](int mo, u32(&c)[16]) {
+        // coefficients j2 >= 1 come back negated (ntt_inverse_l4_core)
+#pragma unroll
+        for (int r = 0; r < 16; r++) emit(mo, r, r == 0 ? c[r] : 0u - c[r]);
+    };
+    if constexpr (K == 1) {
+        u64 sum[2][16];
+        {
+            u64 x0[16], x1[16];
+            digits_forward(0, x0, x1);
+            br_mac2<1, true>(sum, x0, x1, row, lane);
+        }
+        u64 x0[16], x1[16];
+        digits_forward(1, x0, x1);
+        {
+            L4 s[16];
+            u32 c[16];
+            br_mac2_l4<1>(s, sum[0], x0, x1, row + 4 * BK_POLY_ELEMS, lane);
+            ntt_inverse_l4_core(c, s, lds.xbuf, lds.tw1i, L);
+            finish(0, c);
+        }
+        {
+            L4 s[16];
+            u32 c[16];
+            br_mac2_l4<1>(s, sum[1], x0, x1, row + 5 * BK_POLY_ELEMS, lane);
+            ntt_inverse_l4_core(c, s, lds.xbuf, lds.tw1i, L);
+            finish(1, c);
+        }
     } else {
+        u64 sum[K + 1][16];
 #pragma unroll
         for (int mo = 0; mo <= K; mo++)
 #pragma unroll
             for (int r = 0; r < 16; r++) sum[mo][r] = 0;
 #pragma unroll 1
         for (int m = 0; m <= K; m++) {
-            u32 T[16];
-            tsrc(m, T);
             u64 x0[16], x1[16];
-            i32 dg[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) dg[r] = br_digit<0>(T[r]);
-            ntt_forward_small(x0, dg, lds.xbuf, lds.tw1f, L);
-#pragma unroll
-            for (int r = 0; r < 16; r++) dg[r] = br_digit<1>(T[r]);
-            ntt_forward_small(x1, dg, lds.xbuf, lds.tw1f, L);
+            digits_forward(m, x0, x1);
             br_mac2<K, false>(sum, x0, x1, row + (long)m * 2 * (K + 1) * BK_POLY_ELEMS, lane);
         }
+        // Explicitly sequenced (not a `#pragma unroll` loop: the three inverse transforms exceed the
+        // unroller's size threshold and a rolled loop would put `sum` into scratch memory).
+        u32 c[16];
+        ntt_inverse_l4_i32(c, sum[0], lds.xbuf, lds.tw1i, L);
+        finish(0, c);
+        ntt_inverse_l4_i32(c, sum[1], lds.xbuf, lds.tw1i, L);
+        finish(1, c);
+        if constexpr (K >= 2) {
+            ntt_inverse_l4_i32(c, sum[2], lds.xbuf, lds.tw1i, L);
+            finish(2, c);
+        }
+        static_assert(K <= 2, "add the further inverse transforms");
     }
-    // NEG_OUT: coefficients j2 >= 1 come back negated (callers use br_coeff_to_u32).  Explicitly
-    // sequenced (not a `#pragma unroll` loop: for K = 2 the three inverse transforms exceed the
-    // unroller's size threshold and a rolled loop would put `sum` into scratch memory).
-    ntt_inverse_t<true>(sum[0], lds.xbuf, lds.tw1i, L);
-    ntt_inverse_t<true>(sum[1], lds.xbuf, lds.tw1i, L);
-    if constexpr (K >= 2) ntt_inverse_t<true>(sum[2], lds.xbuf, lds.tw1i, L);
-    static_assert(K <= 2, "add the further inverse transforms");
 }
-
-// int32 value of coefficient register r of br_external_product's result
-FF_FN u32 br_coeff_to_u32(u64 v, int r) { return r == 0 ? (u32)ff_to_i32(v) : 0u - (u32)ff_to_i32(v); }
 
 // ACC = (0, ..., 0, X^(2N - barb) * mu) (bootstrap.py:176-182): body coefficient j is +mu if
 // (j + barb) mod 2N < N, else -mu.  Fills the registers and the LDS mirror.
@@ -225,16 +285,14 @@ FF_FN void br_init_acc(u32 (&acc)[K + 1][16], u32 barb, i32 mu, const BrLds &lds
 }
 
 // One blind-rotate step with rotation amount a in [0, 2N) (bootstrap.py:96-109):
-// ACC += BK_row (.) ((X^a - 1) ACC).  K = 1: acc registers and the LDS mirror are both updated.
-// K > 1: the accumulator lives in the LDS mirror only during the loop (the registers are needed
-// for the (K+1) x 16 field-element sums); br_blind_rotate reloads acc at the end.
+// ACC += BK_row (.) ((X^a - 1) ACC).  The accumulator lives in the LDS mirror during the loop (the
+// registers are needed by the transforms and the (K+1) x 16 field-element sums); br_blind_rotate loads
+// it into registers at the end.
 template <int K>
-FF_FN void br_step(u32 (&acc)[K + 1][16], u32 a, const u64 *row, const BrLds &lds, const NttLane &L)
+FF_FN void br_step(u32 a, const u64 *row, const BrLds &lds, const NttLane &L)
 {
     const int lane = L.lane;
-    u64 sum[K + 1][16];
     br_external_product<K>(
-        sum,
         [&](int m, u32 (&T)[16]) {
             // T = (X^a - 1) ACC_m  (polynomials_cpu.py:46-58 with minus_one)
 #pragma unroll
@@ -242,24 +300,11 @@ FF_FN void br_step(u32 (&acc)[K + 1][16], u32 a, const u64 *row, const BrLds &ld
                 const u32 j = (u32)(lane + 64 * r);
                 const u32 t = (j - a) & 2047u;
                 const u32 v = (u32)lds.acc[m * 1024 + (t & 1023u)];
-                u32 self;
-                if constexpr (K == 1) self = acc[m][r];
-                else self = (u32)lds.acc[m * 1024 + j];
+                const u32 self = (u32)lds.acc[m * 1024 + j];
                 T[r] = ((t & 1024u) ? 0u - v : v) - self;
             }
         },
-        row, lds, L);
-#pragma unroll
-    for (int mo = 0; mo <= K; mo++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            if constexpr (K == 1) {
-                acc[mo][r] += br_coeff_to_u32(sum[mo][r], r);
-                lds.acc[mo * 1024 + lane + 64 * r] = (i32)acc[mo][r];
-            } else {
-                lds.acc[mo * 1024 + lane + 64 * r] += (i32)br_coeff_to_u32(sum[mo][r], r);
-            }
-        }
+        [&](int mo, int r, u32 v) { lds.acc[mo * 1024 + lane + 64 * r] += (i32)v; }, row, lds, L);
     WAVE_SYNC();
 }
 
@@ -272,14 +317,12 @@ FF_FN void br_blind_rotate(u32 (&acc)[K + 1][16], const u64 *bk, int n, u32 barb
     for (int i = 0; i < n; i++) {
         const u32 a = WAVE_UNIFORM((u32)lds.bara[i]);
         if (a == 0) continue;   // (X^0 - 1) ACC = 0: the external product adds nothing
-        br_step<K>(acc, a, bk + (long)i * BK_ROW_ELEMS_K(K), lds, L);
+        br_step<K>(a, bk + (long)i * BK_ROW_ELEMS_K(K), lds, L);
     }
-    if constexpr (K > 1) {
 #pragma unroll
-        for (int m = 0; m <= K; m++)
+    for (int m = 0; m <= K; m++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[m][r] = (u32)lds.acc[m * 1024 + L.lane + 64 * r];
-    }
+        for (int r = 0; r < 16; r++) acc[m][r] = (u32)lds.acc[m * 1024 + L.lane + 64 * r];
 }
 
 // Sample extraction straight from registers (tlwe_cpu.py:55-58); out_a has K * 1024 entries
@@ -341,7 +384,7 @@ FF_FN void brt_step(u32 a, const u64 *row, const BrTeamLds &lds, const NttLane &
         dg[r] = (((i32)(T + TGSW_OFFSET) >> sh) & 1023) - 512;
     }
     u64 x[16];
-    ntt_forward_small(x, dg, lds.xbuf, lds.tw1f, L);
+    ntt_forward_small_l4(x, dg, lds.xbuf, lds.tw1f, L);
     u64 ps[2][16];
 #pragma unroll
     for (int mo = 0; mo < 2; mo++)
@@ -363,9 +406,10 @@ FF_FN void brt_step(u32 a, const u64 *row, const BrTeamLds &lds, const NttLane &
                 acc = ff_add(acc, lds.part[((src * 2 + w) * 16 + r) * 64 + lane]);
             sum[r] = acc;
         }
-        ntt_inverse_t<true>(sum, lds.xbuf, lds.tw1i, L);
+        u32 c[16];
+        ntt_inverse_l4_i32(c, sum, lds.xbuf, lds.tw1i, L);
 #pragma unroll
-        for (int r = 0; r < 16; r++) lds.acc[w * 1024 + lane + 64 * r] += (i32)br_coeff_to_u32(sum[r], r);
+        for (int r = 0; r < 16; r++) lds.acc[w * 1024 + lane + 64 * r] += (i32)(r == 0 ? c[r] : 0u - c[r]);
     }
     team_sync();
 }

@@ -119,35 +119,27 @@ __global__ __launch_bounds__(64 * BR_WAVES_K(K), K == 1 ? 2 : 1) void k_blind_ro
             lds.acc[m * 1024 + lane + 64 * r] = (i32)acc[m][r];
         }
     WAVE_SYNC();
+    // (the accumulator is read from / updated in the LDS mirror, see blind_rotate.h)
     if (external_mul_only) {
-        u64 sum[K + 1][16];
         br_external_product<K>(
-            sum,
             [&](int m, u32(&T)[16]) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    if constexpr (K == 1) T[r] = acc[m][r];
-                    else T[r] = (u32)lds.acc[m * 1024 + lane + 64 * r];   // run-time m: see blind_rotate.h
-                }
+                for (int r = 0; r < 16; r++) T[r] = (u32)lds.acc[m * 1024 + lane + 64 * r];
             },
+            [&](int mo, int r, u32 v) { lds.acc[mo * 1024 + lane + 64 * r] = (i32)v; },
             bk + (long)row0 * BK_ROW_ELEMS_K(K), lds, L);
-#pragma unroll
-        for (int m = 0; m <= K; m++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[m][r] = br_coeff_to_u32(sum[m][r], r);
     } else {
         for (int i = 0; i < n_rows; i++) {
             const u32 a = WAVE_UNIFORM((u32)bara[bit * bara_stride + i]) & 2047u;
             if (a == 0) continue;
-            br_step<K>(acc, a, bk + (long)(row0 + i) * BK_ROW_ELEMS_K(K), lds, L);
-        }
-        if constexpr (K > 1) {   // the accumulator lived in the LDS mirror during the steps
-#pragma unroll
-            for (int m = 0; m <= K; m++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[m][r] = (u32)lds.acc[m * 1024 + lane + 64 * r];
+            br_step<K>(a, bk + (long)(row0 + i) * BK_ROW_ELEMS_K(K), lds, L);
         }
     }
+    WAVE_SYNC();
+#pragma unroll
+    for (int m = 0; m <= K; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[m][r] = (u32)lds.acc[m * 1024 + lane + 64 * r];
 #pragma unroll
     for (int m = 0; m <= K; m++)
 #pragma unroll

@@ -230,17 +230,15 @@ FF_FN void ntt_forward_small_l4(u64 (&out)[16], const i32 (&d)[16], u64 *xbuf, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// Inverse transform (1/N folded into tw1i) of 64-bit field elements (any representative) in the wave
-// layout, down to the coefficients modulo 2^32 (ntt.mako:402-408): the caller guarantees that the
+// Inverse transform (1/N folded into tw1i) of field elements in the wave layout, given as limbs
+// (w0 in (-2^24, 2^24), w1 in (-2^11, 2^24), w2, w3 in [0, 2^24): what l4_dot2 / l4_from_u64 deliver),
+// down to the coefficients modulo 2^32 (ntt.mako:402-408): the caller guarantees that the
 // true coefficients are integers of magnitude < 2^62 (here: < 2^52).
 //   c[j2] = coefficient lane + 64 j2 for j2 = 0, and MINUS that coefficient for j2 >= 1
 // (the post-twist 2^(-6 j2) = -2^(96 - 6 j2) is applied without its sign, as in ntt_inverse_t<true>).
 // ---------------------------------------------------------------------------------------------
-FF_FN void ntt_inverse_l4_i32(u32 (&c)[16], const u64 (&in)[16], u64 *xbuf, const u64 *tw1i, const NttLane &L)
+FF_FN void ntt_inverse_l4_core(u32 (&c)[16], L4 (&x)[16], u64 *xbuf, const u64 *tw1i, const NttLane &L)
 {
-    L4 x[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) l4_from_u64(x[r], in[r]);
     l4_ntt4<-48>(x[0], x[1], x[2], x[3]);
     l4_ntt4<-48>(x[4], x[5], x[6], x[7]);
     l4_ntt4<-48>(x[8], x[9], x[10], x[11]);
@@ -270,4 +268,13 @@ FF_FN void ntt_inverse_l4_i32(u32 (&c)[16], const u64 (&in)[16], u64 *xbuf, cons
     POST(0); POST(1); POST(2); POST(3); POST(4); POST(5); POST(6); POST(7); POST(8);
     POST(9); POST(10); POST(11); POST(12); POST(13); POST(14); POST(15);
 #undef POST
+}
+
+// the same from 64-bit field elements (any representative)
+FF_FN void ntt_inverse_l4_i32(u32 (&c)[16], const u64 (&in)[16], u64 *xbuf, const u64 *tw1i, const NttLane &L)
+{
+    L4 x[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) l4_from_u64(x[r], in[r]);
+    ntt_inverse_l4_core(c, x, xbuf, tw1i, L);
 }
