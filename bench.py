@@ -7,9 +7,10 @@ bench.py -- bootstrapped-gate throughput on MI355X (BASELINE.json metric).
 
 A "step" is one gate over one batch of synthetic ciphertexts that already live in HBM (keys and
 ciphertexts are generated from fixed seeds before the timed region).  One process per GPU; the
-batch shards over ranks as independent bits (no data-path collective); with N > 1 every step ends
-with the result gather (RCCL all_gather of the output ciphertexts), as in the reference's
-examples/multi_gpu.py.  Rank 0 prints ONE JSON line.
+batch shards over ranks as independent bits (no data-path collective); every step launched through
+torch.distributed.run (also with ONE rank: that is how the RCCL route is exercised on a 1-GPU box) ends
+with the result gather to rank 0 (RCCL over xGMI), as in the reference's examples/multi_gpu.py.
+Rank 0 prints ONE JSON line.
 """
 
 import argparse
@@ -35,40 +36,110 @@ A_BR_NAND = A_BK + 2 * A_LWE + A_EXT             # bootstrap kernel alone, one b
 HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def _profile_json(name):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
 def pmc_traffic(transform, gate, bits):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes
     (profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command,
     corrected as MI355X_MICROARCH.md prescribes); None for configurations that were not measured."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            entry = json.load(f)[transform]
-    except Exception:
-        return None
-    if gate != "nand" or bits != 4096:
+    entry = (_profile_json("pmc_traffic.json") or {}).get(transform)
+    if entry is None or gate != "nand" or bits != 4096:
         return None
     return entry["hbm_bytes_per_launch"]
 
 
-def cpu_baseline(gate, sample_bits):
-    """Times the CPU oracle (a C restatement of the reference's *_cpu.py composition, OpenMP over
-    bits) on a bounded sample of the same workload, on this host's cores."""
+FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X vector fp64: 256 CUs x 128 flop/clk x 2.4 GHz (v_fma_f64 measured
+                                    # at 4.2 cycles per wave64 instruction: profiles/r01_microbench_valu_rates.txt)
+
+
+def issue_roofline(transform, bits, rotations, n_iter, kernel_ms):
+    """What actually bounds the bootstrap kernel, from TRACKED files only:
+    profiles/isa_mix.json (tools/isa_mix.py: instructions per blind-rotate iteration by issue class),
+    profiles/valu_class_costs.json (tools/microbench_l4: measured cycles per class at this occupancy),
+    profiles/pmc_<transform>.json (tools/profile.sh: SQ_INSTS_VALU, SQ_WAVE_CYCLES -> sustained clock).
+    NTT: VALU issue -- sum(count_class x cycles_class) against the SIMD cycles the launch had.
+    FFT: fp64 -- flops issued against the vector fp64 peak."""
+    mix = _profile_json("isa_mix.json")
+    costs = _profile_json("valu_class_costs.json")
+    pmc = _profile_json("pmc_%s.json" % transform)
+    if mix is None:
+        return None
+    k = mix["k_bootstrap<1>" if transform == "NTT" else "k_bootstrap_fft"]
+    iters = bits * rotations * n_iter
+    out = {"isa_mix_per_iteration": {c: k.get(c, 0) for c in (
+        "valu", "valu_full_rate", "valu_half_rate", "valu_f64", "s_nop", "lds", "vmem", "scratch")},
+        "vgprs": k.get("vgprs"), "scratch_bytes": k.get("scratch_bytes")}
+    clock = None
+    if pmc is not None:
+        d = pmc.get("derived", {})
+        clock = d.get("shader_clock_ghz_from_wave_cycles")
+        out["pmc"] = {"valu_instructions_per_wave_iteration": (d.get("valu_instructions_per_wave") or 0) / n_iter,
+                      "sustained_clock_ghz": clock,
+                      "cycles_per_valu_instruction_per_simd": d.get("cycles_per_valu_instruction_per_simd"),
+                      "frac_wave_cycles_issuing": d.get("frac_SQ_ACTIVE_INST_ANY"),
+                      "frac_wave_cycles_waiting_for_issue": d.get("frac_SQ_WAIT_INST_ANY"),
+                      "frac_wave_cycles_at_waitcnt": d.get("frac_SQ_WAIT_ANY")}
+    simds = 1024
+    if transform == "NTT" and costs is not None and clock:
+        cyc = k.get("valu_full_rate", 0) * costs["full_rate_cycles"] + k.get("valu_half_rate", 0) * costs["half_rate_cycles"]
+        issued = iters * cyc                                  # SIMD cycles of VALU issue the launch needs
+        avail = simds * clock * 1e9 * kernel_ms * 1e-3        # SIMD cycles the launch had
+        out.update({"bound": "valu-issue", "achieved": issued / (kernel_ms * 1e-3) / 1e9, "peak": simds * clock,
+                    "unit": "G SIMD issue cycles/s", "frac": issued / avail,
+                    "model": "sum over issue classes of (instructions x measured cycles): %d x %.2f + %d x %.2f = %.0f "
+                             "cycles per bit-iteration" % (k.get("valu_full_rate", 0), costs["full_rate_cycles"],
+                                                           k.get("valu_half_rate", 0), costs["half_rate_cycles"], cyc)})
+    elif transform == "FFT":
+        flops = iters * 64.0 * k.get("f64_flops_per_lane", 0)
+        out.update({"bound": "fp64-fma", "achieved": flops / (kernel_ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": flops / (kernel_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                    "model": "fp64 flops issued per bit-iteration (fma = 2): 64 lanes x %d" % k.get("f64_flops_per_lane", 0)})
+    return out
+
+
+def cpu_baseline_and_parity(gate, sample_bits, cs_host, gpu_out):
+    """Runs the CPU oracle (a C restatement of the reference's *_cpu.py composition, OpenMP over bits)
+    on the first `sample_bits` bits of the SAME ciphertexts the GPU just processed, on this host's
+    cores: its wall time is the reported CPU baseline, its output words are the parity check.
+
+    cs_host: three (a, b, cv) host triples; gpu_out: {label: (gate, exact, (a, b, cv))} host arrays of
+    the GPU results to compare (NTT path: every word must match; FFT path: stated tolerance).
+    The oracle regenerates the cloud key from the bench's key seed (GPU key generation == oracle key
+    generation from one seed: tests/test_gpu_kernels.py::test_gpu_keygen_matches_oracle_keygen)."""
     from oracle import oracle as orc
     lwe_key, tlwe_key, ck = orc.make_key_pair(orc.DeterministicRNG(123))
-    rng = orc.DeterministicRNG(456)
-    ms = [rng.uniform_bool((sample_bits,)).astype(bool) for _ in range(3)]
-    cs = [orc.encrypt(rng, lwe_key, m) for m in ms]
-    t0 = time.time()
-    if gate == 'mux':
-        r = orc.gate_mux(ck, cs[0], cs[1], cs[2])
-        ok = (orc.decrypt(lwe_key, r) == numpy.where(ms[0], ms[1], ms[2])).all()
-    else:
-        r = orc.gate('gate_nand', ck, cs[0], cs[1])
-        ok = (orc.decrypt(lwe_key, r) == ~(ms[0] & ms[1])).all()
-    dt = time.time() - t0
-    assert ok
-    return dict(value=sample_bits / dt, unit="gates/s", cores=orc.num_threads(), kind="port",
-                sample="%d-bit %s, full n=500 bootstrap + keyswitch, %.1f s" % (sample_bits, gate.upper(), dt),
-                ms_per_bit=1000.0 * dt / sample_bits)
+    n = sample_bits
+    cs = [tuple(x[:n] for x in c) for c in cs_host]
+    results, times = {}, {}
+    needed = {g for g, _, _ in gpu_out.values()} | {gate}
+    for g in sorted(needed):
+        t0 = time.time()
+        results[g] = orc.gate_mux(ck, cs[0], cs[1], cs[2]) if g == 'mux' else orc.gate('gate_nand', ck, cs[0], cs[1])
+        times[g] = time.time() - t0
+    parity = {}
+    for label, (g, exact, arrs) in gpu_out.items():
+        ref = results[g]
+        da = (arrs[0][:n].astype(numpy.int64) - ref[0].astype(numpy.int64) + 2**31) % 2**32 - 2**31
+        db = (arrs[1][:n].astype(numpy.int64) - ref[1].astype(numpy.int64) + 2**31) % 2**32 - 2**31
+        differing = int((da != 0).sum() + (db != 0).sum())
+        entry = {"bits": n, "words": int(da.size + db.size), "differing": differing,
+                 "variances_differing": int((arrs[2][:n] != ref[2]).sum())}
+        if not exact:
+            entry["max_abs_diff_lsb"] = int(max(abs(da).max(), abs(db).max()))
+            entry["tolerance_lsb"] = 16
+        parity[label] = entry
+    dt = times[gate]
+    base = dict(value=n / dt, unit="gates/s", cores=orc.num_threads(), kind="port",
+                sample="first %d bits of the benchmarked %s batch, full n=500 bootstrap + keyswitch, %.1f s" % (
+                    n, gate.upper(), dt),
+                ms_per_bit=1000.0 * dt / n)
+    return base, parity
 
 
 def main():
@@ -90,16 +161,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    # launched by torch.distributed.run (RANK set): the process group is created for ANY world size, so
+    # a 1-GPU box still drives device-side RCCL gathers; a plain `python bench.py` has no group
+    use_dist = world > 1 or ("RANK" in os.environ and os.environ.get("NUFHE_BENCH_NO_DIST") != "1")
+    if use_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         backend = os.environ.get("NUFHE_BENCH_BACKEND", "nccl")   # "gloo": test-only, ranks may share a GPU
         if backend == "gloo":
             local_rank = local_rank % max(1, torch.cuda.device_count())
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     import nufhe_amd
     from nufhe_amd import _lib
@@ -123,9 +200,10 @@ def main():
             vm.gate_mux(cs[0], cs[1], cs[2], dest=out)
         else:
             vm.gate_nand(cs[0], cs[1], dest=out)
-        if world > 1:
-            # the result gather of examples/multi_gpu.py, here one RCCL all_gather per array
-            multi_gpu.gather_ciphertext(out, world * B)
+        if use_dist:
+            # the result gather of examples/multi_gpu.py:104-107: every rank's slice goes to rank 0
+            # (one RCCL gather per array; 2008 bytes per bit cross xGMI once)
+            multi_gpu.gather_ciphertext(out, world * B, dst=0)
 
     import ctypes
     lib = _lib.lib()
@@ -133,7 +211,7 @@ def main():
         step()
     lib.nufhe_profile_enable(thr.handle, 1)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     br_ms, ks_ms = [], []
     t0 = time.perf_counter()
@@ -145,25 +223,36 @@ def main():
             _lib.check(lib.nufhe_profile_last(thr.handle, ctypes.byref(a), ctypes.byref(b)))
             br_ms.append(a.value); ks_ms.append(b.value)
     torch.cuda.synchronize()
-    if world > 1:
+    own_elapsed = time.perf_counter() - t0          # this rank alone (a straggler shows up here)
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64,
-                         device=thr.device if dist.get_backend() == "nccl" else "cpu")
+    per_rank_ms = [1e3 * own_elapsed / args.steps]
+    if use_dist:
+        dev = thr.device if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        own = torch.tensor([1e3 * own_elapsed / args.steps], dtype=torch.float64, device=dev)
+        every = torch.zeros(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(every, own)
+        per_rank_ms = [float(x) for x in every.cpu()]
 
     # the result gather alone (reported separately; it is also part of every timed step)
     gather_ms = None
-    if world > 1:
-        multi_gpu.gather_ciphertext(out, world * B)
+    gathered_ok = None
+    if use_dist:
+        full = multi_gpu.gather_ciphertext(out, world * B, dst=0)
         torch.cuda.synchronize(); dist.barrier()
         t1 = time.perf_counter()
         for _ in range(5):
-            multi_gpu.gather_ciphertext(out, world * B)
+            multi_gpu.gather_ciphertext(out, world * B, dst=0)
         torch.cuda.synchronize(); dist.barrier()
         gather_ms = 1e3 * (time.perf_counter() - t1) / 5
+        if rank == 0:
+            # rank 0's own slice must sit at the head of the gathered arrays
+            gathered_ok = bool((full[0][:B] == out.a).all() and (full[1][:B] == out.b).all()
+                               and full[0].shape[0] == world * B)
 
     # secondary measurements, OUTSIDE the timed region: the other BASELINE configurations on the same
     # ciphertexts (3 steps each after 1 warm-up); reported under "other_configs", never in "value"
@@ -172,16 +261,17 @@ def main():
         def measure(fn, nsteps=3):
             fn()
             torch.cuda.synchronize()
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             t1 = time.perf_counter()
             for _ in range(nsteps):
                 fn()
             torch.cuda.synchronize()
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             return (time.perf_counter() - t1) / nsteps
         out2 = vm.empty_ciphertext((B,))
+        out3 = vm.empty_ciphertext((B,))
         other_gate = "nand" if args.gate == "mux" else "mux"
         if other_gate == "mux":
             dt = measure(lambda: vm.gate_mux(cs[0], cs[1], cs[2], dest=out2))
@@ -195,8 +285,8 @@ def main():
         ctx_o = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(123), thread=thr)
         sk_o, ck_o = ctx_o.make_key_pair(transform_type=other_tr)     # same secret key bits (same seed)
         vm_o = ctx_o.make_virtual_machine(ck_o)
-        dt = measure(lambda: vm_o.gate_nand(cs[0], cs[1], dest=out2))
-        ok = bool((ctx_o.decrypt(sk_o, out2) == ~(ms[0] & ms[1])).all())
+        dt = measure(lambda: vm_o.gate_nand(cs[0], cs[1], dest=out3))
+        ok = bool((ctx_o.decrypt(sk_o, out3) == ~(ms[0] & ms[1])).all())
         other["gate_nand_%s" % other_tr] = {
             "ms_per_step_per_gpu": 1e3 * dt, "ms_per_bit": 1e3 * dt / B, "gates_per_s_per_gpu": B / dt, "correct": ok}
         del vm_o, ck_o
@@ -261,37 +351,51 @@ def main():
                 args.gate, B, "5" if args.transform == "FFT" else (
                     "3" if args.gate == "mux" else ("2" if world == 1 else "4"))),
                 "bits_per_gpu": B, "transform": args.transform, "parallelism": "bits sharded over %d GPU(s), keys replicated" % world},
-            "roofline": {
-                "bound": "hbm", "kernel": "k_bootstrap%s (fused mod-switch + blind rotate + extract)" % (
-                    "_fft" if args.transform == "FFT" else ""),
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(args.transform, args.gate, B),
-                "kernel_ms": br_avg, "keyswitch_ms": ks_avg,
-                "algorithmic_bytes_per_launch": a_kernel,
-                "gate_streaming_model_GBs": a_gate / (ms_per_step * 1e-3) / 1e9,
-            },
+            "roofline": {},
         }
-        if args.transform == "NTT":
-            # what actually binds K1: VALU issue.  Instruction count per bit-iteration from
-            # the ISA of the loop body (confirmed by PMC SQ_INSTS_VALU), 4 cycles per wave64 instruction,
-            # 1024 SIMDs, sustained clock from PMC SQ_WAVE_CYCLES (2.1 GHz).
-            valu_per_iter, simds, clock = 14126, 1024, 2.1e9
-            issued = B * n_rot * 500 * valu_per_iter
-            result["roofline"]["valu_issue"] = {
-                "instructions_per_launch": issued,
-                "frac_of_simd_cycles": issued * 4 / (simds * clock * br_avg * 1e-3),
-                "note": "wave64 VALU instructions x 4 cycles / (1024 SIMDs x 2.1 GHz x kernel time)"}
+        streaming = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": a_kernel,
+            "gate_streaming_model_GBs": a_gate / (ms_per_step * 1e-3) / 1e9,
+            "note": "BASELINE.json's HBM axis: every bit streams its 32.8 MB key once, no reuse (SURVEY §8d). The "
+                    "kernel shares each key row between all resident waves through L2, so this is a model figure, "
+                    "not traffic; the measured HBM bytes are in 'traffic'"}
+        roof = issue_roofline(args.transform, B, n_rot, 500, br_avg) or {}
+        if "bound" not in roof:        # profile files missing: fall back to the streaming model as the headline
+            roof.update({k: streaming[k] for k in ("bound", "achieved", "peak", "unit", "frac")})
+        roof.update({"kernel": "k_bootstrap%s (fused mod-switch + blind rotate + extract)" % (
+                         "_fft" if args.transform == "FFT" else ""),
+                     "traffic": pmc_traffic(args.transform, args.gate, B),
+                     "kernel_ms": br_avg, "keyswitch_ms": ks_avg, "streaming_model": streaming})
+        result["roofline"] = roof
+        result["per_rank_ms_per_step"] = per_rank_ms
         if gather_ms is not None:
             result["gather_ms"] = gather_ms
             result["gather_bytes_per_rank"] = B * 2008
+            result["gather"] = {"backend": dist.get_backend(), "dst": 0, "verified": gathered_ok}
         if other:
             result["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:
             nthreads = os.cpu_count() or 1
-            sample = args.cpu_sample_bits or max(16, min(256, 4 * nthreads))
-            result["cpu_baseline"] = cpu_baseline(args.gate, sample)
+            sample = min(B, args.cpu_sample_bits or max(16, min(256, 4 * nthreads)))
+
+            def host(ct):
+                return tuple(x.detach().cpu().numpy() for x in (ct.a, ct.b, ct.current_variances))
+            main_label = "gate_%s_%s" % (args.gate, args.transform)
+            gpu_out = {main_label: (args.gate, args.transform == "NTT", host(out))}
+            if not args.no_extra:
+                gpu_out["gate_%s_%s" % (other_gate, args.transform)] = (other_gate, args.transform == "NTT", host(out2))
+                gpu_out["gate_nand_%s" % other_tr] = ("nand", other_tr == "NTT", host(out3))
+            result["cpu_baseline"], result["parity"] = cpu_baseline_and_parity(
+                args.gate, sample, [host(c) for c in cs], gpu_out)
+            result["parity"]["note"] = ("GPU output words (a[500] and b per bit) vs the CPU oracle on the same input "
+                                        "ciphertexts; NTT legs must show differing = 0, the FFT leg is held to "
+                                        "max_abs_diff_lsb <= tolerance_lsb (tests/test_gpu_fft.py)")
+            bad = [k for k, v in result["parity"].items() if isinstance(v, dict) and (
+                v["differing"] != 0 if k.endswith("NTT") else v.get("max_abs_diff_lsb", 0) > v.get("tolerance_lsb", 0))]
+            result["correct"] = bool(result["correct"] and not bad)
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

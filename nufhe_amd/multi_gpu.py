@@ -5,7 +5,7 @@ which ships pickled slices between Python threads through host memory).
 One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on GPUs, "gloo" in the CPU
 tests).  The batch is cut into contiguous per-rank slices, the cloud key is replicated, every rank
 runs its gates locally with no data-path collective, and the only communication is the result
-gather.  The functions below contain no device-specific code: they work on whatever tensors
+gather to one rank (RCCL gather = grouped send/recv over xGMI).  The functions below contain no device-specific code: they work on whatever tensors
 (``a``, ``b``, ``current_variances``) they are given.
 """
 
@@ -29,11 +29,15 @@ def shard_ciphertext(ciphertext, world_size: int, rank: int):
     return ciphertext[lo:hi]
 
 
-def gather_arrays(local_tensors, nbits: int, group=None):
+def gather_arrays(local_tensors, nbits: int, group=None, dst=0):
     """
-    All-gathers per-rank result slices (first axis = bits, possibly ragged by one) into full
-    arrays, in rank order.  ``local_tensors`` is a tuple such as (a [b_r, n], b [b_r], cv [b_r]).
-    Returns a tuple of full tensors [nbits, ...] on every rank.
+    Collects per-rank result slices (first axis = bits, possibly ragged by one) into full arrays, in
+    rank order.  ``local_tensors`` is a tuple such as (a [b_r, n], b [b_r], cv [b_r]).
+
+    ``dst`` = rank that receives the result (default 0, the reference's main thread collecting the
+    slices, examples/multi_gpu.py:104-107): returns a tuple of full tensors [nbits, ...] there and None
+    on the other ranks -- every rank sends its 2008 bytes per bit exactly once.  ``dst=None`` gathers on
+    every rank (world_size times the traffic; for callers that continue a circuit on all ranks).
     """
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -41,6 +45,7 @@ def gather_arrays(local_tensors, nbits: int, group=None):
     base, extra = divmod(nbits, world)
     cap = base + (1 if extra else 0)
     lo, hi = shard_bounds(nbits, world, rank)
+    gloo_on_gpu = dist.get_backend(group) == 'gloo'
     out = []
     for t in local_tensors:
         if t.shape[0] != hi - lo:
@@ -50,24 +55,34 @@ def gather_arrays(local_tensors, nbits: int, group=None):
             padded = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
             padded[:t.shape[0]] = t
         padded = padded.contiguous()
-        if dist.get_backend(group) == 'gloo' and padded.is_cuda:
-            # test-only route (several ranks sharing one GPU over gloo): stage through the host
-            full_h = torch.empty((world * cap,) + tuple(t.shape[1:]), dtype=t.dtype)
-            dist.all_gather_into_tensor(full_h, padded.cpu(), group=group)
-            full = full_h.to(t.device)
+        # test-only route (several ranks sharing one GPU over gloo): stage through the host
+        stage = gloo_on_gpu and padded.is_cuda
+        send = padded.cpu() if stage else padded
+        full = None
+        if dst is None:
+            full = torch.empty((world * cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=send.device)
+            dist.all_gather_into_tensor(full, send, group=group)
+        elif rank == dst:
+            full = torch.empty((world * cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=send.device)
+            dist.gather(send, list(full.split(cap, dim=0)), dst=dst, group=group)
         else:
-            full = torch.empty((world * cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-            dist.all_gather_into_tensor(full, padded, group=group)
-        if extra:
-            pieces = []
-            for r in range(world):
-                l, h = shard_bounds(nbits, world, r)
-                pieces.append(full[r * cap:r * cap + (h - l)])
-            full = torch.cat(pieces, dim=0)
+            dist.gather(send, None, dst=dst, group=group)
+        if full is not None:
+            if stage:
+                full = full.to(t.device)
+            if extra:
+                pieces = []
+                for r in range(world):
+                    l, h = shard_bounds(nbits, world, r)
+                    pieces.append(full[r * cap:r * cap + (h - l)])
+                full = torch.cat(pieces, dim=0)
         out.append(full)
+    if dst is not None and rank != dst:
+        return None
     return tuple(out)
 
 
-def gather_ciphertext(local_ct, nbits: int, group=None):
-    """Gathers an LweSampleArray's slices; returns (a, b, current_variances) full tensors."""
-    return gather_arrays((local_ct.a, local_ct.b, local_ct.current_variances), nbits, group=group)
+def gather_ciphertext(local_ct, nbits: int, group=None, dst=0):
+    """Collects an LweSampleArray's slices; returns (a, b, current_variances) full tensors on ``dst``
+    (every rank for ``dst=None``), None elsewhere."""
+    return gather_arrays((local_ct.a, local_ct.b, local_ct.current_variances), nbits, group=group, dst=dst)

@@ -269,4 +269,78 @@ def test_bench_two_ranks_on_one_gpu():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['correct'] and d['scaling'] == 'weak' and d['gather_ms'] > 0
+    assert d['gather']['dst'] == 0 and d['gather']['verified'] is True and len(d['per_rank_ms_per_step']) == 2
     assert abs(d['value'] - 2 * 256 * 1000.0 / d['ms_per_step']) < 1e-6 * d['value']
+
+
+def test_config2_config3_every_word_vs_oracle(env, orc):
+    """BASELINE configs 2 and 3 at their full size: EVERY output word (a[500], b) and variance of the
+    4096-bit NAND and the 4096-bit MUX equals the CPU oracle (test/test_gates.py:178-228 structure,
+    lwe_cpu.py:62-93 for the keyswitch).  The oracle needs ~1-2 minutes on the box's host cores."""
+    H = env['H']; vm = env['vm']; ctx = env['ctx']; sk = env['secret_key']; ck = env['ck']
+    rng = numpy.random.RandomState(2024)
+    B = 4096
+    ms = [rng.randint(0, 2, size=(B,)).astype(bool) for _ in range(3)]
+    cs = [ctx.encrypt(sk, m) for m in ms]
+    host = [H.ct_arrays(c) for c in cs]
+    ra, rb, rcv = H.ct_arrays(vm.gate_nand(cs[0], cs[1]))
+    exp = orc.gate('gate_nand', ck, host[0][:2], host[1][:2])
+    assert ra.size + rb.size == B * 501
+    assert int((ra != exp[0]).sum()) == 0 and int((rb != exp[1]).sum()) == 0 and int((rcv != exp[2]).sum()) == 0
+    ma, mb, mcv = H.ct_arrays(vm.gate_mux(cs[0], cs[1], cs[2]))
+    expm = orc.gate_mux(ck, *[h[:2] for h in host])
+    assert int((ma != expm[0]).sum()) == 0 and int((mb != expm[1]).sum()) == 0 and int((mcv != expm[2]).sum()) == 0
+
+
+def test_config4_eight_logical_shards_on_one_device(env, orc):
+    """BASELINE config 4 (32768-bit NAND over 8 GPUs, examples/multi_gpu.py:86-114) as far as one GPU
+    allows: the batch is cut by the same shard_bounds the ranks use, each of the 8 shards of 4096 bits
+    goes through gate_nand as its own call (what rank r would run), the slices are concatenated in rank
+    order.  Every decrypted bit and the first 32 ciphertexts of EACH shard are checked against the
+    truth table / the CPU oracle.  (N-GPU wall-clock is not measured here: see DESIGN.md §6.)"""
+    import nufhe_amd
+    from nufhe_amd import multi_gpu
+    H = env['H']; vm = env['vm']; ctx = env['ctx']; sk = env['secret_key']; ck = env['ck']
+    rng = numpy.random.RandomState(4)
+    B, G = 32768, 8
+    m1 = rng.randint(0, 2, size=(B,)).astype(bool); m2 = rng.randint(0, 2, size=(B,)).astype(bool)
+    c1 = ctx.encrypt(sk, m1); c2 = ctx.encrypt(sk, m2)
+    parts = []
+    for r in range(G):
+        lo, hi = multi_gpu.shard_bounds(B, G, r)
+        assert hi - lo == 4096
+        s1 = multi_gpu.shard_ciphertext(c1, G, r); s2 = multi_gpu.shard_ciphertext(c2, G, r)
+        parts.append(vm.gate_nand(s1, s2))
+        exp = orc.gate('gate_nand', ck, tuple(x[lo:lo + 32] for x in H.ct_arrays(c1)[:2]),
+                       tuple(x[lo:lo + 32] for x in H.ct_arrays(c2)[:2]))
+        pa, pb, pcv = H.ct_arrays(parts[-1])
+        assert (pa[:32] == exp[0]).all() and (pb[:32] == exp[1]).all() and (pcv[:32] == exp[2]).all(), r
+    full = nufhe_amd.concatenate(parts)
+    assert full.shape == (B,)
+    assert (ctx.decrypt(sk, full) == ~(m1 & m2)).all()
+    # one unsharded call over all 32768 bits gives the same ciphertexts (bits are independent)
+    whole = vm.gate_nand(c1, c2)
+    assert whole == full
+
+
+def test_bench_rccl_route_world_size_one():
+    """bench.py launched by torch.distributed.run with ONE rank and the `nccl` backend: the process
+    group is created with device_id=, the per-step result gather (device int32 / float32 tensors) and
+    the timing collectives go through RCCL -- the same code path the 8-GPU run takes, minus the xGMI
+    links."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != 'NUFHE_BENCH_BACKEND'}
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+           '--master-addr', '127.0.0.1', '--master-port', '29541', os.path.join(root, 'bench.py'),
+           '--gpus', '1', '--steps', '2', '--warmup', '1', '--bits', '512', '--no-extra', '--no-cpu-baseline']
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+    lines = [l for l in proc.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['correct']
+    assert d['gather']['backend'] == 'nccl' and d['gather']['verified'] is True and d['gather_ms'] > 0
+    assert len(d['per_rank_ms_per_step']) == 1

@@ -46,8 +46,13 @@ def _worker(rank, world, port, nbits, results):
     lo, hi = multi_gpu.shard_bounds(nbits, world, rank)
     local = (_fake_gate(a[lo:hi], a2[lo:hi]), _fake_gate(b[lo:hi], b2[lo:hi]),
              torch.full((hi - lo,), float(rank)))
-    full = multi_gpu.gather_arrays(local, nbits)
+    full = multi_gpu.gather_arrays(local, nbits, dst=None)       # every rank receives everything
     ok = bool((full[0] == _fake_gate(a, a2)).all() and (full[1] == _fake_gate(b, b2)).all())
+    on0 = multi_gpu.gather_arrays(local, nbits)                  # default: rank 0 only
+    if rank == 0:
+        ok = ok and all(bool((x == y).all()) for x, y in zip(on0, full))
+    else:
+        ok = ok and on0 is None
     owners = full[2].to(torch.int64)
     expect_owner = torch.cat([torch.full((multi_gpu.shard_bounds(nbits, world, r)[1]
                                           - multi_gpu.shard_bounds(nbits, world, r)[0],), r) for r in range(world)])

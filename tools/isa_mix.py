@@ -1,16 +1,22 @@
 """
-isa_mix.py -- instruction mix of one blind-rotate iteration of k_bootstrap<1>, counted in the ISA.
+isa_mix.py -- instruction mix of one blind-rotate iteration of the bootstrap kernels, counted in the ISA.
 
-    python tools/isa_mix.py            # compiles nufhe_amd/csrc/kernels.hip to assembly (hipcc -S)
+    python tools/isa_mix.py            # compiles nufhe_amd/csrc/kernels.hip to assembly (hipcc -S) and prints
+    python tools/isa_mix.py --write    # ... and refreshes profiles/isa_mix.json (read by bench.py)
 
-Prints VGPR / scratch use and, for the body of the per-iteration loop, the number of VALU, SALU, LDS,
-memory, s_waitcnt and s_nop instructions (inner loops weighted by their trip counts where the
-compiler kept them rolled).  The VALU figure is the one that decides the kernel's speed.
-`tools/isa_pieces.hip` compiles the building blocks (16-point pass, twiddle layers, paired MAC ...)
-as separate kernels for the same kind of count:
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -Inufhe_amd/csrc -S --cuda-device-only tools/isa_pieces.hip -o /tmp/p.s
+For the body of the per-iteration loop of k_bootstrap<1> (NTT) and k_bootstrap_fft it reports VGPR /
+scratch use and the number of VALU instructions by ISSUE CLASS (measured on gfx950 at the kernel's
+occupancy, profiles/r02_microbench_l4.txt):
+    full   v_add/sub/subrev_u32, v_and/or/xor/not_b32, v_lshrrev_b32, v_ashrrev_i32, v_mov_b32, v_cndmask_b32
+    half   everything else 32/64-bit integer (carry chains, compares, v_lshlrev, v_perm, v_mad_u64_u32, VOP3 ...)
+    f64    v_fma_f64 / v_mul_f64 / v_add_f64 (counted separately: flops)
+plus SALU, LDS, memory, s_waitcnt and hazard s_nop counts.  The weighted VALU figure decides the NTT
+kernel's speed.  `profiles/isa_mix.json` also records a hash of the device sources so that
+tests/test_cabi_and_host.py can tell when it is stale.
 """
 import collections
+import hashlib
+import json
 import os
 import re
 import subprocess
@@ -18,65 +24,95 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'nufhe_amd', 'csrc')
+FULL_RATE = {'v_add_u32', 'v_sub_u32', 'v_subrev_u32', 'v_and_b32', 'v_or_b32', 'v_xor_b32', 'v_not_b32',
+             'v_lshrrev_b32', 'v_ashrrev_i32', 'v_mov_b32', 'v_cndmask_b32'}
+F64 = {'v_fma_f64': 2, 'v_mul_f64': 1, 'v_add_f64': 1}
+KERNELS = {'k_bootstrap<1>': '_Z11k_bootstrapILi1EEv8BrLaunch', 'k_bootstrap_fft': '_Z15k_bootstrap_fft8BrLaunch'}
 
 
-def main():
-    asm = '/tmp/nufhe_kernels.s'
-    out = subprocess.run(
-        ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', 'kernels.hip', '-o', asm,
-         '-Rpass-analysis=kernel-resource-usage'] + sys.argv[1:], cwd=CSRC, capture_output=True, text=True)
-    text = out.stderr
-    m = re.search(r'Function Name: _Z11k_bootstrapILi1EEv8BrLaunch.*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+)', text, re.S)
-    if m:
-        print('k_bootstrap<1>: VGPRs %s, scratch %s B' % m.groups())
-    lines = open(asm).read().split('\n')
-    start = next(i for i, l in enumerate(lines) if l.startswith('_Z11k_bootstrapILi1EEv8BrLaunch:'))
-    end = next(i for i, l in enumerate(lines) if i > start and 's_endpgm' in l)
-    lines = lines[start:end]
+def source_hash():
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith(('.h', '.hip')):
+            h.update(name.encode())
+            h.update(open(os.path.join(CSRC, name), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def strip(op):
+    return re.sub(r'_(e32|e64|sdwa|dpp)$', '', op)
+
+
+def loop_body(lines):
+    """lines of the per-iteration loop = the longest span closed by a backward branch"""
     labels = {}
     for i, l in enumerate(lines):
         mm = re.match(r'^(\.LBB\d+_\d+):', l)
         if mm:
             labels[mm.group(1)] = i
-    loops = []
+    best = None
     for i, l in enumerate(lines):
-        mm = re.search(r's_cbranch_\w+ (\.LBB\d+_\d+)', l)
+        mm = re.search(r's_c?branch\w* (\.LBB\d+_\d+)', l)
         if mm and mm.group(1) in labels and labels[mm.group(1)] < i:
-            loops.append((labels[mm.group(1)], i))
-    # the iteration loop = the largest backward-branch span or the Depth=1 header after the prologue
-    hdr = [i for i, l in enumerate(lines) if 'Loop Header: Depth=1' in l and i > 300]
-    body_start = hdr[-1] if hdr else 0
-    inner = sorted([lp for lp in loops if lp[0] > body_start and lp[1] - lp[0] > 1000], key=lambda x: x[1] - x[0])
-    body_end = next((i for i, l in enumerate(lines) if i > body_start + 3000 and re.match(r'^\.LBB\d+_\d+:\s*$', l)
-                     and not any(a <= i <= b for a, b in inner)), len(lines) - 1)
+            span = (labels[mm.group(1)], i)
+            if best is None or span[1] - span[0] > best[1] - best[0]:
+                best = span
+    return lines[best[0]:best[1] + 1]
 
-    def weight(i):
-        w = 1
-        for k, (a, b) in enumerate(inner):
-            if a <= i <= b:
-                w *= 2          # rolled m- or d-loop: two trips each
-        return w
 
+def count(body):
     c = collections.Counter()
-    for i in range(body_start, body_end):
-        mm = re.match(r'^\s+([a-z_0-9]+)', lines[i])
+    for l in body:
+        mm = re.match(r'^\s+([a-z_0-9]+)', l)
         if not mm:
             continue
-        op, w = mm.group(1), weight(i)
+        op = strip(mm.group(1))
         if op == 's_nop':
-            c['s_nop'] += w
-            c['nop_cycles'] += w * (int(lines[i].split()[1]) + 1)
+            c['s_nop'] += 1
+            c['nop_wait_states'] += int(l.split()[1]) + 1
+        elif op in F64:
+            c['valu'] += 1
+            c['valu_f64'] += 1
+            c['f64_flops_per_lane'] += F64[op]
         elif op.startswith('v_'):
-            c['valu'] += w
+            c['valu'] += 1
+            c['valu_full_rate' if op in FULL_RATE else 'valu_half_rate'] += 1
         elif op.startswith('s_waitcnt'):
-            c['waitcnt'] += w
+            c['waitcnt'] += 1
         elif op.startswith('s_'):
-            c['salu'] += w
+            c['salu'] += 1
         elif op.startswith('ds_'):
-            c['lds'] += w
-        elif op.startswith(('global', 'scratch', 'buffer')):
-            c['vmem'] += w
-    print('per blind-rotate iteration (rolled inner loops: %d):' % len(inner), dict(c))
+            c['lds'] += 1
+        elif op.startswith('scratch'):
+            c['scratch'] += 1
+        elif op.startswith(('global', 'buffer')):
+            c['vmem'] += 1
+    return dict(c)
+
+
+def main():
+    asm = '/tmp/nufhe_kernels.s'
+    args = [a for a in sys.argv[1:] if a != '--write']
+    out = subprocess.run(
+        ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', 'kernels.hip', '-o', asm,
+         '-Rpass-analysis=kernel-resource-usage'] + args, cwd=CSRC, capture_output=True, text=True)
+    if out.returncode:
+        sys.exit(out.stderr[-3000:])
+    text = out.stderr
+    all_lines = open(asm).read().split('\n')
+    result = {'source_hash': source_hash(),
+              'note': 'python tools/isa_mix.py --write; per blind-rotate iteration of one wave (one bit)'}
+    for name, sym in KERNELS.items():
+        m = re.search(r'Function Name: ' + re.escape(sym) + r'\b.*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+)', text, re.S)
+        start = next(i for i, l in enumerate(all_lines) if l.startswith(sym + ':'))
+        end = next(i for i, l in enumerate(all_lines) if i > start and 's_endpgm' in l)
+        c = count(loop_body(all_lines[start:end]))
+        c['vgprs'] = int(m.group(1)) if m else None
+        c['scratch_bytes'] = int(m.group(2)) if m else None
+        result[name] = c
+        print(name, json.dumps(c))
+    if '--write' in sys.argv:
+        json.dump(result, open(os.path.join(ROOT, 'profiles', 'isa_mix.json'), 'w'), indent=1, sort_keys=True)
 
 
 if __name__ == '__main__':

@@ -87,12 +87,13 @@ static void run_transform(const char *name, u64 *d_io, i32 *d_d, u64 *d_tw, long
 #define ASM1(str) asm volatile(str : "+v"(a[i]) : "v"(b), "v"(c), "s"(sc))
 
 template <int OP>
-__global__ __launch_bounds__(512, 2) void k_op(uint32_t *out, uint32_t seed)
+__global__ __launch_bounds__(512, 2) void k_op(uint32_t *out, uint32_t seed, long long *cycles)
 {
     uint32_t a[UNROLL], b = seed + threadIdx.x, c = (seed * 3 + 1) & 15, sc = seed * 5 + 7;
 #pragma unroll
     for (int i = 0; i < UNROLL; i++) a[i] = seed + i * 977 + threadIdx.x;
     asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(b), "v"(a[0]) : "vcc");
+    const long long t0 = clock64();
     for (int it = 0; it < ITERS; it++) {
 #pragma unroll
         for (int i = 0; i < UNROLL; i++) {
@@ -122,8 +123,17 @@ __global__ __launch_bounds__(512, 2) void k_op(uint32_t *out, uint32_t seed)
             else if (OP == 23) ASM1("v_pk_add_u16 %0, %0, %1");
             else if (OP == 24) ASM1("v_pk_sub_i16 %0, %0, %1");
             else if (OP == 25) ASM1("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD src0_sel:DWORD src1_sel:WORD_0");
+            else if (OP == 26) ASM1("v_add_u32 %0, %3, %0");
+            else if (OP == 27) ASM1("v_and_b32 %0, 0xffffff, %0");
+            else if (OP == 28) ASM1("v_lshlrev_b32 %0, 12, %0");
+            else if (OP == 29) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(*(uint64_t *)&a[i & ~1]) : "v"(b), "v"(c) : "vcc");
+            else if (OP == 30) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(*(uint64_t *)&a[i & ~1]) : "v"(*(uint64_t *)&a[(i + 2) & 14]));
+            else if (OP == 31) asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
+            else if (OP == 32) asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(*(double *)&a[i & ~1]));
         }
     }
+    const long long t1 = clock64();
+    if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
     uint32_t r = 0;
 #pragma unroll
     for (int i = 0; i < UNROLL; i++) r ^= a[i];
@@ -131,23 +141,28 @@ __global__ __launch_bounds__(512, 2) void k_op(uint32_t *out, uint32_t seed)
 }
 
 template <int OP>
-static void run_op(const char *name, uint32_t *d_out)
+static void run_op(const char *name, uint32_t *d_out, long long *d_cyc)
 {
     const int blocks = 256;     // one 8-wave work-group per CU = 2 waves per SIMD
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k_op<OP>, dim3(blocks), dim3(512), 0, 0, d_out, 12345u);
+    hipLaunchKernelGGL(k_op<OP>, dim3(blocks), dim3(512), 0, 0, d_out, 12345u, d_cyc);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k_op<OP>, dim3(blocks), dim3(512), 0, 0, d_out, 12345u);
+    hipLaunchKernelGGL(k_op<OP>, dim3(blocks), dim3(512), 0, 0, d_out, 12345u, d_cyc);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
-    const double wave_ops = (double)blocks * 8 * ITERS * UNROLL;
-    const double per_simd_per_s = wave_ops / (ms * 1e-3) / 1024.0;
-    printf("%-34s %8.3f ms   %6.2f cycles per wave-instruction per SIMD (@2.4 GHz, 2 waves/SIMD)\n", name, ms,
-           2.4e9 / per_simd_per_s);
+    std::vector<long long> cyc(blocks * 8);
+    hipMemcpy(cyc.data(), d_cyc, cyc.size() * 8, hipMemcpyDeviceToHost);
+    double avg = 0;
+    for (long long v : cyc) avg += (double)v;
+    avg /= cyc.size();
+    // a wave shares its SIMD with one other wave running the same stream: while one wave is resident for
+    // `avg` ticks the SIMD issues 2 x ITERS x UNROLL instructions
+    printf("%-34s %8.3f ms   %6.2f clock64 ticks per wave-instruction per SIMD (2 waves/SIMD)\n", name, ms,
+           avg / ((double)ITERS * UNROLL) / 2.0);
 }
 
 int main()
@@ -184,31 +199,38 @@ int main()
 
     uint32_t *d_out;
     hipMalloc(&d_out, 256 * 512 * 4);
-    run_op<0>("v_add_u32", d_out);
-    run_op<21>("v_sub_u32", d_out);
-    run_op<15>("v_subrev_u32", d_out);
-    run_op<11>("v_sub_u32 (sgpr src0)", d_out);
-    run_op<18>("v_add_u32 (literal)", d_out);
-    run_op<1>("v_and_b32", d_out);
-    run_op<2>("v_or_b32", d_out);
-    run_op<22>("v_xor_b32", d_out);
-    run_op<12>("v_not_b32", d_out);
-    run_op<4>("v_mov_b32", d_out);
-    run_op<3>("v_ashrrev_i32 (const)", d_out);
-    run_op<14>("v_lshrrev_b32 (vgpr amount)", d_out);
-    run_op<13>("v_lshlrev_b32 (vgpr amount)", d_out);
-    run_op<5>("v_cndmask_b32 (vcc, set once)", d_out);
-    run_op<19>("v_max_i32", d_out);
-    run_op<6>("v_perm_b32", d_out);
-    run_op<7>("v_lshl_add_u32", d_out);
-    run_op<8>("v_add3_u32", d_out);
-    run_op<17>("v_and_or_b32", d_out);
-    run_op<9>("v_mad_i32_i24", d_out);
-    run_op<16>("v_mul_i32_i24", d_out);
-    run_op<10>("v_bfm_b32", d_out);
-    run_op<20>("v_bfe_i32", d_out);
-    run_op<23>("v_pk_add_u16", d_out);
-    run_op<24>("v_pk_sub_i16", d_out);
-    run_op<25>("v_add_u32_sdwa", d_out);
+    run_op<0>("v_add_u32", d_out, d_cyc);
+    run_op<21>("v_sub_u32", d_out, d_cyc);
+    run_op<15>("v_subrev_u32", d_out, d_cyc);
+    run_op<11>("v_sub_u32 (sgpr src0)", d_out, d_cyc);
+    run_op<18>("v_add_u32 (literal)", d_out, d_cyc);
+    run_op<1>("v_and_b32", d_out, d_cyc);
+    run_op<2>("v_or_b32", d_out, d_cyc);
+    run_op<22>("v_xor_b32", d_out, d_cyc);
+    run_op<12>("v_not_b32", d_out, d_cyc);
+    run_op<4>("v_mov_b32", d_out, d_cyc);
+    run_op<3>("v_ashrrev_i32 (const)", d_out, d_cyc);
+    run_op<14>("v_lshrrev_b32 (vgpr amount)", d_out, d_cyc);
+    run_op<13>("v_lshlrev_b32 (vgpr amount)", d_out, d_cyc);
+    run_op<5>("v_cndmask_b32 (vcc, set once)", d_out, d_cyc);
+    run_op<19>("v_max_i32", d_out, d_cyc);
+    run_op<6>("v_perm_b32", d_out, d_cyc);
+    run_op<7>("v_lshl_add_u32", d_out, d_cyc);
+    run_op<8>("v_add3_u32", d_out, d_cyc);
+    run_op<17>("v_and_or_b32", d_out, d_cyc);
+    run_op<9>("v_mad_i32_i24", d_out, d_cyc);
+    run_op<16>("v_mul_i32_i24", d_out, d_cyc);
+    run_op<10>("v_bfm_b32", d_out, d_cyc);
+    run_op<20>("v_bfe_i32", d_out, d_cyc);
+    run_op<23>("v_pk_add_u16", d_out, d_cyc);
+    run_op<24>("v_pk_sub_i16", d_out, d_cyc);
+    run_op<25>("v_add_u32_sdwa", d_out, d_cyc);
+    run_op<26>("v_add_u32 (sgpr src0)", d_out, d_cyc);
+    run_op<27>("v_and_b32 (literal)", d_out, d_cyc);
+    run_op<28>("v_lshlrev_b32 (const)", d_out, d_cyc);
+    run_op<29>("v_mad_u64_u32", d_out, d_cyc);
+    run_op<30>("v_lshl_add_u64", d_out, d_cyc);
+    run_op<31>("v_addc_co_u32", d_out, d_cyc);
+    run_op<32>("v_fma_f64", d_out, d_cyc);
     return 0;
 }
