@@ -78,7 +78,9 @@ def issue_roofline(transform, bits, rotations, n_iter, kernel_ms):
     clock = None
     if pmc is not None:
         d = pmc.get("derived", {})
-        clock = d.get("shader_clock_ghz_from_wave_cycles")
+        # sustained shader clock of the profiled launches: GRBM_GUI_ACTIVE per XCD / kernel time (agrees
+        # with SQ_BUSY_CYCLES per shader engine); fall back to the wave-cycle estimate
+        clock = d.get("grbm_gui_active_per_xcd_ghz") or d.get("shader_clock_ghz_from_wave_cycles")
         out["pmc"] = {"valu_instructions_per_wave_iteration": (d.get("valu_instructions_per_wave") or 0) / n_iter,
                       "sustained_clock_ghz": clock,
                       "cycles_per_valu_instruction_per_simd": d.get("cycles_per_valu_instruction_per_simd"),
