@@ -17,12 +17,26 @@
 //    end; in between B is an exchange buffer;
 //  * bara (u16 x 512) lives in the 8 x 128 bytes of row padding of buffer A, which the exchanges
 //    never touch.
+//  * BRF_PARK accumulator words per lane are parked in LDS during the external product (the kernel sits at the 256-VGPR limit of 2 waves per SIMD and would otherwise spill to
+//    scratch memory): 4 per lane in the row padding of buffer B (free whenever B is an exchange
+//    buffer), the rest in a small extra region.
+#define BRF_PARK 7
+#define BRF_PARK_EXTRA_BYTES ((BRF_PARK - 4) * 64 * 4)
 struct BrFftLds {
     cplx *xbufA;         // FFT_XBUF_ELEMS complex
     cplx *xbufB;         // FFT_XBUF_ELEMS complex; acc mirror aliases its first 8 KiB
+    u32 *park;           // [(BRF_PARK - 4) * 64]
     const cplx *tw1;     // [512]
     const cplx *tw2;     // [64]
 };
+
+// LDS slot of parked value j (0 .. BRF_PARK-1) of this lane
+FF_FN u32 *brf_park_slot(const BrFftLds &lds, int j, int lane)
+{
+    const int idx = j * 64 + lane;
+    if (j < 4) return (u32 *)((unsigned char *)lds.xbufB + (idx >> 5) * (FFT_ROW * 16) + 1024) + (idx & 31);
+    return lds.park + (idx - 256);
+}
 
 FF_FN i32 *brf_acc_mirror(const BrFftLds &lds) { return (i32 *)lds.xbufB; }
 
@@ -49,22 +63,39 @@ FF_FN u32 brf_prologue(const BrSource &s0, const BrSource &s1, i32 c0, long bit,
 }
 
 // MAC of the two transformed digit polynomials (d = 0, 1) of input polynomial m against
-// BK_row[m][d][mo], mo = 0, 1 (tgsw_cpu.py:63-77)
+// BK_row[m][d][mo], mo = 0, 1 (tgsw_cpu.py:63-77).  The 32 key loads (16 bytes per lane each) are
+// software-pipelined in groups of BRF_KEY_GROUP: the next group is in flight while the current one is
+// multiplied -- left to itself the compiler hoists all 32 loads (128 VGPRs) above the arithmetic and
+// spills part of the accumulator to scratch.
+#define BRF_KEY_GROUP 2
 FF_FN void brf_mac_pair(cplx (&sum)[2][8], const cplx (&x)[2][8], const cplx *row, int m, int lane)
 {
+    // group g: polynomial (m, d, mo) = g / GROUPS_PER_POLY, registers GROUP * (g % GROUPS_PER_POLY) ...
+    constexpr int GPP = 8 / BRF_KEY_GROUP, NG = 4 * GPP;
+    const cplx *base = row + (long)(m * 2) * 2 * BKF_POLY_ELEMS + lane;
+    auto addr = [&](int g, int i) {
+        const int poly = g / GPP, r = BRF_KEY_GROUP * (g % GPP) + i;    // poly = d * 2 + mo
+        return base + poly * BKF_POLY_ELEMS + r * 64;
+    };
+    cplx k[BRF_KEY_GROUP], n[BRF_KEY_GROUP];
 #pragma unroll
-    for (int d = 0; d < 2; d++) {
-        const cplx *poly = row + (m * 2 + d) * 2 * BKF_POLY_ELEMS;
+    for (int i = 0; i < BRF_KEY_GROUP; i++) k[i] = *addr(0, i);
 #pragma unroll
-        for (int mo = 0; mo < 2; mo++) {
-            const cplx *p = poly + mo * BKF_POLY_ELEMS + lane;
+    for (int g = 0; g < NG; g++) {
+        if (g + 1 < NG) {
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const cplx k = p[r * 64];
-                sum[mo][r].re += x[d][r].re * k.re - x[d][r].im * k.im;
-                sum[mo][r].im += x[d][r].re * k.im + x[d][r].im * k.re;
-            }
+            for (int i = 0; i < BRF_KEY_GROUP; i++) n[i] = *addr(g + 1, i);
+            BR_ISSUE_FENCE();
         }
+        const int d = (g / GPP) >> 1, mo = (g / GPP) & 1;
+#pragma unroll
+        for (int i = 0; i < BRF_KEY_GROUP; i++) {
+            const int r = BRF_KEY_GROUP * (g % GPP) + i;
+            sum[mo][r].re += x[d][r].re * k[i].re - x[d][r].im * k[i].im;
+            sum[mo][r].im += x[d][r].re * k[i].im + x[d][r].im * k[i].re;
+        }
+#pragma unroll
+        for (int i = 0; i < BRF_KEY_GROUP; i++) k[i] = n[i];
     }
 }
 
@@ -134,8 +165,14 @@ FF_FN void brf_step(u32 (&acc)[2][16], u32 a, const cplx *row, const BrFftLds &l
             T[m][r] = ((t & 1024u) ? 0u - v : v) - acc[m][r];     // polynomials_cpu.py:46-58
         }
     WAVE_SYNC();    // every lane has read the mirror before buffer B is reused for exchanges
+    // park BRF_PARK accumulator words in LDS for the duration of the product (they are only needed
+    // again for the update below)
+#pragma unroll
+    for (int r = 0; r < BRF_PARK; r++) *brf_park_slot(lds, r, lane) = acc[0][r];
     u32 res[2][16];
     brf_external_product(res, T, row, lds, L);
+#pragma unroll
+    for (int r = 0; r < BRF_PARK; r++) acc[0][r] = *brf_park_slot(lds, r, lane);
 #pragma unroll
     for (int mo = 0; mo < 2; mo++)
 #pragma unroll

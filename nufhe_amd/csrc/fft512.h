@@ -233,10 +233,24 @@ FF_FN void fft_inverse(cplx (&x)[8], cplx *xbuf, const cplx *tw1, const cplx *tw
     fft_inverse_n<1>(xs, bufs, tw1, tw2, L);
 }
 
+#if defined(NUFHE_EMU)
+// tests/emu only: distance of the values handed to the final rounding from the nearest integer
+// (0.5 = a rounding decision could flip) and their largest magnitude
+extern double g_emu_fft_max_frac, g_emu_fft_max_abs;
+#endif
+
 // round-to-nearest-even to the low 32 bits (two's complement), valid for |v| < 2^51
-// (fft.mako:272-277: round -> int64 -> truncate to int32)
+// (fft.mako:272-277: round -> int64 -> truncate to int32).  The products of the blind rotation stay
+// below 2^52 in the worst case and below ~2^46 on real keys.
 FF_FN u32 fft_round_to_u32(double v)
 {
+#if defined(NUFHE_EMU)
+    {
+        const double f = fabs(v - nearbyint(v));
+        if (f > g_emu_fft_max_frac) g_emu_fft_max_frac = f;
+        if (fabs(v) > g_emu_fft_max_abs) g_emu_fft_max_abs = fabs(v);
+    }
+#endif
     const double magic = 6755399441055744.0;   // 1.5 * 2^52
     union { double d; u64 u; } c;
     c.d = v + magic;

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64 * BR_WAVES_K(K), K == 1 ? 2 : 1) void k_blind_ro
 // ------------------------------------------------------------------------------------------
 #define FTABLE_LDS_BYTES ((FFT_TW1_ELEMS + FFT_TW2_ELEMS) * 16)
 #define WAVE_FXBUF_BYTES (FFT_XBUF_ELEMS * 16)
-#define WAVE_BRF_LDS_BYTES (2 * WAVE_FXBUF_BYTES)   /* acc mirror and bara are aliased: blind_rotate_fft.h */
+#define WAVE_BRF_LDS_BYTES (2 * WAVE_FXBUF_BYTES + BRF_PARK_EXTRA_BYTES)   /* acc mirror and bara are aliased: blind_rotate_fft.h */
 
 __device__ __forceinline__ void load_ftables(const cplx *__restrict__ g_tw1, const cplx *__restrict__ g_tw2)
 {
@@ -168,6 +168,7 @@ __device__ __forceinline__ BrFftLds carve_brf_lds(int wave)
     BrFftLds lds;
     lds.xbufA = (cplx *)base;
     lds.xbufB = (cplx *)(base + WAVE_FXBUF_BYTES);
+    lds.park = (u32 *)(base + 2 * WAVE_FXBUF_BYTES);
     lds.tw1 = (const cplx *)g_smem;
     lds.tw2 = (const cplx *)g_smem + FFT_TW1_ELEMS;
     return lds;

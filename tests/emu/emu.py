@@ -146,3 +146,11 @@ def bootstrap_bit_fft(bk_internal, n, src0, p0, src1, p1, c0, mu, team=False):
                                 _p(a1, c_i32p), _p(b1, c_i32p), ctypes.c_int32(p1),
                                 ctypes.c_int32(c0), ctypes.c_int32(mu))
     return out_a, out_b[0]
+
+
+def fft_margin():
+    """(largest distance from an integer, largest magnitude) of the values rounded by the FFT inverse
+    transforms since the last call (host build statistics)."""
+    a = ctypes.c_double(); b = ctypes.c_double()
+    lib().emu_fft_margin(ctypes.byref(a), ctypes.byref(b))
+    return a.value, b.value

@@ -16,6 +16,7 @@
 #include "../../nufhe_amd/csrc/blind_rotate_fft.h"
 #include "emu_wave.h"
 
+double g_emu_fft_max_frac = 0.0, g_emu_fft_max_abs = 0.0;   // fft512.h (NUFHE_EMU)
 static u64 g_tw1f[1024], g_tw1i[1024];
 static bool g_tables = false;
 static void tables()
@@ -177,6 +178,13 @@ extern "C" void emu_bootstrap_bit_k2(i32 *out_a, i32 *out_b, const u64 *bk_inter
 
 extern "C" {
 
+// reads and resets the rounding-margin statistics gathered by fft_round_to_u32 (host build only)
+void emu_fft_margin(double *max_frac, double *max_abs)
+{
+    *max_frac = g_emu_fft_max_frac; *max_abs = g_emu_fft_max_abs;
+    g_emu_fft_max_frac = 0.0; g_emu_fft_max_abs = 0.0;
+}
+
 static cplx g_ftw1[FFT_TW1_ELEMS], g_ftw2[FFT_TW2_ELEMS];
 static bool g_ftables = false;
 static void ftables() { if (!g_ftables) { fft_make_tables(g_ftw1, g_ftw2); g_ftables = true; } }
@@ -246,7 +254,8 @@ void emu_bootstrap_bit_fft(i32 *out_a, i32 *out_b, const double *bk_internal, in
 {
     ftables();
     std::vector<cplx> xbuf(2 * FFT_XBUF_ELEMS);
-    BrFftLds lds{xbuf.data(), xbuf.data() + FFT_XBUF_ELEMS, g_ftw1, g_ftw2};
+    std::vector<u32> park((BRF_PARK - 4) * 64);
+    BrFftLds lds{xbuf.data(), xbuf.data() + FFT_XBUF_ELEMS, park.data(), g_ftw1, g_ftw2};
     BrSource s0{a0, b0, 0, 0, p0}, s1{a1, b1, 0, 0, p1};
     emu_run_wave([&](int lane) {
         FftLane L = fft_lane_init(lane);

@@ -143,8 +143,15 @@ def test_bootstrap_wave_body_fft_full_key(orc, oracle_keys):
     ta = (-c1[0] - c2[0]).astype(numpy.int32); tb = (numpy.int32(MU) - c1[1] - c2[1]).astype(numpy.int32)
     ea, eb = orc.bootstrap_extract(ck.bk, ta, tb, MU)
     bkf = of.bk_from_coeffs(of.tgsw_coeffs_from_reference_bk(ck.bk))
+    emu.fft_margin()
     ga, gb = emu.bootstrap_bit_fft(emu.bkf_from_reference(bkf), 500, (c1[0][0], c1[1]), -1, (c2[0][0], c2[1]), -1, MU, MU)
     assert (ga == ea[0]).all() and gb == eb[0]
+    # rounding margin of the whole blind rotation (1,024,000 rounded values): the fp64 error before
+    # `round` must stay far from 0.5 and the magnitudes inside the 2^51 range of the magic-number round
+    # (products of real keys are ~2^44..2^46, error ~ 2^-53 * 10 * |v|)
+    max_frac, max_abs = emu.fft_margin()
+    print("FFT blind rotation: max |v - round(v)| = %.4f, max |v| = 2^%.1f" % (max_frac, numpy.log2(max_abs)))
+    assert max_frac < 0.125 and max_abs < 2.0**49
     # the 4-wave team variant (different fp64 summation order): still equal to the exact result
     ga, gb = emu.bootstrap_bit_fft(emu.bkf_from_reference(bkf), 500, (c1[0][0], c1[1]), -1, (c2[0][0], c2[1]), -1, MU, MU,
                                    team=True)

@@ -9,15 +9,22 @@ Stated tolerance: fp64 rounding may move a coefficient of an ext
   * product of a full-range int32 polynomial with a small one: EXACT (test_computation.py:106-124),
   * one external product: max |delta| <= 1 LSB vs the exact (NTT) result on <= 1e-4 of coefficients,
   * a whole gate (500 external products + keyswitch): decrypted bits identical; every output word
-    within 2^16 LSB (2^-16 torus) of the exact path, i.e. 2^-12 of the 1/16 decision margin.
-On the seeded inputs below the observed deviation is ZERO (bit-identical to the exact path), which
-the tests also record.
+    within 2^4 LSB (2^-28 torus) of the exact path.
+Why so tight: the values handed to `round` are the exact integers plus the fp64 error of the
+transforms, about 10 * 2^-53 * |v| with |v| <= 2^47 on real keys, i.e. < 0.06 -- an eighth of the 0.5 at
+which a rounding decision could flip (measured over a whole blind rotation on the host build of the
+same code: tests/test_emu_device_code.py::test_bootstrap_wave_body_fft_full_key, max 0.055).  Every
+external product therefore rounds to the exact result and the observed deviation is ZERO (bit-identical
+to the exact path), which the tests also record; the 2^4 allowance covers keys / inputs whose products
+approach the 2^52 worst case.
 """
 
 import ctypes
 
 import numpy
 import pytest
+
+FFT_TOLERANCE_LSB = 2**4     # per output word of a whole gate vs the exact (NTT) path
 
 import golden_inputs as gi
 
@@ -138,7 +145,7 @@ def test_config5_fft_gates_vs_exact_path(fft_env, thr, H, orc):
         ra, rb, rcv = H.ct_arrays(got)
         da = (ra.astype(numpy.int64) - exp[0].astype(numpy.int64) + 2**31) % 2**32 - 2**31
         db = (rb.astype(numpy.int64) - exp[1].astype(numpy.int64) + 2**31) % 2**32 - 2**31
-        assert numpy.abs(da).max() <= 2**16 and numpy.abs(db).max() <= 2**16, name
+        assert numpy.abs(da).max() <= FFT_TOLERANCE_LSB and numpy.abs(db).max() <= FFT_TOLERANCE_LSB, name
         print("FFT %s: output words differing from the exact path: %d of %d" % (
             name, int((da != 0).sum() + (db != 0).sum()), da.size + db.size))
 
@@ -164,7 +171,7 @@ def test_config5_fft_context_end_to_end_4096(thr):
     import gpu_helpers as H
     a1, b1, _ = H.ct_arrays(r); a2, b2, _ = H.ct_arrays(r2)
     d = (a1.astype(numpy.int64) - a2.astype(numpy.int64) + 2**31) % 2**32 - 2**31
-    assert numpy.abs(d).max() <= 2**16
+    assert numpy.abs(d).max() <= FFT_TOLERANCE_LSB
     print("FFT vs NTT, 4096-bit NAND: differing words:", int((d != 0).sum()), "of", d.size)
     # serialization round trip of an FFT key
     cloud3 = ctx.load_cloud_key(cloud.dumps())
@@ -194,7 +201,7 @@ def test_fft_small_batch_team_kernel(fft_env, thr, H, orc):
             ra, rb, rcv = got[limit][name]
             da = (ra.astype(numpy.int64) - exp[name][0].astype(numpy.int64) + 2**31) % 2**32 - 2**31
             db = (rb.astype(numpy.int64) - exp[name][1].astype(numpy.int64) + 2**31) % 2**32 - 2**31
-            assert numpy.abs(da).max() <= 2**16 and numpy.abs(db).max() <= 2**16, (name, limit)
+            assert numpy.abs(da).max() <= FFT_TOLERANCE_LSB and numpy.abs(db).max() <= FFT_TOLERANCE_LSB, (name, limit)
             assert (rcv == exp[name][2]).all()
         same = all((x == y).all() for x, y in zip(got[0][name], got[-1][name]))
         print("FFT %s: team kernel == wave kernel: %s; words differing from the exact path: %d" % (
