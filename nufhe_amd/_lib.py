@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnufhe_hip.so")
+# NUFHE_HIP_LIBRARY: load another build of the same library (kernel-tuning experiments, tools/)
+LIB_PATH = os.environ.get("NUFHE_HIP_LIBRARY") or os.path.join(_HERE, "libnufhe_hip.so")
 
 
 class NufheError(RuntimeError):

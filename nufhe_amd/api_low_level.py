@@ -25,34 +25,33 @@ class NuFHEParameters:
         error reaches half a torus LSB -- see DESIGN.md for the stated tolerance).
     """
 
+    #: the one parameter set of the scheme (the values of nufhe/api_low_level.py:49-61); standard
+    #: deviations are given as multiples of sqrt(2 / pi)
+    SCHEME = {
+        "lwe_size": 500,                      # n: size of the in/out LWE samples
+        "tlwe_polynomial_degree": 1024,       # N
+        "bootstrap_decomposition": (2, 10),   # (l, log2 Bg) of the gadget
+        "keyswitch_decomposition": (8, 2),    # (t, log2 base)
+        "stdev_keyswitch": 2.0**-15,          # noise of fresh / keyswitched samples
+        "stdev_bootstrap": 9e-9,              # noise of the bootstrapping-key samples
+        "stdev_max": 2.0**-6,                 # largest tolerated noise: a quarter of the 1/16 margin
+    }
+    #: (transform, mask size) pairs with a gfx950 bootstrap kernel
+    SUPPORTED = {('NTT', 1), ('NTT', 2), ('FFT', 1), ('FFT', 2)}
+
     def __init__(self, transform_type='NTT', tlwe_mask_size=1):
         assert transform_type in ('FFT', 'NTT')
         assert tlwe_mask_size >= 1
-        if tlwe_mask_size > 2 or (tlwe_mask_size == 2 and transform_type != 'NTT'):
-            raise NotImplementedError(
-                "gfx950 kernels exist for tlwe_mask_size=1 (NTT, FFT) and tlwe_mask_size=2 (NTT)")
-
-        tlwe_polynomial_degree = 1024
-        lwe_size = 500
-        bs_decomp_length = 2
-        bs_log2_base = 10
-        ks_decomp_length = 8
-        ks_log2_base = 2
-
-        coeff = (2 / numpy.pi)**0.5
-        ks_stdev = 1/2**15 * coeff
-        bs_stdev = 9e-9 * coeff
-        max_stdev = 1/2**4 / 4 * coeff
-
-        params_in = LweParams(lwe_size, ks_stdev, max_stdev)
-        params_accum = TLweParams(
-            tlwe_polynomial_degree, tlwe_mask_size, bs_stdev, max_stdev, transform_type)
-        params_bs = TGswParams(params_accum, bs_decomp_length, bs_log2_base)
-
-        self.ks_decomp_length = ks_decomp_length
-        self.ks_log2_base = ks_log2_base
-        self.in_out_params = params_in
-        self.tgsw_params = params_bs
+        if (transform_type, tlwe_mask_size) not in self.SUPPORTED:
+            raise NotImplementedError("no gfx950 kernel for transform %s with tlwe_mask_size=%d (have: %s)" % (
+                transform_type, tlwe_mask_size, sorted(self.SUPPORTED)))
+        cfg = self.SCHEME
+        unit = float(numpy.sqrt(2 / numpy.pi))
+        accumulator = TLweParams(cfg["tlwe_polynomial_degree"], tlwe_mask_size, cfg["stdev_bootstrap"] * unit,
+                                 cfg["stdev_max"] * unit, transform_type)
+        self.ks_decomp_length, self.ks_log2_base = cfg["keyswitch_decomposition"]
+        self.in_out_params = LweParams(cfg["lwe_size"], cfg["stdev_keyswitch"] * unit, cfg["stdev_max"] * unit)
+        self.tgsw_params = TGswParams(accumulator, *cfg["bootstrap_decomposition"])
         self._transform_type = transform_type
         self._tlwe_mask_size = tlwe_mask_size
 
@@ -122,6 +121,15 @@ class NuFHECloudKey:
         import ctypes
         from . import _lib
         lwe = ks.lwe
+        # the library stores decomposition length 8 / base 4 keys of ext_size rows (nufhe_ks_upload
+        # reads exactly that many words): reject anything else before handing over host pointers
+        ext_size = native.mask_size * 1024
+        expect = (ext_size, 8, 4)
+        if (tuple(lwe.shape) != expect or lwe.a.shape[-1] != native.lwe_size
+                or lwe.a.dtype != numpy.int32 or lwe.b.dtype != numpy.int32
+                or lwe.current_variances.dtype != numpy.float32):
+            raise ValueError("keyswitch key of shape %s x %d (%s) does not match the cloud key's %s x %d (int32)" % (
+                tuple(lwe.shape), lwe.a.shape[-1], lwe.a.dtype, expect, native.lwe_size))
         _lib.call("nufhe_ks_upload", native.handle,
                   lwe.a.ctypes.data_as(ctypes.c_void_p), lwe.b.ctypes.data_as(ctypes.c_void_p),
                   lwe.current_variances.ctypes.data_as(ctypes.c_void_p))

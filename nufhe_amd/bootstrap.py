@@ -15,7 +15,7 @@ import numpy
 from . import _lib
 from . import serialization
 from .device import ptr
-from .lwe import LweParams, LweKey, LweSampleArray, LweKeyswitchKey, _Flat
+from .lwe import LweParams, LweKey, LweSampleArray, LweKeyswitchKey, _Flat, check_lwe_size
 from .tgsw import TGswKey, TGswParams, tgsw_encrypt_int
 from .utils import arrays_equal
 
@@ -29,6 +29,7 @@ class NativeCloudKey:
         self.thr = thr
         self.transform_type = transform_type
         self.mask_size = mask_size
+        self.lwe_size = int(lwe_size)
         handle = ctypes.c_void_p()
         _lib.call("nufhe_cloudkey_create", thr.handle, int(lwe_size), self.TRANSFORMS[transform_type],
                   int(mask_size), ctypes.byref(handle))
@@ -114,6 +115,8 @@ def bootstrap(thr, result: LweSampleArray, bk: BootstrapKey, ks: LweKeyswitchKey
     result = LWE(mu) iff phase(x) > 0, LWE(-mu) iff phase(x) < 0  (nufhe/bootstrap.py:206-229).
     With ``no_keyswitch`` the result is an LWE sample under the extracted key (size N*k).
     """
+    check_lwe_size("bootstrap result", result, bk.extract_params.size if no_keyswitch else bk.in_out_params.size)
+    check_lwe_size("bootstrap argument", x, bk.in_out_params.size)
     res = _Flat(result, result.shape, output=True)
     src = _Flat(x, result.shape)
     _lib.call("nufhe_bootstrap", thr.handle, bk._native.handle, res.desc, src.desc,

@@ -20,8 +20,10 @@
 //  * BRF_PARK accumulator words per lane are parked in LDS during the external product (the kernel sits at the 256-VGPR limit of 2 waves per SIMD and would otherwise spill to
 //    scratch memory): 4 per lane in the row padding of buffer B (free whenever B is an exchange
 //    buffer), the rest in a small extra region.
+#ifndef BRF_PARK
 #define BRF_PARK 7
-#define BRF_PARK_EXTRA_BYTES ((BRF_PARK - 4) * 64 * 4)
+#endif
+#define BRF_PARK_EXTRA_BYTES ((BRF_PARK > 4 ? BRF_PARK - 4 : 0) * 64 * 4)
 struct BrFftLds {
     cplx *xbufA;         // FFT_XBUF_ELEMS complex
     cplx *xbufB;         // FFT_XBUF_ELEMS complex; acc mirror aliases its first 8 KiB

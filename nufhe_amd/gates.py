@@ -11,7 +11,7 @@ import numpy
 
 from . import _lib
 from .lwe import (
-    LweSampleArray, _Flat,
+    LweSampleArray, _Flat, check_lwe_size,
     lwe_negate, lwe_copy, lwe_noiseless_trivial,
     )
 from .numeric_functions import phase_to_t32
@@ -61,8 +61,16 @@ def check_shape(result, *args):
 MU = phase_to_t32(1, 8)
 
 
+def _check_sizes(cloud_key, result, *args):
+    n = cloud_key.params.in_out_params.size
+    check_lwe_size("gate result", result, n)
+    for x in args:
+        check_lwe_size("gate argument", x, n)
+
+
 def _binary_gate(thr, cloud_key, result, a, b, c, pa, pb):
     check_shape(result, a, b)
+    _check_sizes(cloud_key, result, a, b)
     res = _Flat(result, result.shape, output=True)
     fa = _Flat(a, result.shape)
     fb = _Flat(b, result.shape)
@@ -150,6 +158,7 @@ def gate_mux(thr, cloud_key, result, a, b, c, perf_params=None):
     (0, 1/8) + u1 + u2, one keyswitch  (nufhe/gates.py:600-664).
     """
     check_shape(result, a, b, c)
+    _check_sizes(cloud_key, result, a, b, c)
     res = _Flat(result, result.shape, output=True)
     fa = _Flat(a, result.shape)
     fb = _Flat(b, result.shape)

@@ -9,6 +9,7 @@ in the reference's order, so that one seed gives the same ciphertexts as the CPU
 """
 
 import io
+import logging
 import pickle
 
 import numpy
@@ -195,6 +196,24 @@ class LweSampleArray:
 
 # ---- flattening of (possibly strided / broadcast) N-d views into the C descriptor -------------
 
+_log = logging.getLogger("nufhe_amd")
+
+#: number of times a view could not be described by (pointer, one bit stride) and went through a
+#: contiguous temporary (torch copy in, and copy back for outputs); each occurrence is also logged at
+#: DEBUG level on the "nufhe_amd" logger.  Views whose leading axes collapse to one stride -- slices of
+#: the first axis, steps, broadcasts of one sample -- never copy.
+flat_copies = 0
+
+
+def check_lwe_size(what: str, sample, expected: int):
+    """The kernels address ``a`` rows of exactly the key's LWE size; a different size would read or
+    write out of bounds (the reference gets a type error from Reikna here)."""
+    size = sample.a.shape[-1]
+    if size != expected:
+        raise ValueError("{what}: LWE size {size} does not match the key's {expected}".format(
+            what=what, size=size, expected=expected))
+
+
 class _Flat:
     """2D/1D views of a sample broadcast to ``shape``; ``writeback()`` copies results back when a
     contiguous temporary had to be used for an output view."""
@@ -217,6 +236,11 @@ class _Flat:
         except RuntimeError:
             ok = False
         if not ok:
+            global flat_copies
+            flat_copies += 1
+            _log.debug("ciphertext view of shape %s (strides a=%s b=%s) is not expressible as one bit stride: "
+                       "%s through a contiguous temporary", shape, tuple(a.stride()), tuple(b.stride()),
+                       "result written back" if output else "operand copied")
             if output:
                 self._targets = (a, b, cv)
             a2 = a.contiguous().view(nbits, n)
@@ -337,6 +361,8 @@ def lwe_keyswitch(thr: DeviceThread, result: LweSampleArray, ks: LweKeyswitchKey
     """nufhe/lwe.py:311-322: translate the sample to the output key (LWE(N*k) -> LWE(n))."""
     if ks._native is None:
         raise ValueError("this keyswitch key is not attached to a cloud key on the device")
+    check_lwe_size("lwe_keyswitch result", result, ks.output_size)
+    check_lwe_size("lwe_keyswitch sample", sample, ks.input_size)
     res = _Flat(result, result.shape, output=True)
     src = _Flat(sample, result.shape)
     _lib.call("nufhe_keyswitch", thr.handle, ks._native.handle, res.desc, src.desc, res.nbits)
@@ -365,6 +391,7 @@ def lwe_encrypt(thr: DeviceThread, rng, result: LweSampleArray, messages, noise:
 def lwe_decrypt(thr: DeviceThread, sample: LweSampleArray, key: LweKey):
     """nufhe/lwe.py:336-343: phase b - a.s on the GPU (LweDecrypt, lwe_cpu.py:107-112), returned
     as a host array."""
+    check_lwe_size("lwe_decrypt sample", sample, key.params.size)
     flat = _Flat(sample, sample.shape)
     out = thr.array((flat.nbits,), Torus32)
     key_dev = key.key.contiguous()

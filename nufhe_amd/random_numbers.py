@@ -4,17 +4,11 @@ randomness is drawn on the host and uploaded; the draw ORDER of key generation a
  is preserved so that one seed gives the same keys and ciphertexts.
 """
 
-import random
-from os import urandom
+import os
 
 import numpy
 
 from .numeric_functions import Torus32, Int32, double_to_t32
-
-Float = numpy.dtype('float64')
-MantissaInt = numpy.dtype('uint64')
-BPF = numpy.finfo(Float).nmant + 1
-RECIP_BPF = 2**(-BPF)
 
 
 class DeterministicRNG:
@@ -34,37 +28,51 @@ class DeterministicRNG:
 
 
 class SecureRNG:
-    """A cryptographically secure RNG backed by the OS (random_numbers.py:65-130)."""
+    """
+    Cryptographically secure randomness: every value is derived from ``os.urandom`` bytes (same three
+    methods as the reference's SecureRNG, random_numbers.py:65-124, so the two are interchangeable in
+    ``Context(rng=...)``; the construction below is this package's own).
 
-    def __init__(self):
-        self.rng = random.SystemRandom()
+    * bits: the low bit of one random byte each;
+    * torus elements: 4 random bytes each, read as a little-endian int32;
+    * Gaussians: Marsaglia's polar method on pairs of uniforms in (-1, 1) built from 53 random bits;
+      rejected pairs (about 21 %) are redrawn until the request is filled.
+    """
+
+    def _bytes(self, count, dtype):
+        dtype = numpy.dtype(dtype)
+        return numpy.frombuffer(os.urandom(int(count) * dtype.itemsize), dtype=dtype)
 
     def uniform_bool(self, shape):
-        length = int(numpy.prod(shape))
-        nbytes = (length - 1) // 8 + 1
-        bits = numpy.unpackbits(numpy.frombuffer(urandom(nbytes), numpy.uint8))[:length]
-        return bits.reshape(shape).astype(Int32)
+        n = int(numpy.prod(shape, dtype=numpy.int64))
+        return (self._bytes(n, numpy.uint8) & 1).astype(Int32).reshape(shape)
 
     def uniform_torus32(self, shape):
-        length = int(numpy.prod(shape))
-        return numpy.frombuffer(urandom(length * 4), Int32).reshape(shape).copy()
+        n = int(numpy.prod(shape, dtype=numpy.int64))
+        return self._bytes(n, '<i4').astype(Torus32).reshape(shape)
 
-    def _uniform_float(self, length):
-        # open interval (0, 1): drop one extra bit, then shift by half a step
-        mantissa = numpy.frombuffer(urandom(length * MantissaInt.itemsize), MantissaInt)
-        mantissa = mantissa >> numpy.uint64(MantissaInt.itemsize * 8 - (BPF - 1))
-        mantissa = mantissa * numpy.uint64(2) + numpy.uint64(1)
-        return mantissa * RECIP_BPF
+    def _symmetric_uniform(self, n):
+        # 53 random bits -> k / 2^53 in [0, 1) -> 2 x - 1 in [-1, 1)
+        k = self._bytes(n, '<u8') >> numpy.uint64(11)
+        return k.astype(numpy.float64) * (2.0 / 9007199254740992.0) - 1.0
 
     def gauss(self, shape, std_dev):
-        orig_length = int(numpy.prod(shape))
-        length = orig_length + orig_length % 2
-        u1 = self._uniform_float(length // 2)
-        u2 = self._uniform_float(length // 2)
-        r = (-2 * numpy.log(u1))**0.5
-        theta = 2 * numpy.pi * u2
-        result = numpy.concatenate([r * numpy.cos(theta), r * numpy.sin(theta)])[:orig_length]
-        return result.reshape(shape) * std_dev
+        n = int(numpy.prod(shape, dtype=numpy.int64))
+        out = numpy.empty(n, numpy.float64)
+        filled = 0
+        while filled < n:
+            want = n - filled
+            pairs = max(16, int(0.7 * want) + 8)        # each accepted pair yields two normals
+            u = self._symmetric_uniform(pairs)
+            v = self._symmetric_uniform(pairs)
+            s = u * u + v * v
+            keep = (s > 0.0) & (s < 1.0)
+            u, v, s = u[keep], v[keep], s[keep]
+            f = numpy.sqrt(-2.0 * numpy.log(s) / s)
+            z = numpy.stack([u * f, v * f], axis=1).reshape(-1)[:want]
+            out[filled:filled + z.size] = z
+            filled += z.size
+        return out.reshape(shape) * std_dev
 
 
 def rand_gaussian_torus32_host(rng, message, sigma: float, shape, centered=False):

@@ -106,8 +106,10 @@ def test_parameters_match_reference_defaults():
     assert NuFHEParameters(transform_type='FFT') != p
     p2 = NuFHEParameters(tlwe_mask_size=2)
     assert p2.tgsw_params.tlwe_params.extracted_lweparams.size == 2048 and p2 != p
+    p3 = NuFHEParameters(transform_type='FFT', tlwe_mask_size=2)      # every (transform, k <= 2) pair exists
+    assert p3.tgsw_params.tlwe_params.extracted_lweparams.size == 2048 and p3 != p2
     with pytest.raises(NotImplementedError):
-        NuFHEParameters(transform_type='FFT', tlwe_mask_size=2)
+        NuFHEParameters(tlwe_mask_size=3)
 
 
 def test_rng_order_matches_oracle(orc):

@@ -62,8 +62,8 @@ def test_parameters_k2_host_side():
     p = nufhe_amd.NuFHEParameters(tlwe_mask_size=2)
     assert p.tgsw_params.tlwe_params.mask_size == 2
     assert p.tgsw_params.tlwe_params.extracted_lweparams.size == 2048
-    with pytest.raises(NotImplementedError):
-        nufhe_amd.NuFHEParameters(transform_type='FFT', tlwe_mask_size=2)
+    pf = nufhe_amd.NuFHEParameters(transform_type='FFT', tlwe_mask_size=2)
+    assert pf.tgsw_params.tlwe_params.mask_size == 2 and pf.tgsw_params.tlwe_params.transform_type == 'FFT'
     with pytest.raises(NotImplementedError):
         nufhe_amd.NuFHEParameters(tlwe_mask_size=3)
 

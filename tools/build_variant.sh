@@ -1,0 +1,15 @@
+#!/bin/bash
+# build_variant.sh NAME "-DFLAG=..." -- an alternate build of libnufhe_hip.so for kernel-tuning experiments:
+# gpurun_variants/libnufhe_hip_NAME.so (git-ignored, travels to the GPU box); select it with
+# NUFHE_HIP_LIBRARY=$PWD/gpurun_variants/libnufhe_hip_NAME.so
+NAME=$1; shift
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+mkdir -p "$ROOT/gpurun_variants/obj_$NAME"
+cd "$ROOT/nufhe_amd/csrc"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-pass-failed -Wno-unused-value $@"
+/opt/rocm/bin/hipcc $FLAGS -c kernels.hip -o "$ROOT/gpurun_variants/obj_$NAME/kernels.o" &
+/opt/rocm/bin/hipcc $FLAGS -c api.hip -o "$ROOT/gpurun_variants/obj_$NAME/api.o" &
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/gpurun_variants/libnufhe_hip_$NAME.so" \
+    "$ROOT/gpurun_variants/obj_$NAME/kernels.o" "$ROOT/gpurun_variants/obj_$NAME/api.o"
+ls -la "$ROOT/gpurun_variants/libnufhe_hip_$NAME.so"
