@@ -34,11 +34,16 @@ class NativeCloudKey:
         _lib.call("nufhe_cloudkey_create", thr.handle, int(lwe_size), self.TRANSFORMS[transform_type],
                   int(mask_size), ctypes.byref(handle))
         self.handle = handle
+        thr._cloud_keys.add(self)
+
+    def destroy(self):
+        if self.handle and not self.thr._released:
+            _lib.lib().nufhe_cloudkey_destroy(self.handle)
+        self.handle = None
 
     def __del__(self):
         try:
-            if self.handle and not self.thr._released:
-                _lib.lib().nufhe_cloudkey_destroy(self.handle)
+            self.destroy()
         except Exception:
             pass
 
@@ -98,6 +103,10 @@ class BootstrapKey:
                     bk_params.tlwe_params.polynomial_degree // (2 if fft else 1))
         if tuple(arr.shape) != expected:
             raise ValueError("bootstrap key array has shape %s, expected %s" % (arr.shape, expected))
+        if in_out_params.size != native.lwe_size or bk_params.tlwe_params.mask_size != native.mask_size:
+            raise ValueError("bootstrap key stream (n = %d, k = %d) does not match the cloud key parameters "
+                             "(n = %d, k = %d)" % (in_out_params.size, bk_params.tlwe_params.mask_size,
+                                                   native.lwe_size, native.mask_size))
         _lib.call("nufhe_bk_upload_reference", native.handle, arr.ctypes.data_as(ctypes.c_void_p))
         return cls(in_out_params, bk_params, native)
 
@@ -115,6 +124,7 @@ def bootstrap(thr, result: LweSampleArray, bk: BootstrapKey, ks: LweKeyswitchKey
     result = LWE(mu) iff phase(x) > 0, LWE(-mu) iff phase(x) < 0  (nufhe/bootstrap.py:206-229).
     With ``no_keyswitch`` the result is an LWE sample under the extracted key (size N*k).
     """
+    thr.check_stream()
     check_lwe_size("bootstrap result", result, bk.extract_params.size if no_keyswitch else bk.in_out_params.size)
     check_lwe_size("bootstrap argument", x, bk.in_out_params.size)
     res = _Flat(result, result.shape, output=True)

@@ -45,6 +45,7 @@ struct Scratch {
 
 struct nufhe_ctx {
     int device = 0;
+    int num_cus = 256;         // of this context's device
     hipStream_t stream = nullptr;
     bool own_stream = false;
     u64 *d_tw1f = nullptr;
@@ -110,13 +111,13 @@ int check_key(nufhe_ctx *ctx, nufhe_cloudkey *key, bool need_bk, bool need_ks)
     return NUFHE_OK;
 }
 
-int pick_j_per_block(long nbits, int input_size)
+int pick_j_per_block(long nbits, int input_size, int num_cus)
 {
     const long tiles = (nbits + KS_TILE_BITS - 1) / KS_TILE_BITS;
     int jsplit = 1;
     // two 64 KiB-LDS blocks fit a CU: aim at one full wave of 2 x CUs blocks (measured: 512 blocks 1.35 ms,
     // 1024 blocks 1.38 ms, 256 blocks 2.01 ms for 4096 bits)
-    const long target = 2L * kernels_num_cus();
+    const long target = 2L * num_cus;
     while (jsplit < 128 && tiles * jsplit < target) jsplit *= 2;
     return input_size / jsplit;
 }
@@ -136,7 +137,7 @@ int run_keyswitch(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result, 
     P.nbits = nbits;
     P.n = key->n;
     P.input_size = key->ext_size();
-    P.j_per_block = pick_j_per_block(nbits, P.input_size);
+    P.j_per_block = pick_j_per_block(nbits, P.input_size, ctx->num_cus);
     KsFinal F;
     F.acc = P.acc;
     F.ks_b = key->d_ks_b; F.ks_cv = key->d_ks_cv;
@@ -210,7 +211,7 @@ int nufhe_ctx_create(int device, void *stream, int own_stream, nufhe_ctx **out)
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_ftw2, FFT_TW2_ELEMS * sizeof(cplx));
     if (e == hipSuccess) e = hipMemcpy(ctx->d_ftw1, g1.data(), FFT_TW1_ELEMS * sizeof(cplx), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ctx->d_ftw2, g2.data(), FFT_TW2_ELEMS * sizeof(cplx), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = kernels_init_device();
+    if (e == hipSuccess) e = kernels_init_device(&ctx->num_cus);
     for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipEventCreate(&ctx->ev[k]);
     if (e != hipSuccess) {
         nufhe_ctx_destroy(ctx);
@@ -301,8 +302,8 @@ int nufhe_cloudkey_create(nufhe_ctx *ctx, int lwe_size, int transform, int mask_
     if (!key) return fail(NUFHE_EINVAL, "null argument");
     if (transform != NUFHE_TRANSFORM_NTT && transform != NUFHE_TRANSFORM_FFT)
         return fail(NUFHE_EINVAL, "unknown transform %d", transform);
-    if (mask_size < 1 || mask_size > 2 || (mask_size == 2 && transform != NUFHE_TRANSFORM_NTT))
-        return fail(NUFHE_EINVAL, "unsupported tlwe_mask_size %d for transform %d (1, or 2 with NTT)", mask_size, transform);
+    if (mask_size < 1 || mask_size > 2)
+        return fail(NUFHE_EINVAL, "unsupported tlwe_mask_size %d (1 or 2)", mask_size);
     if (lwe_size < 1 || lwe_size > BR_MAX_LWE)
         return fail(NUFHE_EINVAL, "lwe_size %d out of range [1, %d]", lwe_size, BR_MAX_LWE);
     nufhe_cloudkey *k = new nufhe_cloudkey();
@@ -470,7 +471,7 @@ static int run_gate(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result
     }
     if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
     HIP_TRY(launch_bootstrap(P, key->transform, key->mask_size,
-                             ctx->team_max_bits >= 0 ? ctx->team_max_bits : 2L * kernels_num_cus(), ctx->stream));
+                             ctx->team_max_bits >= 0 ? ctx->team_max_bits : 2L * ctx->num_cus, ctx->num_cus, ctx->stream));
     if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     if (keyswitch) {
         const i32 *ea = (const i32 *)ctx->ext_a.ptr, *eb = (const i32 *)ctx->ext_b.ptr;

@@ -197,6 +197,156 @@ FF_FN void brf_blind_rotate(u32 (&acc)[2][16], const cplx *bk, int n, u32 barb, 
 }
 
 // ------------------------------------------------------------------------------------------
+// tlwe_mask_size = K > 1 with the FFT transform (the reference runs this pair through its multi-kernel
+// driver, nufhe/bootstrap.py:96-142 with polynomial_transform_fft; test/test_gates.py:88-100).
+// Same body as above with K + 1 polynomials: TGSW rows have (K+1) * 2 * (K+1) polynomials, K + 1 pairs of
+// forward transforms and K + 1 inverse transforms per step.  The accumulator lives ONLY in its LDS
+// mirror int32[K+1][1024] (not aliased: the registers are needed for the (K+1) x 8 complex sums), so a
+// wave needs 2 x 9216 + (K+1) x 4096 bytes of LDS; the kernel runs 4 waves per CU (one per SIMD, see kernels.hip).
+// ------------------------------------------------------------------------------------------
+struct BrFftLdsK {
+    cplx *xbufA;         // FFT_XBUF_ELEMS complex; bara lives in its row padding (brf_bara_slot)
+    cplx *xbufB;         // FFT_XBUF_ELEMS complex
+    i32 *acc;            // [K+1][1024]
+    const cplx *tw1;
+    const cplx *tw2;
+};
+
+FF_FN uint16_t *brfk_bara_slot(const BrFftLdsK &lds, int i)
+{
+    return (uint16_t *)((unsigned char *)lds.xbufA + (i >> 6) * (FFT_ROW * 16) + 1024) + (i & 63);
+}
+
+// sum[mo] += x[d] (*) BK_row[m][d][mo] for d = 0, 1 and mo = 0..K; key loads pipelined in groups of 4
+template <int K>
+FF_FN void brfk_mac_pair(cplx (&sum)[K + 1][8], const cplx (&x)[2][8], const cplx *row, int m, int lane)
+{
+    constexpr int NG = 2 * (K + 1) * 2;            // groups of 4 registers: (d, mo, half)
+    const cplx *base = row + (long)(m * 2) * (K + 1) * BKF_POLY_ELEMS + lane;
+    auto addr = [&](int g, int i) { return base + (g >> 1) * BKF_POLY_ELEMS + (4 * (g & 1) + i) * 64; };   // g >> 1 = d (K+1) + mo
+    cplx k[4], n[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) k[i] = *addr(0, i);
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) n[i] = *addr(g + 1, i);
+            BR_ISSUE_FENCE();
+        }
+        const int d = (g >> 1) / (K + 1), mo = (g >> 1) % (K + 1);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = 4 * (g & 1) + i;
+            sum[mo][r].re += x[d][r].re * k[i].re - x[d][r].im * k[i].im;
+            sum[mo][r].im += x[d][r].re * k[i].im + x[d][r].im * k[i].re;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) k[i] = n[i];
+    }
+}
+
+// emit(mo, r, v): v = coefficient lane + 64 r (mod 2^32) of sum_{m,d} digit_d(T_m) (*) BK_row[m][d][mo];
+// tsrc(m, T) fills T[r] = coefficient lane + 64 r of input polynomial m; all sources are read before
+// the first emit.
+template <int K, class TSource, class Emit>
+FF_FN void brfk_external_product(TSource &&tsrc, Emit &&emit, const cplx *row, const BrFftLdsK &lds, const FftLane &L)
+{
+    cplx *const bufs[2] = {lds.xbufA, lds.xbufB};
+    cplx sum[K + 1][8];
+#pragma unroll
+    for (int mo = 0; mo <= K; mo++)
+#pragma unroll
+        for (int r = 0; r < 8; r++) sum[mo][r] = cplx{0.0, 0.0};
+#pragma unroll
+    for (int m = 0; m <= K; m++) {
+        u32 T[16];
+        tsrc(m, T);
+        cplx x[2][8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            x[0][r] = cplx{(double)br_digit<0>(T[r]), -(double)br_digit<0>(T[r + 8])};   // a_j - i a_{j+512}
+            x[1][r] = cplx{(double)br_digit<1>(T[r]), -(double)br_digit<1>(T[r + 8])};
+        }
+        fft_forward_n<2>(x, bufs, lds.tw1, lds.tw2, L);
+        brfk_mac_pair<K>(sum, x, row, m, L.lane);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" ::: "memory");
+#endif
+    }
+    static_assert(K == 2, "pairing of the inverse transforms below is written for three polynomials");
+    {
+        cplx (&pair)[2][8] = reinterpret_cast<cplx (&)[2][8]>(sum[0]);
+        fft_inverse_n<2>(pair, bufs, lds.tw1, lds.tw2, L);
+        fft_inverse(sum[2], lds.xbufA, lds.tw1, lds.tw2, L);
+    }
+#pragma unroll
+    for (int mo = 0; mo <= K; mo++)
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            emit(mo, r, fft_round_to_u32(sum[mo][r].re));
+            emit(mo, r + 8, fft_round_to_u32(-sum[mo][r].im));
+        }
+}
+
+// One blind-rotate step on the LDS-resident accumulator: ACC += BK_row (.) ((X^a - 1) ACC)
+template <int K>
+FF_FN void brfk_step(u32 a, const cplx *row, const BrFftLdsK &lds, const FftLane &L)
+{
+    const int lane = L.lane;
+    brfk_external_product<K>(
+        [&](int m, u32 (&T)[16]) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const u32 j = (u32)(lane + 64 * r);
+                const u32 t = (j - a) & 2047u;
+                const u32 v = (u32)lds.acc[m * 1024 + (t & 1023u)];
+                const u32 self = (u32)lds.acc[m * 1024 + j];
+                T[r] = ((t & 1024u) ? 0u - v : v) - self;               // polynomials_cpu.py:46-58
+            }
+        },
+        [&](int mo, int r, u32 v) { lds.acc[mo * 1024 + lane + 64 * r] += (i32)v; }, row, lds, L);
+    WAVE_SYNC();
+}
+
+// prologue + blind rotation + load of the accumulator into registers for br_extract<K>
+template <int K>
+FF_FN void brfk_bootstrap_body(u32 (&acc)[K + 1][16], const BrSource &s0, const BrSource &s1, i32 c0, long bit,
+                               const cplx *bk, int n, i32 mu, const BrFftLdsK &lds, const FftLane &L)
+{
+    const int lane = L.lane;
+    for (int i = lane; i < n; i += 64) {
+        u32 v = 0;
+        if (s0.p) v += (u32)s0.p * (u32)s0.a[bit * s0.a_stride + i];
+        if (s1.p) v += (u32)s1.p * (u32)s1.a[bit * s1.a_stride + i];
+        *brfk_bara_slot(lds, i) = (uint16_t)br_modswitch(v);
+    }
+    u32 vb = (u32)c0;
+    if (s0.p) vb += (u32)s0.p * (u32)s0.b[bit * s0.b_stride];
+    if (s1.p) vb += (u32)s1.p * (u32)s1.b[bit * s1.b_stride];
+    const u32 barb = br_modswitch(vb);
+    // ACC = (0, ..., 0, X^(2N - barb) * mu)  (bootstrap.py:176-182)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const u32 j = (u32)(lane + 64 * r);
+        const u32 t = (j + barb) & 2047u;
+#pragma unroll
+        for (int m = 0; m < K; m++) lds.acc[m * 1024 + j] = 0;
+        lds.acc[K * 1024 + j] = (t < 1024u) ? mu : (i32)(0u - (u32)mu);
+    }
+    WAVE_SYNC();
+    for (int i = 0; i < n; i++) {
+        const u32 a = WAVE_UNIFORM((u32)*brfk_bara_slot(lds, i));
+        if (a == 0) continue;
+        brfk_step<K>(a, bk + (long)i * BK_ROW_POLYS(K) * BKF_POLY_ELEMS, lds, L);
+    }
+#pragma unroll
+    for (int m = 0; m <= K; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[m][r] = (u32)lds.acc[m * 1024 + lane + 64 * r];
+}
+
+// ------------------------------------------------------------------------------------------
 // Team variant of the FFT path (small batches): four wavefronts share one bit exactly as in
 // blind_rotate.h (brt_*): wave w = 2 m + d transforms digit d of polynomial m and multiplies it with
 // BK_row[m][d][0..1]; the partial sums meet in LDS; waves 0/1 add them in the fixed order w = 0..3,

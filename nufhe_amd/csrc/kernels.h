@@ -65,10 +65,10 @@ struct LweView {
     long a_stride, b_stride;
 };
 
-hipError_t kernels_init_device();
+hipError_t kernels_init_device(int *num_cus);
 // transform: 0 = NTT, 1 = FFT
-hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, long team_max_bits, hipStream_t stream);
-int kernels_num_cus();
+hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, long team_max_bits, int num_cus,
+                            hipStream_t stream);
 hipError_t launch_ff_op(u64 *out, const u64 *a, const u64 *b, const u64 *c, const u64 *d, const u64 *e, int op,
                         int shift, long count, hipStream_t stream);
 hipError_t launch_l4_op(u32 *out, u32 *out2, const u32 *a, const u32 *b, const u32 *c, int op, int shift, long count,

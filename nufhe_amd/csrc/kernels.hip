@@ -258,6 +258,79 @@ __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_blind_rotate_accum_fft(
         for (int r = 0; r < 16; r++) my[m * 1024 + lane + 64 * r] = (i32)acc[m][r];
 }
 
+// tlwe_mask_size = 2 with the FFT transform (blind_rotate_fft.h, brfk_*): per wave two exchange buffers
+// + the accumulator int32[3][1024] = 30 KiB.  Four waves per CU, one per SIMD: the (K+1) x 8 complex sums,
+// two transforms in flight and the pipelined key loads need more than the 256 VGPRs a second wave on
+// the SIMD would leave (a fifth wave would fit the LDS but not the register file)
+#define BRF2_WAVES 4
+#define WAVE_BRF2_LDS_BYTES (2 * WAVE_FXBUF_BYTES + 3 * 1024 * 4)
+
+__device__ __forceinline__ BrFftLdsK carve_brf2_lds(int wave)
+{
+    unsigned char *base = g_smem + FTABLE_LDS_BYTES + wave * WAVE_BRF2_LDS_BYTES;
+    BrFftLdsK lds;
+    lds.xbufA = (cplx *)base;
+    lds.xbufB = (cplx *)(base + WAVE_FXBUF_BYTES);
+    lds.acc = (i32 *)(base + 2 * WAVE_FXBUF_BYTES);
+    lds.tw1 = (const cplx *)g_smem;
+    lds.tw2 = (const cplx *)g_smem + FFT_TW1_ELEMS;
+    return lds;
+}
+
+__global__ __launch_bounds__(64 * BRF2_WAVES, 1) void k_bootstrap_fft_k2(BrLaunch P)
+{
+    load_ftables((const cplx *)P.tw_a, (const cplx *)P.tw_b);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long gbit = (long)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (gbit >= P.nbits_total) return;
+    const int job = gbit >= P.bits_per_job ? 1 : 0;
+    const long bit = gbit - (job ? P.bits_per_job : 0);
+    const BrFftLdsK lds = carve_brf2_lds(wave);
+    const FftLane L = fft_lane_init(lane);
+    u32 acc[3][16];
+    brfk_bootstrap_body<2>(acc, P.job[job].s0, P.job[job].s1, P.job[job].c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L);
+    br_extract<2>(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, acc, lane);
+}
+
+__global__ __launch_bounds__(64 * BRF2_WAVES, 1) void k_blind_rotate_accum_fft_k2(
+    i32 *__restrict__ accum, const cplx *__restrict__ bk, const i32 *__restrict__ bara, long bara_stride,
+    int row0, int n_rows, int external_mul_only, long batch, const cplx *__restrict__ tw1,
+    const cplx *__restrict__ tw2)
+{
+    load_ftables(tw1, tw2);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long bit = (long)blockIdx.x * BRF2_WAVES + wave;
+    if (bit >= batch) return;
+    const BrFftLdsK lds = carve_brf2_lds(wave);
+    const FftLane L = fft_lane_init(lane);
+    i32 *my = accum + bit * 3 * 1024;
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) lds.acc[m * 1024 + lane + 64 * r] = my[m * 1024 + lane + 64 * r];
+    WAVE_SYNC();
+    constexpr long kRow = (long)BK_ROW_POLYS(2) * BKF_POLY_ELEMS;
+    if (external_mul_only) {
+        brfk_external_product<2>(
+            [&](int m, u32(&T)[16]) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) T[r] = (u32)lds.acc[m * 1024 + lane + 64 * r];
+            },
+            [&](int mo, int r, u32 v) { lds.acc[mo * 1024 + lane + 64 * r] = (i32)v; }, bk + row0 * kRow, lds, L);
+    } else {
+        for (int i = 0; i < n_rows; i++) {
+            const u32 a = WAVE_UNIFORM((u32)bara[bit * bara_stride + i]) & 2047u;
+            if (a == 0) continue;
+            brfk_step<2>(a, bk + (row0 + i) * kRow, lds, L);
+        }
+    }
+    WAVE_SYNC();
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) my[m * 1024 + lane + 64 * r] = lds.acc[m * 1024 + lane + 64 * r];
+}
+
 #define FFT_BLOCK_THREADS 256
 #define FFT_WAVES_PER_BLOCK 4
 
@@ -744,12 +817,11 @@ static const size_t kBrfLds = brf_lds_bytes(BR_WAVES_PER_BLOCK);
 // fill a CU, so a batch that does not fill the chip is spread over as many CUs as possible (a wave
 // that has a SIMD to itself runs its 500 iterations ~1.7x sooner than two waves sharing one) and a
 // batch needing r rounds uses the smallest group size that still needs r rounds.
-static int g_num_cus = 256;
-static int br_pick_waves(long nbits, int max_waves)
+static int br_pick_waves(long nbits, int max_waves, int num_cus)
 {
-    const long per_round = (long)g_num_cus * max_waves;
+    const long per_round = (long)num_cus * max_waves;
     const long rounds = (nbits + per_round - 1) / per_round;
-    const long groups = (long)g_num_cus * rounds;
+    const long groups = (long)num_cus * rounds;
     long w = (nbits + groups - 1) / groups;
     if (w < 1) w = 1;
     if (w > max_waves) w = max_waves;
@@ -758,12 +830,15 @@ static int br_pick_waves(long nbits, int max_waves)
 static const size_t kFftLds = FTABLE_LDS_BYTES + (size_t)FFT_WAVES_PER_BLOCK * WAVE_FXBUF_BYTES;
 
 // per-device one-time setup: the fused kernels use up to ~156 KiB of dynamic LDS (> the 64 KiB default cap)
-hipError_t kernels_init_device()
+// *num_cus receives the CU count of the CURRENT device (kept per context: contexts on devices of
+// different sizes may coexist in one process)
+hipError_t kernels_init_device(int *num_cus)
 {
     int dev = 0, cus = 0;
+    *num_cus = 256;
     if (hipGetDevice(&dev) == hipSuccess &&
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-        g_num_cus = cus;
+        *num_cus = cus;
     hipError_t e = hipFuncSetAttribute((const void *)k_bootstrap<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(1));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(2));
@@ -780,10 +855,14 @@ hipError_t kernels_init_device()
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap_fft, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrfLds);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void *)k_blind_rotate_accum_fft, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrfLds);
+    e = hipFuncSetAttribute((const void *)k_blind_rotate_accum_fft, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBrfLds);
+    if (e != hipSuccess) return e;
+    const int brf2 = (int)(FTABLE_LDS_BYTES + (size_t)BRF2_WAVES * WAVE_BRF2_LDS_BYTES);
+    e = hipFuncSetAttribute((const void *)k_bootstrap_fft_k2, hipFuncAttributeMaxDynamicSharedMemorySize, brf2);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void *)k_blind_rotate_accum_fft_k2, hipFuncAttributeMaxDynamicSharedMemorySize, brf2);
 }
 
-int kernels_num_cus() { return g_num_cus; }
 
 hipError_t launch_ff_op(u64 *out, const u64 *a, const u64 *b, const u64 *c, const u64 *d, const u64 *e, int op,
                         int shift, long count, hipStream_t stream)
@@ -801,25 +880,30 @@ hipError_t launch_l4_op(u32 *out, u32 *out2, const u32 *a, const u32 *b, const u
     return hipGetLastError();
 }
 
-hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, long team_max_bits, hipStream_t stream)
+hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, long team_max_bits, int num_cus,
+                            hipStream_t stream)
 {
     if (P.nbits_total == 0) return hipSuccess;
     if (transform == 0 && mask_size == 1 && P.nbits_total <= team_max_bits) {
         // small batch: 4 waves per bit, one bit per CU at a time
         hipLaunchKernelGGL(k_bootstrap_team, dim3((unsigned)P.nbits_total), dim3(64 * BRT_WAVES), TEAM_LDS_BYTES, stream, P);
     } else if (transform == 0 && mask_size == 1) {
-        const int w = br_pick_waves(P.nbits_total, BR_WAVES_K(1));
+        const int w = br_pick_waves(P.nbits_total, BR_WAVES_K(1), num_cus);
         hipLaunchKernelGGL(k_bootstrap<1>, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), br_lds_bytes(1, w), stream, P);
     } else if (transform == 0 && mask_size == 2) {
-        const int w = br_pick_waves(P.nbits_total, BR_WAVES_K(2));
+        const int w = br_pick_waves(P.nbits_total, BR_WAVES_K(2), num_cus);
         hipLaunchKernelGGL(k_bootstrap<2>, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), br_lds_bytes(2, w), stream, P);
     } else if (transform == 1 && mask_size == 1 && P.nbits_total <= team_max_bits / 2) {
         // small batch, FFT: 4 waves per bit (one bit per CU; the wave-per-bit kernel is ahead again
         // once the batch needs a second round of teams)
         hipLaunchKernelGGL(k_bootstrap_fft_team, dim3((unsigned)P.nbits_total), dim3(64 * BRT_WAVES), TEAMF_LDS_BYTES, stream, P);
     } else if (transform == 1 && mask_size == 1) {
-        const int w = br_pick_waves(P.nbits_total, BR_WAVES_PER_BLOCK);
+        const int w = br_pick_waves(P.nbits_total, BR_WAVES_PER_BLOCK, num_cus);
         hipLaunchKernelGGL(k_bootstrap_fft, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), brf_lds_bytes(w), stream, P);
+    } else if (transform == 1 && mask_size == 2) {
+        const int w = br_pick_waves(P.nbits_total, BRF2_WAVES, num_cus);
+        hipLaunchKernelGGL(k_bootstrap_fft_k2, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w),
+                           FTABLE_LDS_BYTES + (size_t)w * WAVE_BRF2_LDS_BYTES, stream, P);
     } else
         return hipErrorInvalidValue;
     return hipGetLastError();
@@ -842,6 +926,11 @@ hipError_t launch_blind_rotate_accum(i32 *accum, const void *bk, const i32 *bara
         hipLaunchKernelGGL(k_blind_rotate_accum_fft, dim3(blocks_for(batch, BR_WAVES_PER_BLOCK)), dim3(BR_BLOCK_THREADS),
                            kBrfLds, stream, accum, (const cplx *)bk, bara, bara_stride, row0, n_rows,
                            external_mul_only, batch, (const cplx *)tw_a, (const cplx *)tw_b);
+    else if (transform == 1 && mask_size == 2)
+        hipLaunchKernelGGL(k_blind_rotate_accum_fft_k2, dim3(blocks_for(batch, BRF2_WAVES)), dim3(64 * BRF2_WAVES),
+                           FTABLE_LDS_BYTES + (size_t)BRF2_WAVES * WAVE_BRF2_LDS_BYTES, stream, accum, (const cplx *)bk,
+                           bara, bara_stride, row0, n_rows, external_mul_only, batch, (const cplx *)tw_a,
+                           (const cplx *)tw_b);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

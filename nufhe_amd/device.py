@@ -7,6 +7,7 @@ C ABI with raw pointers.
 """
 
 import ctypes
+import weakref
 
 import numpy
 import torch
@@ -57,6 +58,17 @@ class DeviceThread:
         props = torch.cuda.get_device_properties(self.device)
         self.device_params = DeviceParams(props.name, props.multi_processor_count)
         self._released = False
+        self._cloud_keys = weakref.WeakSet()     # native cloud keys living in this context (freed by release())
+
+    def check_stream(self):
+        """The library enqueues on the torch stream that was current when this object was created; torch's
+        own copies / allocations must run on the same stream to stay ordered with the kernels (and for the
+        caching allocator not to recycle a temporary a kernel still reads).  Raises if the caller switched
+        streams, e.g. inside ``with torch.cuda.stream(s):``."""
+        if torch.cuda.current_stream(self.device) != self._torch_stream:
+            raise RuntimeError(
+                "nufhe_amd: the current torch stream differs from the one this DeviceThread was created on; "
+                "create the DeviceThread (Context) inside the torch.cuda.stream(...) block that uses it")
 
     # ---- memory -------------------------------------------------------------------------
     def array(self, shape, dtype):
@@ -82,6 +94,8 @@ class DeviceThread:
 
     def release(self):
         if not self._released and self.handle:
+            for key in list(self._cloud_keys):    # ~100 MB of device memory each: free them with the context
+                key.destroy()
             _lib.lib().nufhe_ctx_destroy(self.handle)
             self._released = True
 

@@ -71,6 +71,7 @@ def _check_sizes(cloud_key, result, *args):
 def _binary_gate(thr, cloud_key, result, a, b, c, pa, pb):
     check_shape(result, a, b)
     _check_sizes(cloud_key, result, a, b)
+    thr.check_stream()
     res = _Flat(result, result.shape, output=True)
     fa = _Flat(a, result.shape)
     fb = _Flat(b, result.shape)
@@ -159,6 +160,7 @@ def gate_mux(thr, cloud_key, result, a, b, c, perf_params=None):
     """
     check_shape(result, a, b, c)
     _check_sizes(cloud_key, result, a, b, c)
+    thr.check_stream()
     res = _Flat(result, result.shape, output=True)
     fa = _Flat(a, result.shape)
     fb = _Flat(b, result.shape)

@@ -417,6 +417,7 @@ def lwe_noiseless_trivial_constant(thr: DeviceThread, result: LweSampleArray, mu
 
 
 def _linear(thr, result, source, p, add_result):
+    thr.check_stream()
     res = _Flat(result, result.shape, output=True)
     src = _Flat(source, result.shape)
     if src.size != res.size:

@@ -97,3 +97,29 @@ def record_structure(data: bytes):
         else:
             out.append((type(obj).__module__ + '.' + type(obj).__qualname__, tuple(sorted(vars(obj)))))
     return out
+
+
+def canonical_records(data: bytes):
+    """The pickle records of a stream in a form that compares by CONTENT: arrays as (dtype, shape, bytes),
+    parameter objects as (class path, sorted attributes), recursively.  Two streams with equal canonical
+    records unpickle to the same objects; their bytes may still differ in pickle memo references (e.g. a
+    parameter record that was loaded and written again no longer shares one dtype object between its
+    NumPy fields)."""
+    def canon(obj):
+        if isinstance(obj, numpy.ndarray):
+            return ('ndarray', obj.dtype.str, obj.shape, numpy.ascontiguousarray(obj).tobytes())
+        if isinstance(obj, numpy.generic):
+            return ('scalar', obj.dtype.str, obj.item())
+        if isinstance(obj, (tuple, list)):
+            return (type(obj).__name__,) + tuple(canon(x) for x in obj)
+        if isinstance(obj, dict):
+            return ('dict',) + tuple(sorted((k, canon(v)) for k, v in obj.items()))
+        if hasattr(obj, '__dict__'):
+            return (type(obj).__module__ + '.' + type(obj).__qualname__,) + tuple(
+                sorted((k, canon(v)) for k, v in vars(obj).items()))
+        return obj
+    out = []
+    file_obj = io.BytesIO(data)
+    while file_obj.tell() < len(data):
+        out.append(canon(pickle.load(file_obj)))
+    return out

@@ -248,6 +248,24 @@ void emu_bootstrap_bit_fft_team(i32 *out_a, i32 *out_b, const double *bk_interna
     });
 }
 
+// tlwe_mask_size = 2 with the FFT transform (brfk_*): out_a has 2048 entries
+void emu_bootstrap_bit_fft_k2(i32 *out_a, i32 *out_b, const double *bk_internal, int n,
+                              const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,
+                              i32 c0, i32 mu)
+{
+    ftables();
+    std::vector<cplx> xbuf(2 * FFT_XBUF_ELEMS);
+    std::vector<i32> accbuf(3 * 1024);
+    BrFftLdsK lds{xbuf.data(), xbuf.data() + FFT_XBUF_ELEMS, accbuf.data(), g_ftw1, g_ftw2};
+    BrSource s0{a0, b0, 0, 0, p0}, s1{a1, b1, 0, 0, p1};
+    emu_run_wave([&](int lane) {
+        FftLane L = fft_lane_init(lane);
+        u32 acc[3][16];
+        brfk_bootstrap_body<2>(acc, s0, s1, c0, 0, (const cplx *)bk_internal, n, mu, lds, L);
+        br_extract<2>(out_a, out_b, acc, lane);
+    });
+}
+
 void emu_bootstrap_bit_fft(i32 *out_a, i32 *out_b, const double *bk_internal, int n,
                            const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,
                            i32 c0, i32 mu)

@@ -175,3 +175,25 @@ def test_bootstrap_wave_body_mask_size_2(orc):
     ga, gb = emu.bootstrap_bit(bki, n, (a0, b0), 1, (a1, b1), 1, -MU, MU, mask_size=2)
     assert ea.shape == (1, 2048)
     assert (ga == ea[0]).all() and gb == eb[0]
+
+
+def test_bootstrap_wave_body_fft_mask_size_2(orc):
+    """tlwe_mask_size = 2 with the FFT transform (the reference runs this pair through its multi-kernel
+    driver, test/test_gates.py:88-100): the brfk_* body on a reduced number of rows of a full-range
+    int32 TGSW key == the EXACT (NTT) oracle on the same key."""
+    from oracle import oracle_fft as of
+    rs = numpy.random.RandomState(62)
+    n = 6
+    tgsw = rs.randint(-2**31, 2**31, size=(n, 3, 2, 3, 1024), dtype=numpy.int32)
+    bk_ntt = orc.tlwe_transform_samples(tgsw)                 # reference format (natural order, prepared)
+    bkf = emu.bkf_from_reference(of.fft_forward(tgsw))        # FFT key in the wave layout
+    MU = 2**29
+    a0 = rs.randint(-2**31, 2**31, size=n, dtype=numpy.int32)
+    a1 = rs.randint(-2**31, 2**31, size=n, dtype=numpy.int32)
+    b0 = rs.randint(-2**31, 2**31, size=1, dtype=numpy.int32)
+    b1 = rs.randint(-2**31, 2**31, size=1, dtype=numpy.int32)
+    ta = (a0 + a1).astype(numpy.int32); tb = (numpy.int32(-MU) + b0 + b1).astype(numpy.int32)
+    ea, eb = orc.bootstrap_extract(bk_ntt, ta[None, :], tb, MU)
+    ga, gb = emu.bootstrap_bit_fft(bkf, n, (a0, b0), 1, (a1, b1), 1, -MU, MU, mask_size=2)
+    assert ea.shape == (1, 2048)
+    assert (ga == ea[0]).all() and gb == eb[0]

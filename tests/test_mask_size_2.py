@@ -183,3 +183,96 @@ def test_gpu_k2_context_end_to_end(thr):
     assert cloud2 == cloud
     vm2 = ctx.make_virtual_machine(cloud2)
     assert (ctx.decrypt(sk, vm2.gate_and(c[0], c[1])) == (m[0] & m[1])).all()
+
+
+# ---- tlwe_mask_size = 2 with the FFT transform (test/test_gates.py:88-100: every (transform, k) pair) ----
+
+FFT_TOLERANCE_LSB = 2**4      # per output word of a gate vs the exact path (tests/test_gpu_fft.py)
+
+
+@pytest.mark.gpu
+def test_gpu_k2_fft_external_mul_vs_reference(thr, H, golden_k2, orc):
+    """TGswTransformedExternalMul with k = 2 and the FFT transform vs the reference-made k = 2 golden
+    (exact integers; the FFT path may deviate by +-1 LSB on <= 1e-4 of the coefficients)."""
+    from nufhe_amd.bootstrap import NativeCloudKey
+    from nufhe_amd.device import ptr
+    from oracle import oracle_fft as of
+    for full in (False, True):
+        accum, bk, row = gi.extmul_inputs_k2(full_range=full)
+        bkf = of.fft_forward(of.tgsw_coeffs_from_reference_bk(bk))
+        native = NativeCloudKey(thr, bk.shape[0], 'FFT', 2)
+        arr = numpy.ascontiguousarray(bkf, numpy.complex128)
+        _call("nufhe_bk_upload_reference", native.handle, arr.ctypes.data_as(ctypes.c_void_p))
+        back = numpy.empty_like(arr)
+        _call("nufhe_bk_download_reference", native.handle, back.ctypes.data_as(ctypes.c_void_p))
+        assert (back == arr).all()
+        acc = H.dev(thr, accum)
+        _call("nufhe_external_mul", thr.handle, native.handle, ptr(acc), row, accum.size // (3 * 1024))
+        ref = golden_k2['tgsw_extmul_k2' + ('_full' if full else '')]
+        delta = H.host(acc).astype(numpy.int64) - ref.astype(numpy.int64)
+        assert numpy.abs(delta).max() <= 1 and (delta != 0).mean() <= 1e-4, full
+        print("k=2 FFT external product (full range: %s): coefficients differing: %d" % (full, int((delta != 0).sum())))
+
+
+@pytest.fixture(scope='module')
+def k2_fft_env(thr, H, orc, k2_inputs):
+    import nufhe_amd
+    from oracle import oracle_fft as of
+    oparams, lwe_key, tlwe_key, ck, cts, ms = k2_inputs
+    params = nufhe_amd.NuFHEParameters(transform_type='FFT', tlwe_mask_size=2)
+    bkf = of.fft_forward(of.tgsw_coeffs_from_reference_bk(ck.bk))
+    ckf = orc.CloudKeyArrays(bkf, ck.ks_a, ck.ks_b, ck.ks_cv)
+    cloud_key = H.cloud_key_from_arrays(thr, ckf, params)
+    secret_key = H.secret_key_from_array(thr, lwe_key, params)
+    ctx = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(790), thread=thr)
+    return dict(ctx=ctx, vm=ctx.make_virtual_machine(cloud_key), sk=secret_key, params=params, ck=ck,
+                lwe_key=lwe_key, oparams=oparams, cloud_key=cloud_key)
+
+
+@pytest.mark.gpu
+def test_gpu_k2_fft_gates_vs_exact_path(k2_fft_env, thr, H, orc, golden_k2, k2_inputs):
+    """k = 2, FFT: the reference-made NAND golden (B = 2) and NAND / XOR / MUX on a ragged 37-bit batch vs
+    the exact (NTT) oracle: decrypted bits identical, every word within the FFT tolerance (observed: 0)."""
+    env = k2_fft_env
+    vm = env['vm']; params = env['params']; ck = env['ck']; lwe_key = env['lwe_key']
+    _, _, _, _, cts, ms = k2_inputs
+    d = [H.ciphertext_from_arrays(thr, c, params) for c in cts]
+    ra, rb, rcv = H.ct_arrays(vm.gate_nand(d[0], d[1]))
+
+    def dev(x, y):
+        return numpy.abs((x.astype(numpy.int64) - y.astype(numpy.int64) + 2**31) % 2**32 - 2**31).max()
+    assert dev(ra, golden_k2['nand_k2_a']) <= FFT_TOLERANCE_LSB and dev(rb, golden_k2['nand_k2_b']) <= FFT_TOLERANCE_LSB
+    assert (rcv == golden_k2['nand_k2_cv']).all()
+    rng = orc.DeterministicRNG(4568)
+    B = 37
+    msg = [rng.uniform_bool((B,)).astype(bool) for _ in range(3)]
+    cs = [orc.encrypt(rng, lwe_key, m, env['oparams']) for m in msg]
+    ds = [H.ciphertext_from_arrays(thr, c, params) for c in cs]
+    for name, got, exp, truth in (
+            ('nand', vm.gate_nand(ds[0], ds[1]), orc.gate('gate_nand', ck, cs[0], cs[1]), ~(msg[0] & msg[1])),
+            ('xor', vm.gate_xor(ds[0], ds[1]), orc.gate('gate_xor', ck, cs[0], cs[1]), msg[0] ^ msg[1]),
+            ('mux', vm.gate_mux(ds[0], ds[1], ds[2]), orc.gate_mux(ck, cs[0], cs[1], cs[2]),
+             numpy.where(msg[0], msg[1], msg[2]))):
+        ga, gb, gcv = H.ct_arrays(got)
+        assert dev(ga, exp[0]) <= FFT_TOLERANCE_LSB and dev(gb, exp[1]) <= FFT_TOLERANCE_LSB, name
+        assert (gcv == exp[2]).all(), name
+        assert (env['ctx'].decrypt(env['sk'], got) == truth).all(), name
+        print("k=2 FFT %s: words differing from the exact path: %d" % (name, int((ga != exp[0]).sum() + (gb != exp[1]).sum())))
+
+
+@pytest.mark.gpu
+def test_gpu_k2_fft_context_end_to_end(thr):
+    """Public API: Context.make_key_pair(transform_type='FFT', tlwe_mask_size=2) on the GPU, gates on 200
+    bits, serialization round trip of the key."""
+    import nufhe_amd
+    ctx = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(32), thread=thr)
+    sk, cloud = ctx.make_key_pair(transform_type='FFT', tlwe_mask_size=2)
+    vm = ctx.make_virtual_machine(cloud)
+    rs = numpy.random.RandomState(3)
+    m = [rs.randint(0, 2, size=200).astype(bool) for _ in range(3)]
+    c = [ctx.encrypt(sk, x) for x in m]
+    assert (ctx.decrypt(sk, vm.gate_nand(c[0], c[1])) == ~(m[0] & m[1])).all()
+    assert (ctx.decrypt(sk, vm.gate_xor(c[0], c[1])) == (m[0] ^ m[1])).all()
+    assert (ctx.decrypt(sk, vm.gate_mux(c[0], c[1], c[2])) == numpy.where(m[0], m[1], m[2])).all()
+    cloud2 = ctx.load_cloud_key(cloud.dumps())
+    assert cloud2 == cloud

@@ -2,10 +2,12 @@
 Reference-compatible serialization, CPU only: the record sequence, the class
 paths inside the pickles and the array formats are the reference's (nufhe/api_low_level.py:116-232,
 lwe.py:92-100,207-243,297-303, bootstrap.py:78-86, tgsw.py:116-124, tlwe.py:135-145,
-polynomials.py:72-80), checked structurally -- the reference itself cannot be imported here.
+polynomials.py:72-80): checked structurally, and against streams written by the reference's own dump
+code (tests/golden/reference_serialized, made by tests/golden/make_golden_serialization.py).
 """
 
 import io
+import os
 import pickle
 import pickletools
 
@@ -106,3 +108,63 @@ def test_import_nufhe_alias_surface():
         assert hasattr(nufhe, name), name
     import nufhe.lwe, nufhe.gates, nufhe.bootstrap, nufhe.api_low_level   # noqa: E401
     assert nufhe.lwe.LweParams is nufhe.api_low_level.LweParams
+
+
+# ---- streams written by the REFERENCE's own dump code (tests/golden/make_golden_serialization.py) ----
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_serialized')
+
+
+def _golden(name):
+    with open(os.path.join(GOLDEN_DIR, name + '.bin'), 'rb') as f:
+        return f.read()
+
+
+def test_reference_written_streams_parse_with_our_readers(orc):
+    """The bytes the reference's own NuFHESecretKey / NuFHECloudKey / LweSampleArray.dump wrote (n = 8
+    fixture) unpickle into THIS package's parameter classes through the `nufhe` alias package and carry
+    exactly the arrays the oracle generates from the same seed; our host-side writer reproduces the
+    reference's bytes."""
+    import io
+    import json
+    import pickle
+    from nufhe_amd import serialization, NuFHEParameters
+    from nufhe_amd.lwe import LweParams
+    manifest = json.load(open(os.path.join(GOLDEN_DIR, 'manifest.json')))
+    assert manifest['reference_load_reads_our_cloud_key_stream'] and manifest['our_host_writer_bytes_equal_reference_bytes']
+    n = manifest['lwe_size']
+    params = orc.Params(lwe_size=n)
+    lwe_key, tlwe_key, ck = orc.make_key_pair(orc.DeterministicRNG(2024), params)
+
+    f = io.BytesIO(_golden('secret_key'))
+    p = pickle.load(f)
+    assert type(p) is NuFHEParameters and p.in_out_params.size == n and p == NuFHEParameters()
+    kp = pickle.load(f); key = pickle.load(f)
+    assert type(kp) is LweParams and kp.size == n and (key == lwe_key).all() and f.read() == b''
+
+    f = io.BytesIO(_golden('cloud_key'))
+    p = pickle.load(f)
+    in_out, bk_params, coeffs, cv = serialization.read_bootstrap_key(f)
+    assert in_out.size == n and bk_params == p.tgsw_params
+    assert coeffs.dtype == numpy.uint64 and coeffs.shape == (n, 2, 2, 2, 1024) and (coeffs == ck.bk).all()
+    assert cv.shape == (n, 2, 2) and (cv == numpy.float32(bk_params.tlwe_params.min_noise**2)).all()
+    ksp, a, b, kcv = serialization.read_ciphertext(f)
+    assert ksp.size == n and (a == ck.ks_a).all() and (b == ck.ks_b).all() and (kcv == ck.ks_cv).all()
+    assert f.read() == b''
+    # our writer, same arrays -> the reference's records (byte-identical when the parameter object is
+    # freshly built, as the generator checks; a loaded-and-rewritten parameter record only differs in
+    # pickle memo references, hence the content comparison here)
+    out = io.BytesIO()
+    pickle.dump(p, out)
+    serialization.write_bootstrap_key(out, in_out, bk_params, coeffs, cv)
+    serialization.write_ciphertext(out, ksp, a, b, kcv)
+    assert serialization.canonical_records(out.getvalue()) == serialization.canonical_records(_golden('cloud_key'))
+    assert out.getvalue()[-2_000_000 + 300_000:] == _golden('cloud_key')[-2_000_000 + 300_000:]   # the array records
+
+    rng = orc.DeterministicRNG(77)
+    m1 = rng.uniform_bool((3, 5)).astype(bool); m2 = rng.uniform_bool((3, 5)).astype(bool)
+    assert m1.astype(int).tolist() == manifest['m1'] and m2.astype(int).tolist() == manifest['m2']
+    c1 = orc.encrypt(rng, lwe_key, m1, params); c2 = orc.encrypt(rng, lwe_key, m2, params)
+    for name, exp in (('ct1', c1), ('ct2', c2), ('nand', orc.gate('gate_nand', ck, c1, c2))):
+        cp, a, b, cv = serialization.read_ciphertext(io.BytesIO(_golden(name)))
+        assert cp.size == n and (a == exp[0]).all() and (b == exp[1]).all() and (cv == exp[2]).all()
