@@ -186,7 +186,18 @@ def main():
 
     thr = DeviceThread(local_rank)
     ctx = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(123), thread=thr)
-    secret_key, cloud_key = ctx.make_key_pair(transform_type=args.transform)   # replicated on every rank (98.6 MB)
+    # cloud-key generation on the GPU, replicated on every rank (98.6 MB): host RNG draws in
+    # the reference's order + upload + TLWE encryptions / transforms / keyswitch-key assembly in HIP kernels
+    keygen_ms = {}
+
+    def timed_key_pair(c, label, **kw):
+        thr.synchronize()
+        t_k = time.perf_counter()
+        pair = c.make_key_pair(**kw)
+        thr.synchronize()
+        keygen_ms[label] = 1e3 * (time.perf_counter() - t_k)
+        return pair
+    secret_key, cloud_key = timed_key_pair(ctx, args.transform, transform_type=args.transform)
     vm = ctx.make_virtual_machine(cloud_key)
 
     B = args.bits
@@ -285,13 +296,21 @@ def main():
             "ms_per_step_per_gpu": 1e3 * dt, "ms_per_bit": 1e3 * dt / B, "gates_per_s_per_gpu": B / dt, "correct": ok}
         other_tr = "FFT" if args.transform == "NTT" else "NTT"
         ctx_o = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(123), thread=thr)
-        sk_o, ck_o = ctx_o.make_key_pair(transform_type=other_tr)     # same secret key bits (same seed)
+        sk_o, ck_o = timed_key_pair(ctx_o, other_tr, transform_type=other_tr)     # same secret key bits (same seed)
         vm_o = ctx_o.make_virtual_machine(ck_o)
         dt = measure(lambda: vm_o.gate_nand(cs[0], cs[1], dest=out3))
         ok = bool((ctx_o.decrypt(sk_o, out3) == ~(ms[0] & ms[1])).all())
         other["gate_nand_%s" % other_tr] = {
             "ms_per_step_per_gpu": 1e3 * dt, "ms_per_bit": 1e3 * dt / B, "gates_per_s_per_gpu": B / dt, "correct": ok}
         del vm_o, ck_o
+        if world == 1:
+            ctx_k = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(123), thread=thr)
+            for tr in ("NTT", "FFT"):
+                pair = timed_key_pair(ctx_k, tr + "_k2", transform_type=tr, tlwe_mask_size=2)
+                del pair
+        other["keygen_ms"] = dict(keygen_ms, note="Context.make_key_pair wall time incl. host random numbers "
+                                  "(numpy RandomState, reference draw order) and their upload; the first entry "
+                                  "also pays the one-time kernel loading")
         if world == 1:
             # the reference's own report (test/test_gates.py:62-75,252-314): 1 warm-up + 10 calls, each
             # bracketed by a synchronize, at sizes B and B/2 -> overall / scaled ms per bit, fixed overhead

@@ -84,6 +84,21 @@ int nufhe_bk_from_coeffs(nufhe_cloudkey *key, const int32_t *d_tgsw);
  * (lwe_cpu.py:30-33); it is checked and NUFHE_EINVAL is returned otherwise. */
 int nufhe_ks_upload(nufhe_cloudkey *key, const int32_t *h_ks_a, const int32_t *h_ks_b,
                     const float *h_ks_cv);
+/* MakeLweKeyswitchKey on the device (lwe.py:265-295, lwe_gpu.py:63-124, lwe_gpu.mako:18-56;
+ * lwe_cpu.py:27-59): builds the key in the library's own layout from DEVICE arrays
+ *   d_noises_a int32 [k*1024][8][3][n]  uniform masks of the digits 1..3 (become the key's `a` as they are)
+ *   d_noises_b int32 [k*1024][8][3]     centred Gaussian noises
+ *   d_in_key   int32 [k*1024]           extracted TLWE key bits;  d_out_key int32 [n]  LWE key bits
+ * b = in_key * digit * 2^(32 - 2 (position + 1)) + noise + <mask, out_key>, variances = `variance`. */
+int nufhe_ks_make(nufhe_cloudkey *key, const int32_t *d_noises_a, const int32_t *d_noises_b,
+                  const int32_t *d_in_key, const int32_t *d_out_key, float variance);
+/* The keyswitch key back in the reference layout of nufhe_ks_upload (LweKeyswitchKey.dump). */
+int nufhe_ks_download_reference(nufhe_cloudkey *key, int32_t *h_ks_a, int32_t *h_ks_b, float *h_ks_cv);
+/* TGswAddMessage (tgsw.py:142-161, tgsw_gpu.mako:18-39; tgsw_cpu.py:109-126): d_tgsw int32
+ * [count][k+1][2][k+1][1024] on the device; adds messages[s] * 2^(32 - 10 (d + 1)) to coefficient 0 of
+ * polynomial m of row (m, d) of sample s. */
+int nufhe_tgsw_add_message(nufhe_ctx *ctx, int32_t *d_tgsw, const int32_t *d_messages, long count,
+                           int mask_size);
 
 /* ---- LWE sample descriptor: a[bit * a_stride + i], b[bit * b_stride], cv[bit * cv_stride] ---- */
 typedef struct {

@@ -49,6 +49,9 @@ PROTOTYPES = {
     "nufhe_cloudkey_create": [_vp, _int, _int, _int, _pp],
     "nufhe_ctx_set_team_max_bits": [_vp, _long],
     "nufhe_ff_op": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _long],
+    "nufhe_ks_make": [_vp, _vp, _vp, _vp, _vp, ctypes.c_float],
+    "nufhe_ks_download_reference": [_vp, _vp, _vp, _vp],
+    "nufhe_tgsw_add_message": [_vp, _vp, _vp, _long, _int],
     "nufhe_l4_op": [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _long],
     "nufhe_cloudkey_destroy": [_vp],
     "nufhe_bk_upload_reference": [_vp, _vp],

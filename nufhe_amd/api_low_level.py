@@ -143,8 +143,7 @@ class NuFHECloudKey:
         tgsw_key = TGswKey.from_rng(thr, params.tgsw_params, rng)
         bk = BootstrapKey.from_rng(thr, rng, secret_key.lwe_key, tgsw_key, native, perf_params)
         ks = LweKeyswitchKey.from_tgsw_key(
-            thr, rng, params.ks_decomp_length, params.ks_log2_base, secret_key.lwe_key, tgsw_key)
-        cls._attach_keyswitch(native, ks)
+            thr, rng, params.ks_decomp_length, params.ks_log2_base, secret_key.lwe_key, tgsw_key, native=native)
         return cls(params, bk, ks, native)
 
     def dump(self, file_obj):

@@ -390,6 +390,15 @@ int nufhe_bk_from_coeffs(nufhe_cloudkey *key, const int32_t *d_tgsw)
     return NUFHE_OK;
 }
 
+static int alloc_ks(nufhe_cloudkey *key)
+{
+    const long rows = (long)key->ext_size() * NUFHE_KS_T;
+    if (!key->d_ks_a3) HIP_TRY(hipMalloc((void **)&key->d_ks_a3, (size_t)rows * 3 * key->n * sizeof(int32_t)));
+    if (!key->d_ks_b) HIP_TRY(hipMalloc((void **)&key->d_ks_b, rows * 4 * sizeof(int32_t)));
+    if (!key->d_ks_cv) HIP_TRY(hipMalloc((void **)&key->d_ks_cv, rows * 4 * sizeof(float)));
+    return NUFHE_OK;
+}
+
 int nufhe_ks_upload(nufhe_cloudkey *key, const int32_t *h_ks_a, const int32_t *h_ks_b, const float *h_ks_cv)
 {
     if (!key || !h_ks_a || !h_ks_b || !h_ks_cv) return fail(NUFHE_EINVAL, "null argument");
@@ -409,13 +418,60 @@ int nufhe_ks_upload(nufhe_cloudkey *key, const int32_t *h_ks_a, const int32_t *h
     std::vector<int32_t> packed((size_t)rows * 3 * n);
     for (long r = 0; r < rows; r++)
         memcpy(packed.data() + (size_t)r * 3 * n, h_ks_a + ((size_t)r * 4 + 1) * n, sizeof(int32_t) * 3 * n);
-    if (!key->d_ks_a3) HIP_TRY(hipMalloc((void **)&key->d_ks_a3, packed.size() * sizeof(int32_t)));
-    if (!key->d_ks_b) HIP_TRY(hipMalloc((void **)&key->d_ks_b, rows * 4 * sizeof(int32_t)));
-    if (!key->d_ks_cv) HIP_TRY(hipMalloc((void **)&key->d_ks_cv, rows * 4 * sizeof(float)));
+    rc = alloc_ks(key);
+    if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(key->d_ks_a3, packed.data(), packed.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(key->d_ks_b, h_ks_b, rows * 4 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(key->d_ks_cv, h_ks_cv, rows * 4 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return NUFHE_OK;
+}
+
+int nufhe_ks_make(nufhe_cloudkey *key, const int32_t *d_noises_a, const int32_t *d_noises_b, const int32_t *d_in_key,
+                  const int32_t *d_out_key, float variance)
+{
+    if (!key || !d_noises_a || !d_noises_b || !d_in_key || !d_out_key) return fail(NUFHE_EINVAL, "null argument");
+    nufhe_ctx *ctx = key->ctx;
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    rc = alloc_ks(key);
+    if (rc) return rc;
+    const long rows = (long)key->ext_size() * NUFHE_KS_T * 3;
+    // the masks are the key's `a` as they are: one device-to-device copy into the key's own storage
+    HIP_TRY(hipMemcpyAsync(key->d_ks_a3, d_noises_a, (size_t)rows * key->n * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                           ctx->stream));
+    HIP_TRY(launch_ks_make(key->d_ks_b, key->d_ks_cv, key->d_ks_a3, d_noises_b, d_in_key, d_out_key, variance, rows,
+                           key->n, ctx->stream));
+    return NUFHE_OK;
+}
+
+int nufhe_ks_download_reference(nufhe_cloudkey *key, int32_t *h_ks_a, int32_t *h_ks_b, float *h_ks_cv)
+{
+    if (!key || !h_ks_a || !h_ks_b || !h_ks_cv) return fail(NUFHE_EINVAL, "null argument");
+    nufhe_ctx *ctx = key->ctx;
+    int rc = check_key(ctx, key, false, true);
+    if (rc) return rc;
+    const long groups = (long)key->ext_size() * NUFHE_KS_T;
+    const size_t bytes = (size_t)groups * 4 * key->n * sizeof(int32_t);
+    int32_t *tmp = nullptr;
+    HIP_TRY(hipMalloc((void **)&tmp, bytes));
+    hipError_t e = launch_ks_to_reference(tmp, key->d_ks_a3, groups, key->n, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_ks_a, tmp, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_ks_b, key->d_ks_b, groups * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_ks_cv, key->d_ks_cv, groups * 4 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(tmp);
+    if (e != hipSuccess) return fail(NUFHE_EHIP, "ks download: %s", hipGetErrorString(e));
+    return NUFHE_OK;
+}
+
+int nufhe_tgsw_add_message(nufhe_ctx *ctx, int32_t *d_tgsw, const int32_t *d_messages, long count, int mask_size)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!d_tgsw || !d_messages) return fail(NUFHE_EINVAL, "null argument");
+    if (count < 0 || mask_size < 1) return fail(NUFHE_EINVAL, "bad sizes");
+    HIP_TRY(launch_tgsw_add_message(d_tgsw, d_messages, count, mask_size, ctx->stream));
     return NUFHE_OK;
 }
 

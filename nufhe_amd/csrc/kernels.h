@@ -71,6 +71,10 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, lon
                             hipStream_t stream);
 hipError_t launch_ff_op(u64 *out, const u64 *a, const u64 *b, const u64 *c, const u64 *d, const u64 *e, int op,
                         int shift, long count, hipStream_t stream);
+hipError_t launch_ks_make(i32 *ks_b, float *ks_cv, const i32 *noises_a, const i32 *noises_b, const i32 *in_key,
+                          const i32 *out_key, float variance, long rows, int n, hipStream_t stream);
+hipError_t launch_ks_to_reference(i32 *out_a, const i32 *ks_a3, long groups, int n, hipStream_t stream);
+hipError_t launch_tgsw_add_message(i32 *tgsw, const i32 *messages, long count, int mask_size, hipStream_t stream);
 hipError_t launch_l4_op(u32 *out, u32 *out2, const u32 *a, const u32 *b, const u32 *c, int op, int shift, long count,
                         hipStream_t stream);
 hipError_t launch_blind_rotate_accum(i32 *accum, const void *bk, const i32 *bara, long bara_stride, int row0,

@@ -717,6 +717,56 @@ __global__ __launch_bounds__(256) void k_lwe_phase(i32 *__restrict__ out, long o
     if (lane == 0) out[i * out_stride] = (i32)((u32)base[i * base_stride] + (u32)sign * acc);
 }
 
+// MakeLweKeyswitchKey (lwe_gpu.mako:18-56, lwe_cpu.py:27-59) on the device, straight into the library's
+// key layout.  Row r = (j, k, h - 1), j < ext_size, k < 8, h = 1..3; the uniform masks noises_a
+// [rows][n] ARE the key's `a` (digits 1..3, the base-0 slice is all zero and is not stored);
+//   b[j][k][h] = in_key[j] * h * 2^(32 - 2 (k + 1)) + noises_b[r] + <noises_a[r], out_key>
+//   cv[j][k][h] = variance;  b[j][k][0] = cv[j][k][0] = 0.       One wave per row.
+__global__ __launch_bounds__(256) void k_ks_make(i32 *__restrict__ ks_b, float *__restrict__ ks_cv,
+                                                 const i32 *__restrict__ noises_a, const i32 *__restrict__ noises_b,
+                                                 const i32 *__restrict__ in_key, const i32 *__restrict__ out_key,
+                                                 float variance, long rows, int n)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + wave;
+    if (r >= rows) return;
+    u32 acc = 0;
+    for (int i = lane; i < n; i += 64) acc += (u32)noises_a[r * n + i] * (u32)out_key[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += (u32)__shfl_xor((int)acc, off, 64);
+    if (lane == 0) {
+        const long jk = r / 3;
+        const int h = (int)(r % 3) + 1, k = (int)(jk % 8);
+        const long j = jk / 8;
+        const u32 message = (u32)in_key[j] * (u32)h * (1u << (32 - 2 * (k + 1)));      // lwe_cpu.py:54
+        ks_b[jk * 4 + h] = (i32)(message + (u32)noises_b[r] + acc);
+        ks_cv[jk * 4 + h] = variance;
+        if (h == 1) { ks_b[jk * 4] = 0; ks_cv[jk * 4] = 0.0f; }
+    }
+}
+
+// keyswitch key, library layout -> reference layout a [rows/3][4][n] (base-0 slice zero-filled)
+__global__ void k_ks_to_reference(i32 *__restrict__ out_a, const i32 *__restrict__ ks_a3, long groups, int n)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= groups * 4 * n) return;
+    const int i = (int)(t % n), h = (int)((t / n) % 4);
+    const long g = t / ((long)4 * n);
+    out_a[t] = h == 0 ? 0 : ks_a3[(g * 3 + (h - 1)) * n + i];
+}
+
+// TGswAddMessage (tgsw_gpu.mako:18-39, tgsw_cpu.py:109-126): TGSW sample s of shape [k+1][l = 2][k+1][1024];
+// coefficient 0 of polynomial m of row (m, d) += message[s] * 2^(32 - 10 (d + 1))
+__global__ void k_tgsw_add_message(i32 *__restrict__ tgsw, const i32 *__restrict__ messages, long count, int k1)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count * k1 * 2) return;
+    const int d = (int)(t % 2), m = (int)((t / 2) % k1);
+    const long s = t / (2 * k1);
+    i32 *p = tgsw + (((s * k1 + m) * 2 + d) * k1 + m) * 1024;
+    p[0] = (i32)((u32)p[0] + (u32)messages[s] * (1u << (32 - 10 * (d + 1))));
+}
+
 // Torus32ToPhase, numeric_functions_cpu.py:23-37
 __global__ void k_t32_to_phase(i32 *__restrict__ result, const i32 *__restrict__ phase, long count, u32 interv)
 {
@@ -1066,6 +1116,32 @@ hipError_t launch_lwe_phase(i32 *out, long out_stride, const i32 *a, long a_stri
     if (count == 0) return hipSuccess;
     hipLaunchKernelGGL(k_lwe_phase, dim3(blocks_for(count, 4)), dim3(256), 0, stream, out, out_stride, a, a_stride,
                        base, base_stride, key, sign, count, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_ks_make(i32 *ks_b, float *ks_cv, const i32 *noises_a, const i32 *noises_b, const i32 *in_key,
+                          const i32 *out_key, float variance, long rows, int n, hipStream_t stream)
+{
+    if (rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ks_make, dim3(blocks_for(rows, 4)), dim3(256), 0, stream, ks_b, ks_cv, noises_a, noises_b,
+                       in_key, out_key, variance, rows, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_ks_to_reference(i32 *out_a, const i32 *ks_a3, long groups, int n, hipStream_t stream)
+{
+    if (groups == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ks_to_reference, dim3(blocks_for(groups * 4 * n, 256)), dim3(256), 0, stream, out_a, ks_a3,
+                       groups, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_tgsw_add_message(i32 *tgsw, const i32 *messages, long count, int mask_size, hipStream_t stream)
+{
+    if (count == 0) return hipSuccess;
+    const int k1 = mask_size + 1;
+    hipLaunchKernelGGL(k_tgsw_add_message, dim3(blocks_for(count * k1 * 2, 256)), dim3(256), 0, stream, tgsw, messages,
+                       count, k1);
     return hipGetLastError();
 }
 

@@ -261,59 +261,65 @@ class _Flat:
 
 class LweKeyswitchKey:
     """
-    nufhe/lwe.py:254-308.  ``lwe`` holds the key in the reference layout
-    (a [N*k, t, base, n], b / current_variances [N*k, t, base]) as host arrays; the device copy lives
-    in the native cloud-key handle (digits 1..3 only -- the base-0 slice is all zeros).
+    nufhe/lwe.py:254-308.  The key lives on the device inside the native cloud-key handle, in the
+    library's own layout (digits 1..3 only -- the base-0 slice is all zeros).  ``lwe`` is the key in the
+    reference layout (a [N*k, t, base, n], b / current_variances [N*k, t, base]) as host arrays: given
+    at construction for keys that come from a stream, downloaded on first use (dump, comparison) for
+    keys generated on the device.
     """
 
-    def __init__(self, lwe):
-        input_size, decomp_length, base = lwe.shape
-        self.lwe = lwe
+    def __init__(self, lwe=None, native=None, params=None, shape=None):
+        if lwe is not None:
+            params, shape = lwe.params, lwe.shape
+        input_size, decomp_length, base = shape
+        self._lwe = lwe
+        self._params = params
+        self._native = native
         self.input_size = input_size
-        self.output_size = lwe.params.size
+        self.output_size = params.size
         self.decomp_length = decomp_length
         self.log2_base = int(numpy.log2(base))
-        self._native = None
+
+    @property
+    def lwe(self):
+        if self._lwe is None:
+            shape = (self.input_size, self.decomp_length, 2**self.log2_base)
+            a = numpy.empty(shape + (self.output_size,), Torus32)
+            b = numpy.empty(shape, Torus32)
+            cv = numpy.empty(shape, ErrorFloat)
+            _lib.call("nufhe_ks_download_reference", self._native.handle, a.ctypes.data, b.ctypes.data, cv.ctypes.data)
+            self._lwe = HostLweSampleArray(self._params, a, b, cv)
+        return self._lwe
 
     @classmethod
-    def from_tgsw_key(cls, thr, rng, ks_decomp_length: int, ks_log2_base: int, lwe_key: LweKey, tgsw_key):
-        """Host-side MakeLweKeyswitchKey (lwe_cpu.py:27-59) in the reference's RNG order
-        (lwe.py:285-288): centred Gaussian noises first, then the uniform masks."""
+    def from_tgsw_key(cls, thr, rng, ks_decomp_length: int, ks_log2_base: int, lwe_key: LweKey, tgsw_key,
+                      native=None):
+        """MakeLweKeyswitchKey (lwe.py:265-295, lwe_cpu.py:27-59) on the device: the random numbers are
+        drawn on the host in the reference's order (lwe.py:285-288: centred Gaussian noises first, then
+        the uniform masks) and uploaded ONCE; messages, noise and the <mask, key> products are combined
+        by nufhe_ks_make straight into the cloud key's storage."""
+        if native is None:
+            raise ValueError("a native cloud key (NativeCloudKey) is needed to hold the keyswitch key")
+        if ks_decomp_length != 8 or ks_log2_base != 2:
+            raise ValueError("the gfx950 keyswitch kernels support ks_decomp_length=8, ks_log2_base=2")
         accum_params = tgsw_key.params.tlwe_params
         extract_params = accum_params.extracted_lweparams
-        in_key = to_numpy(LweKey.from_tlwe_key(extract_params, tgsw_key.tlwe_key).key).astype(Torus32)
-        out_key = to_numpy(lwe_key.key).astype(Torus32)
-
-        input_size = in_key.size
-        output_size = out_key.size
+        in_key = LweKey.from_tlwe_key(extract_params, tgsw_key.tlwe_key).key.contiguous()
+        out_key = lwe_key.key.contiguous()
+        input_size = in_key.shape[0]
+        output_size = out_key.shape[0]
         noise = lwe_key.params.min_noise
         base = 2**ks_log2_base
 
         noises_b = rand_gaussian_torus32_host(
             rng, 0, noise, (input_size, ks_decomp_length, base - 1), centered=True)
         noises_a = rng.uniform_torus32((input_size, ks_decomp_length, base - 1, output_size))
-
-        ks_a = numpy.zeros((input_size, ks_decomp_length, base, output_size), Torus32)
-        ks_b = numpy.zeros((input_size, ks_decomp_length, base), Torus32)
-        ks_cv = numpy.zeros((input_size, ks_decomp_length, base), ErrorFloat)
-
-        hs = numpy.arange(1, base).astype(numpy.uint32)[None, None, :]
-        js = numpy.arange(ks_decomp_length)[None, :, None]
-        scale = (numpy.uint32(1) << (32 - (js + 1) * ks_log2_base).astype(numpy.uint32))
-        messages = in_key.astype(numpy.uint32)[:, None, None] * hs * scale          # lwe_cpu.py:54
-        # <noises_a, out_key> on the GPU (the body of MakeLweKeyswitchKey, lwe_gpu.mako:18-56)
-        na_dev = thr.to_device(noises_a).reshape(-1, output_size)
-        zero_dev = thr.zeros((na_dev.shape[0],), Torus32)
-        dots_dev = thr.array((na_dev.shape[0],), Torus32)
-        _lib.call("nufhe_lwe_phase", thr.handle, ptr(dots_dev), 1, ptr(na_dev), output_size, ptr(zero_dev), 1,
-                  ptr(lwe_key.key.contiguous()), 1, na_dev.shape[0], output_size)
-        dots = to_numpy(dots_dev).view(numpy.uint32).reshape(noises_b.shape)
-        del na_dev
-        ks_a[:, :, 1:, :] = noises_a                                                 # lwe_cpu.py:35
-        ks_b[:, :, 1:] = (messages + noises_b.astype(numpy.uint32) + dots).astype(numpy.uint32).view(Torus32)
-        ks_cv[:, :, 1:] = noise**2                                                   # lwe_cpu.py:37
-
-        return cls(HostLweSampleArray(lwe_key.params, ks_a, ks_b, ks_cv))
+        d_noises_a = thr.to_device(noises_a)
+        d_noises_b = thr.to_device(noises_b)
+        _lib.call("nufhe_ks_make", native.handle, ptr(d_noises_a), ptr(d_noises_b), ptr(in_key), ptr(out_key),
+                  float(numpy.float32(noise**2)))
+        thr.synchronize()            # the uploads may be released
+        return cls(native=native, params=lwe_key.params, shape=(input_size, ks_decomp_length, base))
 
     def dump(self, file_obj):
         self.lwe.dump(file_obj)

@@ -5,6 +5,8 @@ bootstrap-key generation (tgsw_add_message, tgsw.py:142-161 / tgsw_cpu.py:109-12
 
 import numpy
 
+from . import _lib
+from .device import ptr
 from .numeric_functions import Torus32
 from .tlwe import TLweParams, TLweKey, tlwe_encrypt_zero
 
@@ -59,9 +61,9 @@ def tgsw_encrypt_int(thr, rng, messages, noise: float, key: TGswKey):
     k1 = params.tlwe_params.mask_size + 1
     l = params.decomp_length
     shape = tuple(messages.shape)
+    if l != 2 or params.bs_log2_base != 10:
+        raise ValueError("the gfx950 kernels support bs_decomp_length=2, bs_log2_base=10")
     result = tlwe_encrypt_zero(thr, rng, shape + (k1, l), noise, key.tlwe_key)
-    base_powers = thr.to_device(params.base_powers)                  # [l]
-    inc = messages.reshape(shape + (1,)).to(base_powers.dtype) * base_powers   # int32 wraparound
-    for m in range(k1):
-        result[..., m, :, m, 0] += inc
+    count = int(numpy.prod(shape)) if len(shape) else 1
+    _lib.call("nufhe_tgsw_add_message", thr.handle, ptr(result), ptr(messages.contiguous()), count, k1 - 1)
     return result
