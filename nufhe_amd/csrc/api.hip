@@ -49,6 +49,7 @@ struct nufhe_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     u64 *d_tw1f = nullptr;
+    u64 *d_tw1x = nullptr;    // forward table permuted for the limb-form transform (ntt_make_tw1x)
     u64 *d_tw1i = nullptr;
     cplx *d_ftw1 = nullptr;
     cplx *d_ftw2 = nullptr;
@@ -201,7 +202,11 @@ int nufhe_ctx_create(int device, void *stream, int own_stream, nufhe_ctx **out)
     }
     std::vector<u64> f(1024), i(1024);
     ntt_make_tables(f.data(), i.data());
+    std::vector<u64> fx(1024);
+    ntt_make_tw1x(fx.data(), f.data());
     hipError_t e = hipMalloc((void **)&ctx->d_tw1f, 1024 * sizeof(u64));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_tw1x, 1024 * sizeof(u64));
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_tw1x, fx.data(), 1024 * sizeof(u64), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_tw1i, 1024 * sizeof(u64));
     if (e == hipSuccess) e = hipMemcpy(ctx->d_tw1f, f.data(), 1024 * sizeof(u64), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ctx->d_tw1i, i.data(), 1024 * sizeof(u64), hipMemcpyHostToDevice);
@@ -227,6 +232,7 @@ int nufhe_ctx_destroy(nufhe_ctx *ctx)
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     if (ctx->d_tw1f) hipFree(ctx->d_tw1f);
+    if (ctx->d_tw1x) hipFree(ctx->d_tw1x);
     if (ctx->d_tw1i) hipFree(ctx->d_tw1i);
     if (ctx->d_ftw1) hipFree(ctx->d_ftw1);
     if (ctx->d_ftw2) hipFree(ctx->d_ftw2);
@@ -511,7 +517,7 @@ static int run_gate(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result
     P.n = key->n;
     P.mu = mu;
     const bool fft = key->transform == NUFHE_TRANSFORM_FFT;
-    P.tw_a = fft ? (const void *)ctx->d_ftw1 : (const void *)ctx->d_tw1f;
+    P.tw_a = fft ? (const void *)ctx->d_ftw1 : (const void *)ctx->d_tw1x;
     P.tw_b = fft ? (const void *)ctx->d_ftw2 : (const void *)ctx->d_tw1i;
     if (keyswitch) {
         const int ext = key->ext_size();
@@ -726,7 +732,7 @@ int nufhe_external_mul(nufhe_ctx *ctx, nufhe_cloudkey *key, int32_t *d_accum, in
     if (bk_row < 0 || bk_row >= key->n) return fail(NUFHE_EINVAL, "bk_row %d out of range", bk_row);
     const bool fft = key->transform == NUFHE_TRANSFORM_FFT;
     HIP_TRY(launch_blind_rotate_accum(d_accum, key->d_bk, nullptr, 0, bk_row, 1, 1, batch,
-                                      fft ? (const void *)ctx->d_ftw1 : (const void *)ctx->d_tw1f,
+                                      fft ? (const void *)ctx->d_ftw1 : (const void *)ctx->d_tw1x,
                                       fft ? (const void *)ctx->d_ftw2 : (const void *)ctx->d_tw1i, key->transform,
                                       key->mask_size, ctx->stream));
     return NUFHE_OK;
@@ -740,7 +746,7 @@ int nufhe_blind_rotate(nufhe_ctx *ctx, nufhe_cloudkey *key, int32_t *d_accum, co
     if (n_rows < 0 || n_rows > key->n) return fail(NUFHE_EINVAL, "n_rows %d out of range", n_rows);
     const bool fft = key->transform == NUFHE_TRANSFORM_FFT;
     HIP_TRY(launch_blind_rotate_accum(d_accum, key->d_bk, d_bara, bara_stride, 0, n_rows, 0, batch,
-                                      fft ? (const void *)ctx->d_ftw1 : (const void *)ctx->d_tw1f,
+                                      fft ? (const void *)ctx->d_ftw1 : (const void *)ctx->d_tw1x,
                                       fft ? (const void *)ctx->d_ftw2 : (const void *)ctx->d_tw1i, key->transform,
                                       key->mask_size, ctx->stream));
     return NUFHE_OK;

@@ -60,7 +60,7 @@ struct BrLds {
     u64 *xbuf;         // NTT exchange buffer, NTT_XBUF_ELEMS u64
     i32 *acc;          // [K+1][1024] accumulator mirror for rotated reads
     uint16_t *bara;    // [BR_MAX_LWE]
-    const u64 *tw1f;   // [1024]
+    const u64 *tw1x;   // [1024] forward table in the layout of ntt_make_tw1x (limb-form transform)
     const u64 *tw1i;   // [1024]
 };
 
@@ -121,27 +121,37 @@ FF_FN void br_mac(u64 (&sum)[K + 1][16], const u64 (&x)[16], const u64 *poly, in
 // once, sum[mo] (+)= x0 (*) BK[m][0][mo] + x1 (*) BK[m][1][mo] with one reduction per pair of products
 // (ff_dot2).  FIRST: the sums are assigned, not accumulated.  poly = BK_row[m][0][0]; the d = 1
 // polynomials follow K + 1 polynomials later.  Key loads run one step ahead, as in br_mac.
+// BR_KEY_DEPTH key-load steps are kept in flight ahead of the multiplication that consumes them
+#ifndef BR_KEY_DEPTH
+#define BR_KEY_DEPTH 1
+#endif
+
 template <int K, bool FIRST>
 FF_FN void br_mac2(u64 (&sum)[K + 1][16], const u64 (&x0)[16], const u64 (&x1)[16], const u64 *poly, int lane)
 {
+    constexpr int STEPS = 8 * (K + 1), D = BR_KEY_DEPTH;
     const u64 *p = poly + lane * 2;
     const u64 *pd = p + (K + 1) * BK_POLY_ELEMS;
-    u64 k00 = p[0], k01 = p[1], k10 = pd[0], k11 = pd[1];
+    auto off = [](int t) { return (t >> 3) * BK_POLY_ELEMS + (t & 7) * 128; };
+    u64 q[D + 1][4];                      // ring of pending steps: q[i] belongs to step t + i
 #pragma unroll
-    for (int t = 0; t < 8 * (K + 1); t++) {
+    for (int i = 0; i < D; i++) {
+        q[i][0] = p[off(i)]; q[i][1] = p[off(i) + 1]; q[i][2] = pd[off(i)]; q[i][3] = pd[off(i) + 1];
+    }
+#pragma unroll
+    for (int t = 0; t < STEPS; t++) {
         const int mo = t >> 3, h = t & 7;
-        u64 n00 = 0, n01 = 0, n10 = 0, n11 = 0;
-        if (t + 1 < 8 * (K + 1)) {
-            const int off = ((t + 1) >> 3) * BK_POLY_ELEMS + ((t + 1) & 7) * 128;
-            n00 = p[off];
-            n01 = p[off + 1];
-            n10 = pd[off];
-            n11 = pd[off + 1];
+        if (t + D < STEPS) {
+            const int o = off(t + D);
+            q[D][0] = p[o]; q[D][1] = p[o + 1]; q[D][2] = pd[o]; q[D][3] = pd[o + 1];
             BR_ISSUE_FENCE();
         }
-        sum[mo][2 * h] = ff_dot2<!FIRST>(x0[2 * h], k00, x1[2 * h], k10, sum[mo][2 * h]);
-        sum[mo][2 * h + 1] = ff_dot2<!FIRST>(x0[2 * h + 1], k01, x1[2 * h + 1], k11, sum[mo][2 * h + 1]);
-        k00 = n00; k01 = n01; k10 = n10; k11 = n11;
+        sum[mo][2 * h] = ff_dot2<!FIRST>(x0[2 * h], q[0][0], x1[2 * h], q[0][2], sum[mo][2 * h]);
+        sum[mo][2 * h + 1] = ff_dot2<!FIRST>(x0[2 * h + 1], q[0][1], x1[2 * h + 1], q[0][3], sum[mo][2 * h + 1]);
+#pragma unroll
+        for (int i = 0; i < D; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) q[i][j] = q[i + 1][j];
     }
 }
 
@@ -152,23 +162,27 @@ template <int K>
 FF_FN void br_mac2_l4(L4 (&out)[16], const u64 (&prev)[16], const u64 (&x0)[16], const u64 (&x1)[16],
                       const u64 *poly, int lane)
 {
+    constexpr int D = BR_KEY_DEPTH;
     const u64 *p = poly + lane * 2;
     const u64 *pd = p + (K + 1) * BK_POLY_ELEMS;
-    u64 k00 = p[0], k01 = p[1], k10 = pd[0], k11 = pd[1];
+    u64 q[D + 1][4];
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        q[i][0] = p[i * 128]; q[i][1] = p[i * 128 + 1]; q[i][2] = pd[i * 128]; q[i][3] = pd[i * 128 + 1];
+    }
 #pragma unroll
     for (int h = 0; h < 8; h++) {
-        u64 n00 = 0, n01 = 0, n10 = 0, n11 = 0;
-        if (h + 1 < 8) {
-            const int off = (h + 1) * 128;
-            n00 = p[off];
-            n01 = p[off + 1];
-            n10 = pd[off];
-            n11 = pd[off + 1];
+        if (h + D < 8) {
+            const int o = (h + D) * 128;
+            q[D][0] = p[o]; q[D][1] = p[o + 1]; q[D][2] = pd[o]; q[D][3] = pd[o + 1];
             BR_ISSUE_FENCE();
         }
-        l4_dot2<true>(out[2 * h], x0[2 * h], k00, x1[2 * h], k10, prev[2 * h]);
-        l4_dot2<true>(out[2 * h + 1], x0[2 * h + 1], k01, x1[2 * h + 1], k11, prev[2 * h + 1]);
-        k00 = n00; k01 = n01; k10 = n10; k11 = n11;
+        l4_dot2<true>(out[2 * h], x0[2 * h], q[0][0], x1[2 * h], q[0][2], prev[2 * h]);
+        l4_dot2<true>(out[2 * h + 1], x0[2 * h + 1], q[0][1], x1[2 * h + 1], q[0][3], prev[2 * h + 1]);
+#pragma unroll
+        for (int i = 0; i < D; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) q[i][j] = q[i + 1][j];
     }
 }
 
@@ -190,24 +204,15 @@ FF_FN void br_external_product(TSource &&tsrc, Emit &&emit, const u64 *row, cons
 {
     const int lane = L.lane;
     auto digits_forward = [&](int m, u64(&x0)[16], u64(&x1)[16]) {
-        // the source polynomial is fetched once per digit (32 LDS reads) instead of being held in 16
-        // registers across a transform: the kernel sits at the 256-VGPR limit of 2 waves per SIMD
+        u32 T[16];
+        tsrc(m, T);
         i32 dg[16];
-        {
-            u32 T[16];
-            tsrc(m, T);
 #pragma unroll
-            for (int r = 0; r < 16; r++) dg[r] = br_digit<0>(T[r]);
-        }
-        ntt_forward_small_l4(x0, dg, lds.xbuf, lds.tw1f, L);
-        {
-            u32 T[16];
-            tsrc(m, T);
-            BR_ISSUE_FENCE();
+        for (int r = 0; r < 16; r++) dg[r] = br_digit<0>(T[r]);
+        ntt_forward_small_l4(x0, dg, lds.xbuf, lds.tw1x, L);
 #pragma unroll
-            for (int r = 0; r < 16; r++) dg[r] = br_digit<1>(T[r]);
-        }
-        ntt_forward_small_l4(x1, dg, lds.xbuf, lds.tw1f, L);
+        for (int r = 0; r < 16; r++) dg[r] = br_digit<1>(T[r]);
+        ntt_forward_small_l4(x1, dg, lds.xbuf, lds.tw1x, L);
     };
     auto finish = [&](int mo, u32(&c)[16]) {
         // coefficients j2 >= 1 come back negated (ntt_inverse_l4_core)
@@ -362,7 +367,7 @@ struct BrTeamLds {
     i32 *acc;          // [2][1024] accumulator, shared by the team (the only copy during the loop)
     uint16_t *bara;    // [BR_MAX_LWE], shared
     u64 *part;         // [BRT_PART_ELEMS], shared
-    const u64 *tw1f;
+    const u64 *tw1x;
     const u64 *tw1i;
 };
 
@@ -384,7 +389,7 @@ FF_FN void brt_step(u32 a, const u64 *row, const BrTeamLds &lds, const NttLane &
         dg[r] = (((i32)(T + TGSW_OFFSET) >> sh) & 1023) - 512;
     }
     u64 x[16];
-    ntt_forward_small_l4(x, dg, lds.xbuf, lds.tw1f, L);
+    ntt_forward_small_l4(x, dg, lds.xbuf, lds.tw1x, L);
     u64 ps[2][16];
 #pragma unroll
     for (int mo = 0; mo < 2; mo++)

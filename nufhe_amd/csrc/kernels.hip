@@ -12,7 +12,7 @@
 // ------------------------------------------------------------------------------------------
 // LDS carving
 // ------------------------------------------------------------------------------------------
-// [0, 8 KiB)   tw1f     [8 KiB, 16 KiB)  tw1i      then one region per wave:
+// [0, 8 KiB)   tw1f (tw1x for the blind-rotation kernels)     [8 KiB, 16 KiB)  tw1i      then one region per wave:
 //   xbuf (8704 B) | acc mirror (8192 B) | bara (1024 B)            = 17920 B
 #define TABLE_LDS_BYTES (2 * 1024 * 8)
 #define WAVE_XBUF_BYTES (NTT_XBUF_ELEMS * 8)
@@ -44,7 +44,7 @@ __device__ __forceinline__ BrLds carve_br_lds(int wave)
     lds.xbuf = (u64 *)base;
     lds.acc = (i32 *)(base + WAVE_XBUF_BYTES);
     lds.bara = (uint16_t *)(base + WAVE_XBUF_BYTES + WAVE_ACC_BYTES_K(K));
-    lds.tw1f = (const u64 *)g_smem;
+    lds.tw1x = (const u64 *)g_smem;
     lds.tw1i = (const u64 *)g_smem + 1024;
     return lds;
 }
@@ -64,6 +64,11 @@ __global__ __launch_bounds__(64 * BR_WAVES_K(K), 2) void k_bootstrap(BrLaunch P)
 
     const BrLds lds = carve_br_lds<K>(wave);
     const NttLane L = ntt_lane_init(lane);
+#if defined(BR_SETPRIO)
+    // the two waves that share a SIMD (w and w + 4) run the same instruction stream: give one of them
+    // priority so that they drift apart and one computes while the other waits for LDS / key data
+    if (wave & 4) __builtin_amdgcn_s_setprio(BR_SETPRIO);
+#endif
     const u32 barb = br_prologue(P.job[job].s0, P.job[job].s1, P.job[job].c0, bit, P.n, lds, lane);
     WAVE_SYNC();
     u32 acc[K + 1][16];
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(64 * BRT_WAVES, 1) void k_bootstrap_team(BrLaunch P
     lds.bara = (uint16_t *)(base + 2 * 1024 * 4);
     lds.part = (u64 *)(base + 2 * 1024 * 4 + WAVE_BARA_BYTES);
     lds.xbuf = (u64 *)(base + 2 * 1024 * 4 + WAVE_BARA_BYTES + BRT_PART_ELEMS * 8 + wave * WAVE_XBUF_BYTES);
-    lds.tw1f = (const u64 *)g_smem;
+    lds.tw1x = (const u64 *)g_smem;
     lds.tw1i = (const u64 *)g_smem + 1024;
     const NttLane L = ntt_lane_init(lane);
     brt_bootstrap(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, P.job[job].s0, P.job[job].s1,

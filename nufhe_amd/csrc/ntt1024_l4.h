@@ -118,9 +118,14 @@ FF_FN void l4_mul_pow2_lane(L4 &x, u32 lo)
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS exchanges: an element is 16 bytes, the per-wave buffer of ntt1024.h holds 8 per slot, so every
-// exchange runs in two rounds (limbs 0-1, then limbs 2-3) over the same conflict-free addresses.
+// LDS exchanges.  Exchange 1 sits next to the general multiplication, which needs a packed 64-bit operand
+// anyway: the elements cross as 8-byte representatives in one round (see the transforms below).  Exchange
+// 2 moves limbs (16 bytes per element); the per-wave buffer of ntt1024.h holds 8 bytes per slot, so it
+// runs in two rounds (limbs 0-1, then limbs 2-3) over the same conflict-free addresses.
 // ---------------------------------------------------------------------------------------------
+#ifndef L4_EXCH_ROUNDS
+#define L4_EXCH_ROUNDS 2      /* 1 = timing experiment only (drops limbs 2-3: wrong results) */
+#endif
 FF_FN u64 l4_pair(const L4 &x, int h) { return ((u64)x.w[2 * h + 1] << 32) | x.w[2 * h]; }
 FF_FN void l4_set_pair(L4 &x, int h, u64 v)
 {
@@ -128,25 +133,11 @@ FF_FN void l4_set_pair(L4 &x, int h, u64 v)
     x.w[2 * h + 1] = (u32)(v >> 32);
 }
 
-// exchange 1 forward: x[i] = value of k2 = br4(i) at lane j1 -> y[r] = value (k2 = lane >> 2, j1 = (lane & 3) + 4 r)
-FF_FN void l4_exchange1_fwd(L4 (&x)[16], u64 *xbuf, const NttLane &L)
-{
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) xbuf[L.x1w + br4(i) * NTT_ROW] = l4_pair(x[i], h);
-        WAVE_SYNC();
-#pragma unroll
-        for (int r = 0; r < 16; r++) l4_set_pair(x[r], h, xbuf[L.x1r + 4 * r]);
-        WAVE_SYNC();
-    }
-}
-
 // exchange 2 forward: x[i] = value of k1a = br4(i) at lane (k2, q) -> x[4 hi + q] at lane (k2, lo)
 FF_FN void l4_exchange2_fwd(L4 (&x)[16], u64 *xbuf, const NttLane &L)
 {
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
+    for (int h = 0; h < L4_EXCH_ROUNDS; h++) {
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const int k1a = br4(i), hi = k1a >> 2, lo = k1a & 3;
@@ -165,7 +156,7 @@ FF_FN void l4_exchange2_fwd(L4 (&x)[16], u64 *xbuf, const NttLane &L)
 FF_FN void l4_exchange2_inv(L4 (&x)[16], u64 *xbuf, const NttLane &L)
 {
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
+    for (int h = 0; h < L4_EXCH_ROUNDS; h++) {
 #pragma unroll
         for (int hi = 0; hi < 4; hi++)
 #pragma unroll
@@ -180,25 +171,11 @@ FF_FN void l4_exchange2_inv(L4 (&x)[16], u64 *xbuf, const NttLane &L)
     }
 }
 
-// exchange 1 backwards: x[i] = value r = br4(i) at lane (k2, q) -> x[k2] at lane j1
-FF_FN void l4_exchange1_inv(L4 (&x)[16], u64 *xbuf, const NttLane &L)
-{
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) xbuf[L.x1r + 4 * br4(i)] = l4_pair(x[i], h);
-        WAVE_SYNC();
-#pragma unroll
-        for (int k2 = 0; k2 < 16; k2++) l4_set_pair(x[k2], h, xbuf[L.x1w + k2 * NTT_ROW]);
-        WAVE_SYNC();
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // Forward transform of a polynomial of gadget digits (|d| <= 2^9); d[j2] = coefficient lane + 64 j2.
 // out[R]: a 64-bit representative (not canonical) of A_k, k = ntt_freq_index(lane, R).
 // ---------------------------------------------------------------------------------------------
-FF_FN void ntt_forward_small_l4(u64 (&out)[16], const i32 (&d)[16], u64 *xbuf, const u64 *tw1f, const NttLane &L)
+FF_FN void ntt_forward_small_l4(u64 (&out)[16], const i32 (&d)[16], u64 *xbuf, const u64 *tw1x, const NttLane &L)
 {
     L4 x[16];
     // pre-twist 2^(6 j2): a digit lands in ONE limb; the zero limbs fold away in the first stages
@@ -207,10 +184,20 @@ FF_FN void ntt_forward_small_l4(u64 (&out)[16], const i32 (&d)[16], u64 *xbuf, c
     PLACE(8); PLACE(9); PLACE(10); PLACE(11); PLACE(12); PLACE(13); PLACE(14); PLACE(15);
 #undef PLACE
     l4_ntt16_dif<12>(x);
-    // twiddle 1: the one general multiplication layer, psi^((2 k2 + 1) j1)
+    // exchange 1 carries 64-bit representatives (8 bytes per element, one round); twiddle 1, the one
+    // general multiplication layer psi^((2 k2 + 1) j1), is applied by the RECEIVING lane from the table
+    // laid out for it (ntt_make_tw1x: tw1x[r * 64 + lane] = psi^((2 k2 + 1)(q + 4 r)), lane = (k2, q)),
+    // and its 128-bit products are split straight into limbs
 #pragma unroll
-    for (int i = 0; i < 16; i++) l4_mul_u64(x[i], x[i], tw1f[br4(i) * 64 + L.lane]);
-    l4_exchange1_fwd(x, xbuf, L);
+    for (int i = 0; i < 16; i++) xbuf[L.x1w + br4(i) * NTT_ROW] = l4_to_u64(x[i]);
+    WAVE_SYNC();
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        u64 lo, hi;
+        ff_mul_wide(xbuf[L.x1r + 4 * r], tw1x[r * 64 + L.lane], lo, hi);
+        l4_from_u128(x[r], lo, hi);
+    }
+    WAVE_SYNC();
     l4_ntt16_dif<12>(x);
     l4_exchange2_fwd(x, xbuf, L);
     // twiddle 2: 2^(12 q hi + 3 q lo)
@@ -253,10 +240,17 @@ FF_FN void ntt_inverse_l4_core(u32 (&c)[16], L4 (&x)[16], u64 *xbuf, const u64 *
 #undef TW2I
     l4_exchange2_inv(x, xbuf, L);
     l4_ntt16_dif<-12>(x);
-    l4_exchange1_inv(x, xbuf, L);
-    // twiddle 1 inverse (and 1/N)
+    // exchange 1 backwards on 64-bit representatives, then twiddle 1 inverse (and 1/N) at the receiver
 #pragma unroll
-    for (int k2 = 0; k2 < 16; k2++) l4_mul_u64(x[k2], x[k2], tw1i[k2 * 64 + L.lane]);
+    for (int i = 0; i < 16; i++) xbuf[L.x1r + 4 * br4(i)] = l4_to_u64(x[i]);
+    WAVE_SYNC();
+#pragma unroll
+    for (int k2 = 0; k2 < 16; k2++) {
+        u64 lo, hi;
+        ff_mul_wide(xbuf[L.x1w + k2 * NTT_ROW], tw1i[k2 * 64 + L.lane], lo, hi);
+        l4_from_u128(x[k2], lo, hi);
+    }
+    WAVE_SYNC();
     l4_ntt16_dif<-12>(x);
     // post-twist and conversion
 #define POST(j2)                                                         \

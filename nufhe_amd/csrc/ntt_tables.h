@@ -31,3 +31,11 @@ static inline void ntt_make_tables(u64 *tw1f, u64 *tw1i)
             tw1i[k2 * 64 + j1] = ff_mul(ntt_host_pow(psi_inv, e), n_inv);
         }
 }
+
+// Forward table as the limb-form transform reads it (ntt1024_l4.h): after exchange 1 lane (k2, q) holds
+// j1 = q + 4 r in register r, so tw1x[r * 64 + lane] = tw1f[k2 * 64 + q + 4 r]
+static inline void ntt_make_tw1x(u64 *tw1x, const u64 *tw1f)
+{
+    for (int r = 0; r < 16; r++)
+        for (int lane = 0; lane < 64; lane++) tw1x[r * 64 + lane] = tw1f[(lane >> 2) * 64 + (lane & 3) + 4 * r];
+}

@@ -17,11 +17,11 @@
 #include "emu_wave.h"
 
 double g_emu_fft_max_frac = 0.0, g_emu_fft_max_abs = 0.0;   // fft512.h (NUFHE_EMU)
-static u64 g_tw1f[1024], g_tw1i[1024];
+static u64 g_tw1f[1024], g_tw1i[1024], g_tw1x[1024];
 static bool g_tables = false;
 static void tables()
 {
-    if (!g_tables) { ntt_make_tables(g_tw1f, g_tw1i); g_tables = true; }
+    if (!g_tables) { ntt_make_tables(g_tw1f, g_tw1i); ntt_make_tw1x(g_tw1x, g_tw1f); g_tables = true; }
 }
 
 template <int S> static void lsh_all(u64 *r, const u64 *a, long n) { for (long i = 0; i < n; i++) r[i] = ff_mul_pow2<S>(a[i]); }
@@ -92,7 +92,7 @@ void emu_ntt_forward_small_l4(u64 *out, const i32 *in)
         i32 d[16];
         u64 x[16];
         for (int r = 0; r < 16; r++) d[r] = in[ntt_coef_index(lane, r)];
-        ntt_forward_small_l4(x, d, xbuf.data(), g_tw1f, L);
+        ntt_forward_small_l4(x, d, xbuf.data(), g_tw1x, L);
         for (int r = 0; r < 16; r++) out[ntt_freq_index(lane, r)] = x[r];
     });
 }
@@ -133,7 +133,7 @@ static void bootstrap_bit(i32 *out_a, i32 *out_b, const u64 *bk_internal, int n,
     std::vector<u64> xbuf(NTT_XBUF_ELEMS);
     std::vector<i32> accbuf((K + 1) * 1024);
     std::vector<uint16_t> bara(BR_MAX_LWE);
-    BrLds lds{xbuf.data(), accbuf.data(), bara.data(), g_tw1f, g_tw1i};
+    BrLds lds{xbuf.data(), accbuf.data(), bara.data(), g_tw1x, g_tw1i};
     BrSource s0{a0, b0, 0, 0, p0}, s1{a1, b1, 0, 0, p1};
     emu_run_wave([&](int lane) {
         NttLane L = ntt_lane_init(lane);
@@ -156,7 +156,7 @@ extern "C" void emu_bootstrap_bit_team(i32 *out_a, i32 *out_b, const u64 *bk_int
     std::vector<uint16_t> bara(BR_MAX_LWE);
     BrSource s0{a0, b0, 0, 0, p0}, s1{a1, b1, 0, 0, p1};
     emu_run_team(BRT_WAVES, [&](int w, int lane) {
-        BrTeamLds lds{xbuf.data() + w * NTT_XBUF_ELEMS, accbuf.data(), bara.data(), part.data(), g_tw1f, g_tw1i};
+        BrTeamLds lds{xbuf.data() + w * NTT_XBUF_ELEMS, accbuf.data(), bara.data(), part.data(), g_tw1x, g_tw1i};
         NttLane L = ntt_lane_init(lane);
         brt_bootstrap(out_a, out_b, s0, s1, c0, 0, bk_internal, n, mu, lds, L, w, [] { emu_team_sync(); });
     });

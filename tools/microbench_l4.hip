@@ -41,7 +41,7 @@ __global__ __launch_bounds__(512, 2) void k_transform(u64 *io, const i32 *d, con
             ntt_forward_small(x, dg, xbuf, twf, L);
             for (int r = 0; r < 16; r++) dg[r] = (i32)((u32)x[r] & 1023u) - 512;
         } else if (MODE == 1) {     // forward, limb form
-            ntt_forward_small_l4(x, dg, xbuf, twf, L);
+            ntt_forward_small_l4(x, dg, xbuf, twf, L);   // (timing only: the table layout does not matter)
             for (int r = 0; r < 16; r++) dg[r] = (i32)((u32)x[r] & 1023u) - 512;
         } else if (MODE == 2) {     // inverse, 64-bit form (+ conversion to int32)
             ntt_inverse_t<true>(x, xbuf, twi, L);
