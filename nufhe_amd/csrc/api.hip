@@ -710,7 +710,7 @@ int nufhe_l4_op(nufhe_ctx *ctx, uint32_t *d_out, uint32_t *d_out2, const uint32_
 {
     int rc = check_ctx(ctx);
     if (rc) return rc;
-    if (op < 0 || op > 9 || shift < 0 || shift >= 192) return fail(NUFHE_EINVAL, "bad limb op %d / shift %d", op, shift);
+    if (op < 0 || op > 10 || shift < 0 || shift >= 192) return fail(NUFHE_EINVAL, "bad limb op %d / shift %d", op, shift);
     if (!d_out || !d_out2 || !d_a) return fail(NUFHE_EINVAL, "null operand");
     HIP_TRY(launch_l4_op(d_out, d_out2, d_a, d_b, d_c, op, shift, count, ctx->stream));
     return NUFHE_OK;

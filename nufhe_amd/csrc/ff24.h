@@ -197,13 +197,35 @@ FF_FN void l4_place(L4 &r, i32 d)
 #define L4_Z2 0x4002ff40u
 #define L4_Z3 0x80000000u
 
+// lo + 2^64 h0 -> a 64-bit representative (NOT canonical), for any 64-bit lo and h0 < 2^26:
+// 2^64 = 2^32 - 1 (mod P), so s = lo + h0 (2^32 - 1); s wraps at most once and the wrapped value is below
+// 2^58, so adding 2^32 - 1 for the lost 2^64 cannot wrap again.  One multiply-add with its own carry-out.
+FF_FN u64 l4_fold64(u64 lo, u32 h0)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (gfx940+: a VALU-written SGPR needs 2 wait states before a VALU reads it; the assembler does not
+    // insert them inside an asm block)
+    u64 s, carry;
+    u32 m;
+    asm("v_mad_u64_u32 %0, %1, %3, -1, %4\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32 %2, 0, -1, %1"
+        : "=&v"(s), "=&s"(carry), "=v"(m)
+        : "v"(h0), "v"(lo));
+    return s + (u64)m;
+#else
+    const u64 s = lo + (u64)h0 * FF_EPS;
+    return s + ((s < lo) ? FF_EPS : 0);
+#endif
+}
+
 // L4 -> a 64-bit representative of the value (any of x, x + P that fits 64 bits; NOT canonical).
 // Requires |w_i| <= 2^30.
 //   1. u_i = w_i + Z_i > 0;
 //   2. the top limb is cut to 16 bits: (u3 >> 16) 2^88 = (u3 >> 16) (2^56 - 2^24) mod P moves into
 //      limbs 2 and 1, so the carry chain below cannot leave the 96-bit window;
 //   3. exact base-2^24 digits by one carry chain (plain adds and shifts), packed into three words;
-//   4. 2^64 = 2^32 - 1: one multiply-add folds the top word, its carry-out is worth 2^32 - 1 again.
+//   4. the top word (< 2^25) is folded by l4_fold64.
 FF_FN u64 l4_to_u64(const L4 &x)
 {
     const u32 u0 = x.w[0] + L4_Z0, u1 = x.w[1] + L4_Z1, u2 = x.w[2] + L4_Z2, u3 = x.w[3] + L4_Z3;
@@ -214,24 +236,7 @@ FF_FN u64 l4_to_u64(const L4 &x)
     const u32 p0 = l4_pack<0, 3>(t1, u0);                  // digits 0, 1 (low byte)
     const u32 p1 = l4_pack<1, 2>(t2, t1);                  // digits 1 (high 2 bytes), 2 (low 2 bytes)
     const u32 p2 = l4_pack<2, 1>(t3, t2);                  // digit 2 (top byte), 3
-    const u64 lo = ((u64)p1 << 32) | p0;
-#if defined(__HIP_DEVICE_COMPILE__)
-    // s = lo + p2 * (2^32 - 1) with the multiply-add's own carry-out (p2 < 2^25: s wraps at most once
-    // and the wrapped value is < 2^57, so adding 2^32 - 1 for the carry cannot wrap again)
-    u64 s, carry;
-    u32 m;
-    // (gfx940+: a VALU-written SGPR needs 2 wait states before a VALU reads it; the assembler does not
-    // insert them inside an asm block)
-    asm("v_mad_u64_u32 %0, %1, %3, -1, %4\n\t"
-        "s_nop 1\n\t"
-        "v_cndmask_b32 %2, 0, -1, %1"
-        : "=&v"(s), "=&s"(carry), "=v"(m)
-        : "v"(p2), "v"(lo));
-    return s + (u64)m;
-#else
-    const u64 s = lo + (u64)p2 * FF_EPS;
-    return s + ((s < lo) ? FF_EPS : 0);
-#endif
+    return l4_fold64(((u64)p1 << 32) | p0, p2);
 }
 
 // 128-bit product hi:lo -> L4 (exact: bits 96.. re-enter negated at limb 0).
@@ -304,11 +309,17 @@ FF_FN void l4_dot2(L4 &r, u64 a0, u64 b0, u64 a1, u64 b1, u64 c)
 }
 
 // canonical-range conversion at the end of the inverse transform (ntt.mako:402-408, ntt_cpu.py:74-80):
-// the value is an integer c with |c| < 2^62 known to the caller; returns c mod 2^32.
-// Any 64-bit representative x' of c is c (c >= 0, top bit clear) or c + P (top bit set), and
-// P = 1 mod 2^32, so c = x'.lo - x'.bit63.
-FF_FN u32 l4_to_i32(const L4 &x)
+// x * 2^S is an integer c with |c| < 2^62 known to the caller (0 <= S < 24); returns c mod 2^32.
+// Any 64-bit representative v of c is c (c >= 0, top bit clear) or c + P (top bit set), and
+// P = 1 mod 2^32, so c = v.lo - v.bit63.  The sub-limb part 2^S of a twiddle is applied to the packed
+// word (one 64-bit shift + one fold) instead of to the four limbs.
+template <int S>
+FF_FN u32 l4_to_i32_shl(const L4 &x)
 {
-    const u64 v = l4_to_u64(x);
+    static_assert(S >= 0 && S < 24, "sub-limb shift");
+    u64 v = l4_to_u64(x);
+    if constexpr (S > 0) v = l4_fold64(v << S, (u32)(v >> (64 - S)));
     return (u32)v - (u32)(v >> 63);
 }
+
+FF_FN u32 l4_to_i32(const L4 &x) { return l4_to_i32_shl<0>(x); }

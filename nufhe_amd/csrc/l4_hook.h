@@ -13,6 +13,7 @@
 //   8  out = a * 2^(BASE + STEP lo), lo = b[0] & 3: the 24 instantiations of the twiddle-2 layers,
 //      shift = 12 * dir + 3 * hi + (q - 1), dir 0 forward / 1 inverse
 //   9  out = l4_place<6 * shift>((i32)a[0]), shift in [0, 16)
+//  10  out = (l4_to_i32_shl<shift>(a), 0, 0, 0), shift in {0, 6, 12, 18}: (a * 2^shift) as an int32
 #pragma once
 #include "ff24.h"
 #include "ntt1024_l4.h"
@@ -87,6 +88,10 @@ FF_FN void l4_hook(u32 *out, u32 *out2, const u32 *a, const u32 *b, const u32 *c
     case 7: l4_from_u64(R, a01); break;
     case 8: R = A; l4_hook_lane_tw(R, b[0] & 3u, shift); break;
     case 9: L4PlaceDispatch<15>::run(R, (i32)a[0], shift); break;
+    case 10:
+        R.w[0] = shift == 6 ? l4_to_i32_shl<6>(A) : shift == 12 ? l4_to_i32_shl<12>(A)
+                 : shift == 18 ? l4_to_i32_shl<18>(A) : l4_to_i32_shl<0>(A);
+        break;
     }
     for (int i = 0; i < 4; i++) out[i] = R.w[i];
 }

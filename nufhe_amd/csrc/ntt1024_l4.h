@@ -19,8 +19,8 @@
 //   <= 2^28 | twiddle 2 (split) < 2^26, the q = 0 column stays <= 2^28 | pass 3 < 2^29.
 // inverse:
 //   l4_from_u64 < 2^24 | pass 3 <= 2^26 | twiddle 2 < 2^25 (q = 0: <= 2^26) | pass 2: sum of 16
-//   <= 4 * 2^26 + 12 * 2^25 < 2^30 | table product -> (-2^24, 2^24) | pass 1 <= 2^28 | post-twist
-//   split <= 2^24 + 2^22 (multiples of 24: <= 2^28) | l4_to_i32.
+//   <= 4 * 2^26 + 12 * 2^25 < 2^30 | table product -> (-2^24, 2^24) | pass 1 <= 2^28 | post-twist: limb
+//   rotation, then the sub-limb part on the packed word (l4_to_i32_shl).
 #pragma once
 #include "ff24.h"
 #include "ntt1024.h"
@@ -252,12 +252,14 @@ FF_FN void ntt_inverse_l4_core(u32 (&c)[16], L4 (&x)[16], u64 *xbuf, const u64 *
     }
     WAVE_SYNC();
     l4_ntt16_dif<-12>(x);
-    // post-twist and conversion
-#define POST(j2)                                                         \
-    do {                                                                 \
-        L4 y;                                                            \
-        l4_mul_pow2<((j2) > 0 ? 96 : 0) - 6 * (j2)>(y, x[br4(j2)]);      \
-        c[j2] = l4_to_i32(y);                                            \
+    // post-twist 2^(E), E = (j2 > 0 ? 96 : 0) - 6 j2 = 24 k + s, and conversion: the rotation by k is a
+    // renaming, the sub-limb part s is applied to the packed word inside l4_to_i32_shl
+#define POST(j2)                                                              \
+    do {                                                                      \
+        constexpr int E = ((j2) > 0 ? 96 : 0) - 6 * (j2);                     \
+        L4 y;                                                                 \
+        l4_rot<E / 24>(y, x[br4(j2)]);                                        \
+        c[j2] = l4_to_i32_shl<E % 24>(y);                                     \
     } while (0)
     POST(0); POST(1); POST(2); POST(3); POST(4); POST(5); POST(6); POST(7); POST(8);
     POST(9); POST(10); POST(11); POST(12); POST(13); POST(14); POST(15);

@@ -86,6 +86,13 @@ def check_all(run, rs=None, n=3000):
     out, _ = run(6, as_u32(rows6))
     assert [int(o[0]) for o in out] == [cval & 0xFFFFFFFF for cval in small]
 
+    # 10: the same with a sub-limb power of two folded in: (value * 2^s) is the small integer
+    for sh in (0, 6, 12, 18):
+        rows10 = [spread(rs, (cval * pow(2, 192 - sh, P)) % P) for cval in small]     # value = c * 2^-sh
+        rows10 = [r for r in rows10]
+        out, _ = run(10, as_u32(rows10), shift=sh)
+        assert [int(o[0]) for o in out] == [cval & 0xFFFFFFFF for cval in small], sh
+
     # 1: 128-bit product -> limbs;  7: 64-bit word -> limbs
     words = [int(x) for x in rs.randint(0, 2**63, size=n, dtype=numpy.int64).astype(object) * 2 + rs.randint(0, 2, size=n)]
     words2 = [int(x) for x in rs.randint(0, 2**63, size=n, dtype=numpy.int64).astype(object) * 2 + 1]
