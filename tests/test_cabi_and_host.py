@@ -145,3 +145,24 @@ def test_ciphertext_view_indexing_with_ellipsis():
     assert ct[:, 3:4].shape == (4, 1) and ct[...].shape == (4, 16) and ct[1].shape == (16,)
     ct[..., 0:1] = ct[..., 5:6]
     assert (ct.a[:, 0] == a[:, 5]).all()
+
+
+def test_tracked_profile_inputs_of_the_bench_roofline_are_current():
+    """bench.py's issue roofline multiplies the ISA counts of profiles/isa_mix.json by the measured
+    class costs of profiles/valu_class_costs.json: the counts must belong to the CURRENT device sources
+    (tools/isa_mix.py --write records a hash of nufhe_amd/csrc)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location('isa_mix', os.path.join(ROOT, 'tools', 'isa_mix.py'))
+    isa_mix = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(isa_mix)
+    mix = json.load(open(os.path.join(ROOT, 'profiles', 'isa_mix.json')))
+    assert mix['source_hash'] == isa_mix.source_hash(), "run `python tools/isa_mix.py --write` (device sources changed)"
+    for kernel in ('k_bootstrap<1>', 'k_bootstrap_fft'):
+        k = mix[kernel]
+        assert k['valu'] > 1000 and k['vgprs'] <= 256
+    assert mix['k_bootstrap<1>']['scratch_bytes'] == 0
+    costs = json.load(open(os.path.join(ROOT, 'profiles', 'valu_class_costs.json')))
+    assert 2.0 <= costs['full_rate_cycles'] < costs['half_rate_cycles'] <= 6.0
+    for name in ('pmc_NTT.json', 'pmc_FFT.json', 'pmc_traffic.json'):
+        assert os.path.isfile(os.path.join(ROOT, 'profiles', name))
