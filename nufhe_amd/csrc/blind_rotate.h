@@ -456,3 +456,96 @@ FF_FN void brt_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSou
     }
     if (tid == 0) *out_b = lds.acc[1024];
 }
+
+// ------------------------------------------------------------------------------------------
+// Team variant for tlwe_mask_size = K > 1 (small batches): K + 1 wavefronts share one bit, wave m owns
+// input polynomial m -- both of its digit transforms and the paired multiply-accumulate against
+// BK_row[m][0..1][0..K] (exactly the per-m body of br_external_product) -- and leaves K + 1 partial
+// sums in LDS; after the work-group barrier wave mo adds the K + 1 partial sums of OUTPUT polynomial
+// mo, transforms back and updates the shared accumulator.  Critical path: 2 forward + 1 inverse
+// transform instead of 2 (K+1) + (K+1).  The partial sums are canonical field elements and field
+// addition is exact, so the result equals the one-wave kernel bit for bit.
+// ------------------------------------------------------------------------------------------
+#define BRTK_PART_ELEMS(K) (((K) + 1) * ((K) + 1) * 1024)   /* u64: partial sums [wave m][mo][reg][lane] */
+
+template <int K, class TeamSync>
+FF_FN void brtk_step(u32 a, const u64 *row, const BrTeamLds &lds, const NttLane &L, int w, TeamSync &&team_sync)
+{
+    const int lane = L.lane;
+    u32 T[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const u32 j = (u32)(lane + 64 * r);
+        const u32 t = (j - a) & 2047u;
+        const u32 v = (u32)lds.acc[w * 1024 + (t & 1023u)];
+        T[r] = ((t & 1024u) ? 0u - v : v) - (u32)lds.acc[w * 1024 + j];     // (X^a - 1) ACC_w
+    }
+    u64 x0[16], x1[16];
+    i32 dg[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) dg[r] = br_digit<0>(T[r]);
+    ntt_forward_small_l4(x0, dg, lds.xbuf, lds.tw1x, L);
+#pragma unroll
+    for (int r = 0; r < 16; r++) dg[r] = br_digit<1>(T[r]);
+    ntt_forward_small_l4(x1, dg, lds.xbuf, lds.tw1x, L);
+    u64 ps[K + 1][16];
+    br_mac2<K, true>(ps, x0, x1, row + (long)w * 2 * (K + 1) * BK_POLY_ELEMS, lane);
+#pragma unroll
+    for (int mo = 0; mo <= K; mo++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) lds.part[((w * (K + 1) + mo) * 16 + r) * 64 + lane] = ps[mo][r];
+    team_sync();
+    u64 sum[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        u64 acc = lds.part[((0 * (K + 1) + w) * 16 + r) * 64 + lane];
+#pragma unroll
+        for (int src = 1; src <= K; src++) acc = ff_add(acc, lds.part[((src * (K + 1) + w) * 16 + r) * 64 + lane]);
+        sum[r] = acc;
+    }
+    u32 c[16];
+    ntt_inverse_l4_i32(c, sum, lds.xbuf, lds.tw1i, L);
+#pragma unroll
+    for (int r = 0; r < 16; r++) lds.acc[w * 1024 + lane + 64 * r] += (i32)(r == 0 ? c[r] : 0u - c[r]);
+    team_sync();
+}
+
+// Whole bootstrap body of the (K+1)-wave team for one bit; out_a has K * 1024 entries.
+template <int K, class TeamSync>
+FF_FN void brtk_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSource &s1, i32 c0, long bit,
+                          const u64 *bk, int n, i32 mu, const BrTeamLds &lds, const NttLane &L, int w,
+                          TeamSync &&team_sync)
+{
+    constexpr int THREADS = 64 * (K + 1);
+    const int tid = 64 * w + L.lane;
+    for (int i = tid; i < n; i += THREADS) {
+        u32 v = 0;
+        if (s0.p) v += (u32)s0.p * (u32)s0.a[bit * s0.a_stride + i];
+        if (s1.p) v += (u32)s1.p * (u32)s1.a[bit * s1.a_stride + i];
+        lds.bara[i] = (uint16_t)br_modswitch(v);
+    }
+    u32 vb = (u32)c0;
+    if (s0.p) vb += (u32)s0.p * (u32)s0.b[bit * s0.b_stride];
+    if (s1.p) vb += (u32)s1.p * (u32)s1.b[bit * s1.b_stride];
+    const u32 barb = br_modswitch(vb);
+    // ACC = (0, ..., 0, X^(2N - barb) * mu)  (bootstrap.py:176-182)
+    for (int j = tid; j < 1024; j += THREADS) {
+        const u32 t = ((u32)j + barb) & 2047u;
+#pragma unroll
+        for (int m = 0; m < K; m++) lds.acc[m * 1024 + j] = 0;
+        lds.acc[K * 1024 + j] = (t < 1024u) ? mu : (i32)(0u - (u32)mu);
+    }
+    team_sync();
+    for (int i = 0; i < n; i++) {
+        const u32 a = WAVE_UNIFORM((u32)lds.bara[i]);
+        if (a == 0) continue;
+        brtk_step<K>(a, bk + (long)i * BK_ROW_ELEMS_K(K), lds, L, w, team_sync);
+    }
+    // sample extraction (tlwe_cpu.py:55-58)
+    for (int j = tid; j < K * 1024; j += THREADS) {
+        const int m = j >> 10, jj = j & 1023;
+        const u32 v = (u32)lds.acc[j];
+        out_a[m * 1024 + ((1024 - jj) & 1023)] = (i32)(jj == 0 ? v : 0u - v);
+    }
+    if (tid == 0) *out_b = lds.acc[K * 1024];
+}

@@ -100,6 +100,30 @@ __global__ __launch_bounds__(64 * BRT_WAVES, 1) void k_bootstrap_team(BrLaunch P
                   [] { __syncthreads(); });
 }
 
+// Small-batch variant for tlwe_mask_size = 2: a team of 3 waves per bit (blind_rotate.h, brtk_*).
+// LDS: tables | ACC 12 KiB | bara 1 KiB | partial sums 72 KiB | 3 exchange buffers
+#define TEAM2_LDS_BYTES (TABLE_LDS_BYTES + 3 * 1024 * 4 + WAVE_BARA_BYTES + BRTK_PART_ELEMS(2) * 8 + 3 * WAVE_XBUF_BYTES)
+__global__ __launch_bounds__(64 * 3, 1) void k_bootstrap_team_k2(BrLaunch P)
+{
+    load_tables((const u64 *)P.tw_a, (const u64 *)P.tw_b);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long gbit = blockIdx.x;
+    const int job = gbit >= P.bits_per_job ? 1 : 0;
+    const long bit = gbit - (job ? P.bits_per_job : 0);
+    unsigned char *base = g_smem + TABLE_LDS_BYTES;
+    BrTeamLds lds;
+    lds.acc = (i32 *)base;
+    lds.bara = (uint16_t *)(base + 3 * 1024 * 4);
+    lds.part = (u64 *)(base + 3 * 1024 * 4 + WAVE_BARA_BYTES);
+    lds.xbuf = (u64 *)(base + 3 * 1024 * 4 + WAVE_BARA_BYTES + BRTK_PART_ELEMS(2) * 8 + wave * WAVE_XBUF_BYTES);
+    lds.tw1x = (const u64 *)g_smem;
+    lds.tw1i = (const u64 *)g_smem + 1024;
+    const NttLane L = ntt_lane_init(lane);
+    brtk_bootstrap<2>(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, P.job[job].s0, P.job[job].s1,
+                      P.job[job].c0, bit, (const u64 *)P.bk, P.n, P.mu, lds, L, WAVE_UNIFORM(wave),
+                      [] { __syncthreads(); });
+}
+
 // Test hook / multi-kernel-style entry: blind rotate (or a single external product) on
 // accumulators held in global memory: accum int32 [batch][2][1024]
 template <int K>
@@ -904,6 +928,8 @@ hipError_t kernels_init_device(int *num_cus)
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap_team, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAM_LDS_BYTES);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_bootstrap_team_k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAM2_LDS_BYTES);
+    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_blind_rotate_accum<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(1));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_blind_rotate_accum<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(2));
@@ -945,6 +971,9 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, lon
     } else if (transform == 0 && mask_size == 1) {
         const int w = br_pick_waves(P.nbits_total, BR_WAVES_K(1), num_cus);
         hipLaunchKernelGGL(k_bootstrap<1>, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), br_lds_bytes(1, w), stream, P);
+    } else if (transform == 0 && mask_size == 2 && P.nbits_total <= team_max_bits) {
+        // small batch, k = 2: 3 waves per bit (one team per CU at a time)
+        hipLaunchKernelGGL(k_bootstrap_team_k2, dim3((unsigned)P.nbits_total), dim3(64 * 3), TEAM2_LDS_BYTES, stream, P);
     } else if (transform == 0 && mask_size == 2) {
         const int w = br_pick_waves(P.nbits_total, BR_WAVES_K(2), num_cus);
         hipLaunchKernelGGL(k_bootstrap<2>, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), br_lds_bytes(2, w), stream, P);

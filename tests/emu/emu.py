@@ -102,8 +102,7 @@ def bootstrap_bit(bk_internal, n, src0, p0, src1, p1, c0, mu, mask_size=1, team=
     out_a = numpy.empty(1024 * mask_size, numpy.int32); out_b = numpy.empty(1, numpy.int32)
     fn = lib().emu_bootstrap_bit if mask_size == 1 else lib().emu_bootstrap_bit_k2
     if team:
-        assert mask_size == 1
-        fn = lib().emu_bootstrap_bit_team
+        fn = lib().emu_bootstrap_bit_team if mask_size == 1 else lib().emu_bootstrap_bit_team_k2
     fn(_p(out_a, c_i32p), _p(out_b, c_i32p), _p(bk_internal, c_u64p), ctypes.c_int(n),
                             _p(a0, c_i32p), _p(b0, c_i32p), ctypes.c_int32(p0),
                             _p(a1, c_i32p), _p(b1, c_i32p), ctypes.c_int32(p1),

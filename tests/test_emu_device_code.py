@@ -175,6 +175,9 @@ def test_bootstrap_wave_body_mask_size_2(orc):
     ga, gb = emu.bootstrap_bit(bki, n, (a0, b0), 1, (a1, b1), 1, -MU, MU, mask_size=2)
     assert ea.shape == (1, 2048)
     assert (ga == ea[0]).all() and gb == eb[0]
+    # the 3-wave team variant (small batches): same bits
+    ga, gb = emu.bootstrap_bit(bki, n, (a0, b0), 1, (a1, b1), 1, -MU, MU, mask_size=2, team=True)
+    assert (ga == ea[0]).all() and gb == eb[0]
 
 
 def test_bootstrap_wave_body_fft_mask_size_2(orc):

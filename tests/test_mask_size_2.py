@@ -185,6 +185,32 @@ def test_gpu_k2_context_end_to_end(thr):
     assert (ctx.decrypt(sk, vm2.gate_and(c[0], c[1])) == (m[0] & m[1])).all()
 
 
+@pytest.mark.gpu
+def test_gpu_k2_small_batch_team_kernel_equals_wave_kernel(k2_env, thr, H, orc):
+    """k = 2 on a small batch: the 3-waves-per-bit kernel (k_bootstrap_team_k2, batches <= 2 x CUs bits) gives
+    exactly the ciphertexts of the wave-per-bit kernel and of the oracle (NAND and MUX, 70 bits)."""
+    from nufhe_amd import _lib
+    vm = k2_env['vm']; ck = k2_env['ck']; lwe_key = k2_env['lwe_key']; params = k2_env['params']
+    rng = orc.DeterministicRNG(777)
+    B = 70
+    ms = [rng.uniform_bool((B,)).astype(bool) for _ in range(3)]
+    cs = [orc.encrypt(rng, lwe_key, m, k2_env['oparams']) for m in ms]
+    ds = [H.ciphertext_from_arrays(thr, c, params) for c in cs]
+    exp = {'nand': orc.gate('gate_nand', ck, cs[0], cs[1]), 'mux': orc.gate_mux(ck, cs[0], cs[1], cs[2])}
+    got = {}
+    try:
+        for limit in (0, -1):            # 0: wave-per-bit kernel; -1: default switch (team kernel for 70 bits)
+            _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, limit)
+            got[limit] = {'nand': H.ct_arrays(vm.gate_nand(ds[0], ds[1])),
+                          'mux': H.ct_arrays(vm.gate_mux(ds[0], ds[1], ds[2]))}
+    finally:
+        _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, -1)
+    for name in ('nand', 'mux'):
+        for limit in (0, -1):
+            ra, rb, rcv = got[limit][name]
+            assert (ra == exp[name][0]).all() and (rb == exp[name][1]).all() and (rcv == exp[name][2]).all(), (name, limit)
+
+
 # ---- tlwe_mask_size = 2 with the FFT transform (test/test_gates.py:88-100: every (transform, k) pair) ----
 
 FFT_TOLERANCE_LSB = 2**4      # per output word of a gate vs the exact path (tests/test_gpu_fft.py)
