@@ -64,11 +64,6 @@ __global__ __launch_bounds__(64 * BR_WAVES_K(K), 2) void k_bootstrap(BrLaunch P)
 
     const BrLds lds = carve_br_lds<K>(wave);
     const NttLane L = ntt_lane_init(lane);
-#if defined(BR_SETPRIO)
-    // the two waves that share a SIMD (w and w + 4) run the same instruction stream: give one of them
-    // priority so that they drift apart and one computes while the other waits for LDS / key data
-    if (wave & 4) __builtin_amdgcn_s_setprio(BR_SETPRIO);
-#endif
     const u32 barb = br_prologue(P.job[job].s0, P.job[job].s1, P.job[job].c0, bit, P.n, lds, lane);
     WAVE_SYNC();
     u32 acc[K + 1][16];

@@ -123,9 +123,6 @@ FF_FN void l4_mul_pow2_lane(L4 &x, u32 lo)
 // 2 moves limbs (16 bytes per element); the per-wave buffer of ntt1024.h holds 8 bytes per slot, so it
 // runs in two rounds (limbs 0-1, then limbs 2-3) over the same conflict-free addresses.
 // ---------------------------------------------------------------------------------------------
-#ifndef L4_EXCH_ROUNDS
-#define L4_EXCH_ROUNDS 2      /* 1 = timing experiment only (drops limbs 2-3: wrong results) */
-#endif
 FF_FN u64 l4_pair(const L4 &x, int h) { return ((u64)x.w[2 * h + 1] << 32) | x.w[2 * h]; }
 FF_FN void l4_set_pair(L4 &x, int h, u64 v)
 {
@@ -137,7 +134,7 @@ FF_FN void l4_set_pair(L4 &x, int h, u64 v)
 FF_FN void l4_exchange2_fwd(L4 (&x)[16], u64 *xbuf, const NttLane &L)
 {
 #pragma unroll
-    for (int h = 0; h < L4_EXCH_ROUNDS; h++) {
+    for (int h = 0; h < 2; h++) {
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const int k1a = br4(i), hi = k1a >> 2, lo = k1a & 3;
@@ -156,7 +153,7 @@ FF_FN void l4_exchange2_fwd(L4 (&x)[16], u64 *xbuf, const NttLane &L)
 FF_FN void l4_exchange2_inv(L4 (&x)[16], u64 *xbuf, const NttLane &L)
 {
 #pragma unroll
-    for (int h = 0; h < L4_EXCH_ROUNDS; h++) {
+    for (int h = 0; h < 2; h++) {
 #pragma unroll
         for (int hi = 0; hi < 4; hi++)
 #pragma unroll
