@@ -71,6 +71,7 @@ struct nufhe_cloudkey {
     i32 *d_ks_a3 = nullptr;   // [k*1024][8][3][n]
     i32 *d_ks_b = nullptr;    // [k*1024][8][4]
     float *d_ks_cv = nullptr; // [k*1024][8][4]
+    float *d_cv_table = nullptr;   // [k*1024*8 + 1] for uniform-variance keys (KsFinal::cv_table), else NULL
 };
 
 namespace {
@@ -149,6 +150,7 @@ int run_keyswitch(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result, 
     F.out_a_stride = result.a_stride; F.out_b_stride = result.b_stride;
     F.n = key->n;
     F.input_size = key->ext_size();
+    F.cv_table = key->d_cv_table;
     HIP_TRY(launch_keyswitch(P, F, ctx->stream));
     return NUFHE_OK;
 }
@@ -330,6 +332,7 @@ int nufhe_cloudkey_destroy(nufhe_cloudkey *key)
     if (key->d_ks_a3) hipFree(key->d_ks_a3);
     if (key->d_ks_b) hipFree(key->d_ks_b);
     if (key->d_ks_cv) hipFree(key->d_ks_cv);
+    if (key->d_cv_table) hipFree(key->d_cv_table);
     delete key;
     return NUFHE_OK;
 }
@@ -396,6 +399,22 @@ int nufhe_bk_from_coeffs(nufhe_cloudkey *key, const int32_t *d_tgsw)
     return NUFHE_OK;
 }
 
+// Uniform-variance keys (KsFinal::cv_table): table of the float32 partial sums v, v + v, (v + v) + v, ...
+// exactly as a sequential float32 accumulation produces them (volatile: one rounding per addition)
+static int set_cv_table(nufhe_cloudkey *key, bool uniform, float v)
+{
+    if (key->d_cv_table) { hipFree(key->d_cv_table); key->d_cv_table = nullptr; }
+    if (!uniform) return NUFHE_OK;
+    const long terms = (long)key->ext_size() * NUFHE_KS_T;
+    std::vector<float> table(terms + 1);
+    volatile float s = 0.0f;
+    table[0] = 0.0f;
+    for (long c = 1; c <= terms; c++) { s = s + v; table[c] = s; }
+    HIP_TRY(hipMalloc((void **)&key->d_cv_table, table.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(key->d_cv_table, table.data(), table.size() * sizeof(float), hipMemcpyHostToDevice));
+    return NUFHE_OK;
+}
+
 static int alloc_ks(nufhe_cloudkey *key)
 {
     const long rows = (long)key->ext_size() * NUFHE_KS_T;
@@ -421,6 +440,13 @@ int nufhe_ks_upload(nufhe_cloudkey *key, const int32_t *h_ks_a, const int32_t *h
         if (h_ks_b[r * 4] != 0 || h_ks_cv[r * 4] != 0.0f)
             return fail(NUFHE_EINVAL, "keyswitch key: base-0 slice of ks_b/ks_cv is not zero (row %ld)", r);
     }
+    bool uniform = true;
+    const float v0 = h_ks_cv[1];
+    for (long r = 0; r < rows && uniform; r++)
+        for (int h = 1; h < 4; h++)
+            if (h_ks_cv[r * 4 + h] != v0) { uniform = false; break; }
+    rc = set_cv_table(key, uniform && v0 >= 0.0f, v0);
+    if (rc) return rc;
     std::vector<int32_t> packed((size_t)rows * 3 * n);
     for (long r = 0; r < rows; r++)
         memcpy(packed.data() + (size_t)r * 3 * n, h_ks_a + ((size_t)r * 4 + 1) * n, sizeof(int32_t) * 3 * n);
@@ -448,7 +474,7 @@ int nufhe_ks_make(nufhe_cloudkey *key, const int32_t *d_noises_a, const int32_t 
                            ctx->stream));
     HIP_TRY(launch_ks_make(key->d_ks_b, key->d_ks_cv, key->d_ks_a3, d_noises_b, d_in_key, d_out_key, variance, rows,
                            key->n, ctx->stream));
-    return NUFHE_OK;
+    return set_cv_table(key, variance >= 0.0f, variance);
 }
 
 int nufhe_ks_download_reference(nufhe_cloudkey *key, int32_t *h_ks_a, int32_t *h_ks_b, float *h_ks_cv)

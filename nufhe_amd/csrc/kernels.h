@@ -56,6 +56,11 @@ struct KsFinal {
     long out_a_stride, out_b_stride;
     int n;
     int input_size;       // mask_size * 1024
+    // keys whose non-zero variance entries all hold ONE value v (every generated key: lwe_cpu.py:37):
+    // cv_table[c] = v added c times in float32, sequentially; the variance of a result is then
+    // cv_table[number of non-zero digits] -- the value the reference's sequential sum reaches, without
+    // the 8192-term serial addition.  NULL: general keys, sequential sum.
+    const float *cv_table;
 };
 
 struct LweView {

@@ -647,13 +647,14 @@ __global__ __launch_bounds__(KS_BLOCK_THREADS) void k_keyswitch_a(KsLaunch P)
 __global__ __launch_bounds__(256) void k_keyswitch_finalize(KsFinal P)
 {
     __shared__ float cv_terms[8192];
-    __shared__ u32 b_sum;
+    __shared__ u32 b_sum, nz_sum;
     const long bit = blockIdx.x;
-    if (threadIdx.x == 0) b_sum = 0;
+    if (threadIdx.x == 0) { b_sum = 0; nz_sum = 0; }
     __syncthreads();
     for (int c = threadIdx.x; c < P.n; c += blockDim.x)
         P.out_a[bit * P.out_a_stride + c] = (i32)P.acc[bit * P.n + c];
-    u32 bpart = 0;
+    const bool by_count = P.cv_table != nullptr;     // uniform-variance key: count instead of adding
+    u32 bpart = 0, nz = 0;
     float cv = 0.0f;
     for (int j0 = 0; j0 < P.input_size; j0 += 1024) {
         for (int jj = threadIdx.x; jj < 1024; jj += blockDim.x) {
@@ -666,21 +667,25 @@ __global__ __launch_bounds__(256) void k_keyswitch_finalize(KsFinal P)
                 const u32 dg = (a >> (30 - 2 * k)) & 3u;
                 const long idx = ((long)j * 8 + k) * 4 + (long)dg;
                 bpart += (u32)P.ks_b[idx];
-                cv_terms[jj * 8 + k] = P.ks_cv[idx];
+                nz += dg != 0u;
+                if (!by_count) cv_terms[jj * 8 + k] = P.ks_cv[idx];
             }
         }
-        __syncthreads();
-        if (threadIdx.x == 0 && P.out_cv)
-            for (int i = 0; i < 8192; i++) cv += cv_terms[i];
-        __syncthreads();
+        if (!by_count) {
+            __syncthreads();
+            if (threadIdx.x == 0 && P.out_cv)
+                for (int i = 0; i < 8192; i++) cv += cv_terms[i];
+            __syncthreads();
+        }
     }
     atomicAdd(&b_sum, bpart);
+    if (by_count) atomicAdd(&nz_sum, nz);
     __syncthreads();
     if (threadIdx.x == 0) {
         u32 b = (u32)P.c0 + (u32)P.src1_b[bit * P.src1_bstride];
         if (P.src2_b) b += (u32)P.src2_b[bit * P.src2_bstride];
         P.out_b[bit * P.out_b_stride] = (i32)(b - b_sum);
-        if (P.out_cv) P.out_cv[bit * P.out_b_stride] = cv;
+        if (P.out_cv) P.out_cv[bit * P.out_b_stride] = by_count ? P.cv_table[nz_sum] : cv;
     }
 }
 
