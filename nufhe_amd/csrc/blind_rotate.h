@@ -56,12 +56,49 @@ struct BrSource {
     i32 p;             // 0 => term absent
 };
 
+// Pacing of the two wavefronts that share a SIMD.  A work-group of 8 one-bit waves puts waves w and w + 4 on
+// the same SIMD, and the issue arbiter serves the OLDER wave first: measured (tools/probe_segments.py), wave w ran
+// its 500 iterations in 15.2 ms at the expense of wave w + 4, which then needed another 8.1 ms ALONE -- and a single
+// wave fills only ~60 % of the SIMD's issue slots, while the work-group holds the CU until its last wave ends.
+// Each wave therefore publishes its iteration count in LDS and lowers its own priority (s_setprio) while it is
+// ahead of its partner: both finish together and the SIMD has two runnable waves to the end.  Scheduling only --
+// no effect on any result.
+struct BrPace {
+    u32 *mine;          // nullptr: no partner on this SIMD (fewer than 5 waves in the work-group, emulator)
+    const u32 *other;
+};
+
+FF_FN void br_pace(const BrPace &p, u32 done)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (p.mine == nullptr) return;
+    *(volatile u32 *)p.mine = done;
+    const u32 o = WAVE_UNIFORM(*(const volatile u32 *)p.other);
+    if (done > o) __builtin_amdgcn_s_setprio(0);
+    else __builtin_amdgcn_s_setprio(2);
+#else
+    (void)p; (void)done;
+#endif
+}
+
+FF_FN void br_pace_done(const BrPace &p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (p.mine == nullptr) return;
+    *(volatile u32 *)p.mine = 0xFFFFFFFFu;
+    __builtin_amdgcn_s_setprio(0);
+#else
+    (void)p;
+#endif
+}
+
 struct BrLds {
     u64 *xbuf;         // NTT exchange buffer, NTT_XBUF_ELEMS u64
     i32 *acc;          // [K+1][1024] accumulator mirror for rotated reads
     uint16_t *bara;    // [BR_MAX_LWE]
     const u64 *tw1x;   // [1024] forward table in the layout of ntt_make_tw1x (limb-form transform)
     const u64 *tw1i;   // [1024]
+    BrPace pace;
 };
 
 // mod-switch, Torus32ToPhase with mspace 2N = 2048 (numeric_functions_cpu.py:23-37)
@@ -124,6 +161,36 @@ FF_FN void br_mac(u64 (&sum)[K + 1][16], const u64 (&x)[16], const u64 *poly, in
 // BR_KEY_DEPTH key-load steps are kept in flight ahead of the multiplication that consumes them
 #ifndef BR_KEY_DEPTH
 #define BR_KEY_DEPTH 1
+#endif
+
+// Variant-build instrumentation (tools/build_variant.sh probe -DBR_PROBE): shader-clock ticks spent by wave 0
+// of work-group 0 in the segments of one external product, summed over the blind rotation.  Never part of
+// the shipped library.
+#if defined(BR_PROBE) && defined(__HIPCC__)
+__device__ unsigned long long g_br_probe[16];
+__device__ unsigned int g_br_probe_life[2 * 8192];   // per wave: start, end (wall_clock64, 10 ns units, low 32 bits)
+#endif
+#if defined(BR_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+struct BrProbe { long long t[8]; long long last; };
+#define BR_PROBE_ARG , BrProbe &probe_
+#define BR_PROBE_PASS , probe_
+#define BR_PROBE_BEGIN()                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    probe_.last = clock64();                                                                          \
+    __builtin_amdgcn_sched_barrier(0)
+#define BR_PROBE_MARK(i)                                                                              \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        const long long now_ = clock64();                                                             \
+        probe_.t[i] += now_ - probe_.last;                                                            \
+        probe_.last = now_;                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    } while (0)
+#else
+#define BR_PROBE_ARG
+#define BR_PROBE_PASS
+#define BR_PROBE_BEGIN()
+#define BR_PROBE_MARK(i)
 #endif
 
 template <int K, bool FIRST>
@@ -200,7 +267,7 @@ FF_FN void br_mac2_l4(L4 (&out)[16], const u64 (&prev)[16], const u64 (&x0)[16],
 // multiply-accumulate of code -- so tsrc gets a run-time m and must read its polynomial from memory
 // (the LDS mirror), never from a register array.
 template <int K, class TSource, class Emit>
-FF_FN void br_external_product(TSource &&tsrc, Emit &&emit, const u64 *row, const BrLds &lds, const NttLane &L)
+FF_FN void br_external_product(TSource &&tsrc, Emit &&emit, const u64 *row, const BrLds &lds, const NttLane &L BR_PROBE_ARG)
 {
     const int lane = L.lane;
     auto digits_forward = [&](int m, u64(&x0)[16], u64(&x1)[16]) {
@@ -220,27 +287,35 @@ FF_FN void br_external_product(TSource &&tsrc, Emit &&emit, const u64 *row, cons
         for (int r = 0; r < 16; r++) emit(mo, r, r == 0 ? c[r] : 0u - c[r]);
     };
     if constexpr (K == 1) {
+        BR_PROBE_BEGIN();
         u64 sum[2][16];
         {
             u64 x0[16], x1[16];
             digits_forward(0, x0, x1);
+            BR_PROBE_MARK(0);
             br_mac2<1, true>(sum, x0, x1, row, lane);
+            BR_PROBE_MARK(1);
         }
         u64 x0[16], x1[16];
         digits_forward(1, x0, x1);
+        BR_PROBE_MARK(2);
         {
             L4 s[16];
             u32 c[16];
             br_mac2_l4<1>(s, sum[0], x0, x1, row + 4 * BK_POLY_ELEMS, lane);
+            BR_PROBE_MARK(3);
             ntt_inverse_l4_core(c, s, lds.xbuf, lds.tw1i, L);
             finish(0, c);
+            BR_PROBE_MARK(4);
         }
         {
             L4 s[16];
             u32 c[16];
             br_mac2_l4<1>(s, sum[1], x0, x1, row + 5 * BK_POLY_ELEMS, lane);
+            BR_PROBE_MARK(5);
             ntt_inverse_l4_core(c, s, lds.xbuf, lds.tw1i, L);
             finish(1, c);
+            BR_PROBE_MARK(6);
         }
     } else {
         u64 sum[K + 1][16];
@@ -294,7 +369,7 @@ FF_FN void br_init_acc(u32 (&acc)[K + 1][16], u32 barb, i32 mu, const BrLds &lds
 // registers are needed by the transforms and the (K+1) x 16 field-element sums); br_blind_rotate loads
 // it into registers at the end.
 template <int K>
-FF_FN void br_step(u32 a, const u64 *row, const BrLds &lds, const NttLane &L)
+FF_FN void br_step(u32 a, const u64 *row, const BrLds &lds, const NttLane &L BR_PROBE_ARG)
 {
     const int lane = L.lane;
     br_external_product<K>(
@@ -309,8 +384,9 @@ FF_FN void br_step(u32 a, const u64 *row, const BrLds &lds, const NttLane &L)
                 T[r] = ((t & 1024u) ? 0u - v : v) - self;
             }
         },
-        [&](int mo, int r, u32 v) { lds.acc[mo * 1024 + lane + 64 * r] += (i32)v; }, row, lds, L);
+        [&](int mo, int r, u32 v) { lds.acc[mo * 1024 + lane + 64 * r] += (i32)v; }, row, lds, L BR_PROBE_PASS);
     WAVE_SYNC();
+    BR_PROBE_MARK(7);
 }
 
 // The whole blind rotation for one bit; bara comes from the per-wave LDS buffer.
@@ -319,11 +395,28 @@ FF_FN void br_blind_rotate(u32 (&acc)[K + 1][16], const u64 *bk, int n, u32 barb
                            const NttLane &L)
 {
     br_init_acc<K>(acc, barb, mu, lds, L.lane);
+#if defined(BR_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+    BrProbe probe_ = {};
+    const long long probe_w0 = clock64(), probe_r0 = wall_clock64();
+#endif
     for (int i = 0; i < n; i++) {
+        br_pace(lds.pace, (u32)i);
         const u32 a = WAVE_UNIFORM((u32)lds.bara[i]);
         if (a == 0) continue;   // (X^0 - 1) ACC = 0: the external product adds nothing
-        br_step<K>(a, bk + (long)i * BK_ROW_ELEMS_K(K), lds, L);
+        br_step<K>(a, bk + (long)i * BK_ROW_ELEMS_K(K), lds, L BR_PROBE_PASS);
     }
+    br_pace_done(lds.pace);
+#if defined(BR_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+    if (L.lane == 0) {
+        for (int i = 0; i < 8; i++) atomicAdd(&g_br_probe[i], (unsigned long long)probe_.t[i]);
+        atomicAdd(&g_br_probe[14], (unsigned long long)(clock64() - probe_w0));
+        atomicAdd(&g_br_probe[13], 1ull);
+        atomicAdd(&g_br_probe[12], (unsigned long long)(wall_clock64() - probe_r0));   // 100 MHz
+        const unsigned gw = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 8191u;
+        g_br_probe_life[2 * gw] = (unsigned)probe_r0;
+        g_br_probe_life[2 * gw + 1] = (unsigned)wall_clock64();
+    }
+#endif
 #pragma unroll
     for (int m = 0; m <= K; m++)
 #pragma unroll

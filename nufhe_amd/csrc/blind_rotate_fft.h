@@ -30,6 +30,7 @@ struct BrFftLds {
     u32 *park;           // [(BRF_PARK - 4) * 64]
     const cplx *tw1;     // [512]
     const cplx *tw2;     // [64]
+    BrPace pace;         // blind_rotate.h
 };
 
 // LDS slot of parked value j (0 .. BRF_PARK-1) of this lane
@@ -190,10 +191,12 @@ FF_FN void brf_blind_rotate(u32 (&acc)[2][16], const cplx *bk, int n, u32 barb, 
 {
     brf_init_acc(acc, barb, mu, lds, L.lane);
     for (int i = 0; i < n; i++) {
+        br_pace(lds.pace, (u32)i);
         const u32 a = WAVE_UNIFORM((u32)*brf_bara_slot(lds, i));
         if (a == 0) continue;
         brf_step(acc, a, bk + (long)i * BKF_ROW_ELEMS, lds, L);
     }
+    br_pace_done(lds.pace);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -20,6 +20,7 @@
 #define WAVE_ACC_BYTES WAVE_ACC_BYTES_K(1)
 #define WAVE_BARA_BYTES (BR_MAX_LWE * 2)
 #define WAVE_BR_LDS_BYTES_K(K) (WAVE_XBUF_BYTES + WAVE_ACC_BYTES_K(K) + WAVE_BARA_BYTES)
+#define BR_PACE_BYTES 64                  /* one progress word per wave of the one-bit kernels (BrPace) */
 // waves (= bits) per work-group, one work-group per CU: mask size 1 runs 2 waves/SIMD (<= 256 VGPRs,
 // ~19 KiB of LDS each); mask size 2 has a 12 KiB accumulator mirror per wave, 6 waves fill the LDS
 #define BR_WAVES_K(K) ((K) == 1 ? 8 : 6)
@@ -33,14 +34,28 @@ __device__ __forceinline__ void load_tables(const u64 *__restrict__ g_tw1f, cons
         t[i] = g_tw1f[i];
         t[1024 + i] = g_tw1i[i];
     }
+    if (threadIdx.x < BR_PACE_BYTES / 4) ((u32 *)(g_smem + TABLE_LDS_BYTES))[threadIdx.x] = 0;
     __syncthreads();
+}
+
+// progress words of wave `wave` and of the wave it shares its SIMD with (wave ^ 4), behind the tables at `base`
+__device__ __forceinline__ BrPace carve_pace(unsigned char *base, int wave)
+{
+    // (wave-uniform by construction; readfirstlane tells the compiler, so the two addresses live in SGPRs)
+    wave = __builtin_amdgcn_readfirstlane(wave);
+    const int waves = blockDim.x >> 6, other = wave ^ 4;
+    BrPace p;
+    p.mine = other < waves ? (u32 *)base + wave : nullptr;
+    p.other = (const u32 *)base + other;
+    return p;
 }
 
 template <int K>
 __device__ __forceinline__ BrLds carve_br_lds(int wave)
 {
-    unsigned char *base = g_smem + TABLE_LDS_BYTES + wave * WAVE_BR_LDS_BYTES_K(K);
+    unsigned char *base = g_smem + TABLE_LDS_BYTES + BR_PACE_BYTES + wave * WAVE_BR_LDS_BYTES_K(K);
     BrLds lds;
+    lds.pace = carve_pace(g_smem + TABLE_LDS_BYTES, wave);
     lds.xbuf = (u64 *)base;
     lds.acc = (i32 *)(base + WAVE_XBUF_BYTES);
     lds.bara = (uint16_t *)(base + WAVE_XBUF_BYTES + WAVE_ACC_BYTES_K(K));
@@ -144,6 +159,9 @@ __global__ __launch_bounds__(64 * BR_WAVES_K(K), K == 1 ? 2 : 1) void k_blind_ro
         }
     WAVE_SYNC();
     // (the accumulator is read from / updated in the LDS mirror, see blind_rotate.h)
+#if defined(BR_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+    BrProbe probe_ = {};
+#endif
     if (external_mul_only) {
         br_external_product<K>(
             [&](int m, u32(&T)[16]) {
@@ -151,12 +169,12 @@ __global__ __launch_bounds__(64 * BR_WAVES_K(K), K == 1 ? 2 : 1) void k_blind_ro
                 for (int r = 0; r < 16; r++) T[r] = (u32)lds.acc[m * 1024 + lane + 64 * r];
             },
             [&](int mo, int r, u32 v) { lds.acc[mo * 1024 + lane + 64 * r] = (i32)v; },
-            bk + (long)row0 * BK_ROW_ELEMS_K(K), lds, L);
+            bk + (long)row0 * BK_ROW_ELEMS_K(K), lds, L BR_PROBE_PASS);
     } else {
         for (int i = 0; i < n_rows; i++) {
             const u32 a = WAVE_UNIFORM((u32)bara[bit * bara_stride + i]) & 2047u;
             if (a == 0) continue;
-            br_step<K>(a, bk + (long)(row0 + i) * BK_ROW_ELEMS_K(K), lds, L);
+            br_step<K>(a, bk + (long)(row0 + i) * BK_ROW_ELEMS_K(K), lds, L BR_PROBE_PASS);
         }
     }
     WAVE_SYNC();
@@ -183,13 +201,15 @@ __device__ __forceinline__ void load_ftables(const cplx *__restrict__ g_tw1, con
     cplx *t = (cplx *)g_smem;
     for (int i = threadIdx.x; i < FFT_TW1_ELEMS; i += blockDim.x) t[i] = g_tw1[i];
     for (int i = threadIdx.x; i < FFT_TW2_ELEMS; i += blockDim.x) t[FFT_TW1_ELEMS + i] = g_tw2[i];
+    if (threadIdx.x < BR_PACE_BYTES / 4) ((u32 *)(g_smem + FTABLE_LDS_BYTES))[threadIdx.x] = 0;
     __syncthreads();
 }
 
 __device__ __forceinline__ BrFftLds carve_brf_lds(int wave)
 {
-    unsigned char *base = g_smem + FTABLE_LDS_BYTES + wave * WAVE_BRF_LDS_BYTES;
+    unsigned char *base = g_smem + FTABLE_LDS_BYTES + BR_PACE_BYTES + wave * WAVE_BRF_LDS_BYTES;
     BrFftLds lds;
+    lds.pace = carve_pace(g_smem + FTABLE_LDS_BYTES, wave);
     lds.xbufA = (cplx *)base;
     lds.xbufB = (cplx *)(base + WAVE_FXBUF_BYTES);
     lds.park = (u32 *)(base + 2 * WAVE_FXBUF_BYTES);
@@ -887,9 +907,9 @@ __global__ void k_l4_op(u32 *__restrict__ out, u32 *__restrict__ out2, const u32
 // ------------------------------------------------------------------------------------------
 static inline unsigned blocks_for(long n, int per) { return (unsigned)((n + per - 1) / per); }
 
-static constexpr size_t br_lds_bytes(int K, int waves) { return TABLE_LDS_BYTES + (size_t)waves * WAVE_BR_LDS_BYTES_K(K); }
+static constexpr size_t br_lds_bytes(int K, int waves) { return TABLE_LDS_BYTES + BR_PACE_BYTES + (size_t)waves * WAVE_BR_LDS_BYTES_K(K); }
 static constexpr size_t br_lds_bytes(int K) { return br_lds_bytes(K, BR_WAVES_K(K)); }
-static constexpr size_t brf_lds_bytes(int waves) { return FTABLE_LDS_BYTES + (size_t)waves * WAVE_BRF_LDS_BYTES; }
+static constexpr size_t brf_lds_bytes(int waves) { return FTABLE_LDS_BYTES + BR_PACE_BYTES + (size_t)waves * WAVE_BRF_LDS_BYTES; }
 static const size_t kBrfLds = brf_lds_bytes(BR_WAVES_PER_BLOCK);
 
 // Waves (= bits) per work-group for a batch of nbits: one work-group per CU and `max_waves` waves
@@ -1203,3 +1223,19 @@ hipError_t launch_tlwe_extract(i32 *ra, i32 *rb, const i32 *tlwe, long batch, in
                        tlwe, batch, mask_size);
     return hipGetLastError();
 }
+
+#if defined(BR_PROBE)
+// variant builds only (blind_rotate.h, BR_PROBE): read and clear the segment tick counters
+extern "C" int nufhe_probe_read(unsigned long long *out16)
+{
+    unsigned long long zero[16] = {0};
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_br_probe), sizeof(zero)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_br_probe), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+extern "C" int nufhe_probe_lifetimes(unsigned int *out, int count)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_br_probe_life), sizeof(unsigned) * count) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -133,7 +133,7 @@ static void bootstrap_bit(i32 *out_a, i32 *out_b, const u64 *bk_internal, int n,
     std::vector<u64> xbuf(NTT_XBUF_ELEMS);
     std::vector<i32> accbuf((K + 1) * 1024);
     std::vector<uint16_t> bara(BR_MAX_LWE);
-    BrLds lds{xbuf.data(), accbuf.data(), bara.data(), g_tw1x, g_tw1i};
+    BrLds lds{xbuf.data(), accbuf.data(), bara.data(), g_tw1x, g_tw1i, {nullptr, nullptr}};
     BrSource s0{a0, b0, 0, 0, p0}, s1{a1, b1, 0, 0, p1};
     emu_run_wave([&](int lane) {
         NttLane L = ntt_lane_init(lane);
@@ -290,7 +290,7 @@ void emu_bootstrap_bit_fft(i32 *out_a, i32 *out_b, const double *bk_internal, in
     ftables();
     std::vector<cplx> xbuf(2 * FFT_XBUF_ELEMS);
     std::vector<u32> park((BRF_PARK - 4) * 64);
-    BrFftLds lds{xbuf.data(), xbuf.data() + FFT_XBUF_ELEMS, park.data(), g_ftw1, g_ftw2};
+    BrFftLds lds{xbuf.data(), xbuf.data() + FFT_XBUF_ELEMS, park.data(), g_ftw1, g_ftw2, {nullptr, nullptr}};
     BrSource s0{a0, b0, 0, 0, p0}, s1{a1, b1, 0, 0, p1};
     emu_run_wave([&](int lane) {
         FftLane L = fft_lane_init(lane);

@@ -12,7 +12,9 @@
 #include "ntt1024_l4.h"
 #include "ntt_tables.h"
 
+#ifndef REPS
 #define REPS 64
+#endif
 extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
 __device__ __forceinline__ void load_tw(const u64 *g)
@@ -35,6 +37,7 @@ __global__ __launch_bounds__(512, 2) void k_transform(u64 *io, const i32 *d, con
     u32 c[16];
     for (int r = 0; r < 16; r++) dg[r] = d[base + 512 * r];
     for (int r = 0; r < 16; r++) x[r] = io[base + 512 * r];
+    const long long w0 = wall_clock64();
     const long long t0 = clock64();
     for (int it = 0; it < REPS; it++) {
         if (MODE == 0) {            // forward, 64-bit form
@@ -52,8 +55,12 @@ __global__ __launch_bounds__(512, 2) void k_transform(u64 *io, const i32 *d, con
         }
     }
     const long long t1 = clock64();
+    const long long w1 = wall_clock64();
     for (int r = 0; r < 16; r++) io[base + 512 * r] = x[r] + (u64)dg[r];
-    if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
+    if ((threadIdx.x & 63) == 0) {
+        cycles[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
+        cycles[2048 + blockIdx.x * 8 + (threadIdx.x >> 6)] = w1 - w0;     // constant-rate counter (hipDeviceAttributeWallClockRate)
+    }
 }
 
 template <int MODE>
@@ -71,14 +78,17 @@ static void run_transform(const char *name, u64 *d_io, i32 *d_d, u64 *d_tw, long
     hipEventSynchronize(e1);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
-    std::vector<long long> cyc(blocks * 8);
+    std::vector<long long> cyc(2 * blocks * 8);
     hipMemcpy(cyc.data(), d_cyc, cyc.size() * 8, hipMemcpyDeviceToHost);
-    double avg = 0;
-    for (long long v : cyc) avg += (double)v;
-    avg /= cyc.size();
+    double avg = 0, wall = 0;
+    for (int i = 0; i < blocks * 8; i++) { avg += (double)cyc[i]; wall += (double)cyc[2048 + i]; }
+    avg /= blocks * 8; wall /= blocks * 8;
+    int wall_khz = 0;
+    hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0);
     // a wave shares its SIMD with one other wave: SIMD cycles per transform = wave-resident cycles / 2
-    printf("%-34s %8.3f ms   %9.0f clock64 ticks per transform per wave, %7.1f us wall per transform\n", name, ms,
-           avg / REPS, ms * 1e3 / REPS);
+    printf("%-34s %8.3f ms   %9.0f clock64 ticks per transform per wave, %7.1f us wall per transform; "
+           "clock64 rate %.3f GHz (wall_clock64 at %d kHz)\n", name, ms,
+           avg / REPS, ms * 1e3 / REPS, avg / (wall / (wall_khz * 1e3)) * 1e-9, wall_khz);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -181,7 +191,7 @@ int main()
     u64 *d_io, *d_tw;
     i32 *d_d;
     long long *d_cyc;
-    hipMalloc(&d_io, n * 8); hipMalloc(&d_tw, 2048 * 8); hipMalloc(&d_d, n * 4); hipMalloc(&d_cyc, 256 * 8 * 8);
+    hipMalloc(&d_io, n * 8); hipMalloc(&d_tw, 2048 * 8); hipMalloc(&d_d, n * 4); hipMalloc(&d_cyc, 2 * 256 * 8 * 8);
     hipMemcpy(d_io, io.data(), n * 8, hipMemcpyHostToDevice);
     hipMemcpy(d_d, dg.data(), n * 4, hipMemcpyHostToDevice);
     hipMemcpy(d_tw, tw.data(), 2048 * 8, hipMemcpyHostToDevice);
