@@ -99,6 +99,13 @@ def issue_roofline(transform, bits, rotations, n_iter, kernel_ms):
                                                            k.get("valu_half_rate", 0), costs["half_rate_cycles"], cyc)})
     elif transform == "FFT":
         flops = iters * 64.0 * k.get("f64_flops_per_lane", 0)
+        if costs is not None and clock:
+            # secondary reading: the transform is add/sub-dominated (fma = 2 flops is a quarter of its fp64
+            # instructions), so the fma peak is out of reach by construction; issue slots used / available
+            cyc = (k.get("valu_f64", 0) * costs.get("f64_fma_cycles", 4.0) + k.get("valu_full_rate", 0) * costs["full_rate_cycles"]
+                   + k.get("valu_half_rate", 0) * costs["half_rate_cycles"])
+            out["valu_issue"] = {"cycles_per_bit_iteration": cyc,
+                                 "frac": iters * cyc / (simds * clock * 1e9 * kernel_ms * 1e-3)}
         out.update({"bound": "fp64-fma", "achieved": flops / (kernel_ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": flops / (kernel_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                     "model": "fp64 flops issued per bit-iteration (fma = 2): 64 lanes x %d" % k.get("f64_flops_per_lane", 0)})

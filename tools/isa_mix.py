@@ -9,7 +9,7 @@ scratch use and the number of VALU instructions by ISSUE CLASS (measured on gfx9
 occupancy, profiles/r02_microbench_l4.txt):
     full   v_add/sub/subrev_u32, v_and/or/xor/not_b32, v_lshrrev_b32, v_ashrrev_i32, v_mov_b32, v_cndmask_b32
     half   everything else 32/64-bit integer (carry chains, compares, v_lshlrev, v_perm, v_mad_u64_u32, VOP3 ...)
-    f64    v_fma_f64 / v_mul_f64 / v_add_f64 (counted separately: flops)
+    f64    v_fma_f64 / v_fmac_f64 / v_mul_f64 / v_add_f64 (counted separately: flops)
 plus SALU, LDS, memory, s_waitcnt and hazard s_nop counts.  The weighted VALU figure decides the NTT
 kernel's speed.  `profiles/isa_mix.json` also records a hash of the device sources so that
 tests/test_cabi_and_host.py can tell when it is stale.
@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'nufhe_amd', 'csrc')
 FULL_RATE = {'v_add_u32', 'v_sub_u32', 'v_subrev_u32', 'v_and_b32', 'v_or_b32', 'v_xor_b32', 'v_not_b32',
              'v_lshrrev_b32', 'v_ashrrev_i32', 'v_mov_b32', 'v_cndmask_b32'}
-F64 = {'v_fma_f64': 2, 'v_mul_f64': 1, 'v_add_f64': 1}
+F64 = {'v_fma_f64': 2, 'v_fmac_f64': 2, 'v_mul_f64': 1, 'v_add_f64': 1}
 KERNELS = {'k_bootstrap<1>': '_Z11k_bootstrapILi1EEv8BrLaunch', 'k_bootstrap_fft': '_Z15k_bootstrap_fft8BrLaunch'}
 
 
