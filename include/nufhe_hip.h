@@ -200,12 +200,17 @@ int nufhe_blind_rotate(nufhe_ctx *ctx, nufhe_cloudkey *key, int32_t *d_accum,
 int nufhe_tlwe_encrypt_zero(nufhe_ctx *ctx, int32_t *d_result_a, const int32_t *d_key,
                             const int32_t *d_noises1, const int32_t *d_noises2, long batch, int mask_size);
 
-/* Batch-size switch of the k=1 bootstrap: a bootstrap of up to `bits` ciphertext bits (FFT: bits/2) runs the
- * small-batch kernel (4 wavefronts share a bit; NTT ~2.7x, FFT ~1.4x shorter latency, one bit per CU at a time),
- * larger batches the throughput kernel (one wavefront per bit).  bits < 0 restores the default
- * (2 x the CU count); 0 disables the small-batch kernel.  Results are bit-identical either way.
+/* Batch-size switches of the bootstrap.  A bootstrap of up to `bits` ciphertext bits (FFT: bits/2) runs the
+ * small-batch kernel (4 wavefronts share a bit, 3 for tlwe_mask_size = 2; NTT ~2.7x, FFT ~1.4x shorter latency, one
+ * bit per CU at a time), larger batches the throughput kernel (one wavefront per bit).  bits < 0 restores the
+ * default (the CU count for k = 1, twice that for k = 2); 0 disables the small-batch kernel.  Results are
+ * bit-identical either way.
  * No reference counterpart (the reference always splits a bit over 512+ threads, blind_rotate.py:89-187). */
 int nufhe_ctx_set_team_max_bits(nufhe_ctx *ctx, long bits);
+/* NTT, k = 1 only: batches above the small-batch limit and up to `bits` run the medium-batch kernel (2 wavefronts
+ * per bit, up to 4 bits per CU at a time; ~1.5x shorter latency than one wavefront per bit while the batch cannot
+ * give every SIMD two bits).  bits < 0 restores the default (4 x the CU count); 0 disables it. */
+int nufhe_ctx_set_pair_max_bits(nufhe_ctx *ctx, long bits);
 
 /* ---- measurement: time of the last fused gate / bootstrap kernels, from HIP events on the
  * context's stream (milliseconds; blind-rotate kernel and keyswitch kernels separately) ---- */

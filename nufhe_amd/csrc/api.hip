@@ -54,7 +54,8 @@ struct nufhe_ctx {
     cplx *d_ftw1 = nullptr;
     cplx *d_ftw2 = nullptr;
     Scratch ext_a, ext_b, ks_acc;
-    long team_max_bits = -1;   // batches up to this size use the 4-waves-per-bit kernel; -1 = 2 x CUs
+    long team_max_bits = -1;   // batches up to this size use the 4-waves-per-bit kernel; -1 = default (launch_bootstrap)
+    long pair_max_bits = -1;   // above that and up to this size: the 2-waves-per-bit kernel; -1 = 4 x CUs
     bool profile = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
@@ -558,8 +559,8 @@ static int run_gate(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result
         P.out_b = result.b; P.out_b_stride = result.b_stride;
     }
     if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-    HIP_TRY(launch_bootstrap(P, key->transform, key->mask_size,
-                             ctx->team_max_bits >= 0 ? ctx->team_max_bits : 2L * ctx->num_cus, ctx->num_cus, ctx->stream));
+    HIP_TRY(launch_bootstrap(P, key->transform, key->mask_size, ctx->team_max_bits, ctx->pair_max_bits, ctx->num_cus,
+                             ctx->stream));
     if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     if (keyswitch) {
         const i32 *ea = (const i32 *)ctx->ext_a.ptr, *eb = (const i32 *)ctx->ext_b.ptr;
@@ -802,6 +803,14 @@ int nufhe_ctx_set_team_max_bits(nufhe_ctx *ctx, long bits)
     int rc = check_ctx(ctx);
     if (rc) return rc;
     ctx->team_max_bits = bits;
+    return NUFHE_OK;
+}
+
+int nufhe_ctx_set_pair_max_bits(nufhe_ctx *ctx, long bits)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    ctx->pair_max_bits = bits;
     return NUFHE_OK;
 }
 

@@ -642,3 +642,111 @@ FF_FN void brtk_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSo
     }
     if (tid == 0) *out_b = lds.acc[K * 1024];
 }
+
+// ------------------------------------------------------------------------------------------
+// Pair variant (k = 1): TWO wavefronts per ciphertext bit, for batches between the team kernel and a full chip
+// (2 x CUs < bits <= 4 x CUs).  With one wave per bit such a batch leaves every SIMD with a single wave, which
+// fills ~60 % of its issue slots; two waves per bit halve the dependent chain of a bit and put two waves (of
+// different bits) on each SIMD once the batch exceeds 2 x CUs:
+//   wave W (0 or 1)  decomposes BOTH digits of polynomial W of (X^a - 1) ACC, transforms them and multiplies them
+//                    with BK_i[W][0..1][0..1]: its partial sums of both output polynomials  (2 forward transforms)
+//   exchange         the partial sum of the OTHER wave's output goes through this wave's exchange buffer (idle
+//                    between the products and the inverse transform), pair barrier, the other wave adds it to its
+//                    own partial sum, pair barrier (the buffer is free again)
+//   wave W           transforms output polynomial W back and updates ACC[W]         (1 inverse transform)
+// Wave W is the only reader and writer of ACC[W] during the loop.  The partial sums are canonical field elements
+// and field addition is exact, so the result is bit-identical to the one-wave path.  pair_sync() is a barrier over
+// the two waves (kernels.hip: a counter handshake in LDS -- a work-group holds several pairs, which skip a == 0
+// steps independently, so the work-group barrier cannot be used).
+// ------------------------------------------------------------------------------------------
+struct BrPairLds {
+    u64 *xbuf;               // this wave's exchange buffer (NTT_XBUF_ELEMS u64)
+    const u64 *xbuf_other;   // the other wave's
+    i32 *acc;                // [2][1024], shared by the pair
+    uint16_t *bara;          // [BR_MAX_LWE], shared
+    const u64 *tw1x;
+    const u64 *tw1i;
+    BrPace pace;             // against the wave of ANOTHER pair on the same SIMD
+};
+
+template <int W, class PairSync>
+FF_FN void brp_step(u32 a, const u64 *row, const BrPairLds &lds, const NttLane &L, PairSync &&pair_sync)
+{
+    const int lane = L.lane;
+    u32 T[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const u32 j = (u32)(lane + 64 * r);
+        const u32 t = (j - a) & 2047u;
+        const u32 v = (u32)lds.acc[W * 1024 + (t & 1023u)];
+        T[r] = ((t & 1024u) ? 0u - v : v) - (u32)lds.acc[W * 1024 + j];     // (X^a - 1) ACC_W
+    }
+    u64 sum[16];
+    {
+        u64 x0[16], x1[16];
+        i32 dg[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) dg[r] = br_digit<0>(T[r]);
+        ntt_forward_small_l4(x0, dg, lds.xbuf, lds.tw1x, L);
+#pragma unroll
+        for (int r = 0; r < 16; r++) dg[r] = br_digit<1>(T[r]);
+        ntt_forward_small_l4(x1, dg, lds.xbuf, lds.tw1x, L);
+        u64 ps[2][16];
+        br_mac2<1, true>(ps, x0, x1, row + (long)W * 4 * BK_POLY_ELEMS, lane);
+        WAVE_SYNC();     // every lane is done with the exchange buffer
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            lds.xbuf[r * 64 + lane] = ps[1 - W][r];
+            sum[r] = ps[W][r];
+        }
+    }
+    pair_sync();
+#pragma unroll
+    for (int r = 0; r < 16; r++) sum[r] = ff_add(sum[r], lds.xbuf_other[r * 64 + lane]);
+    pair_sync();
+    u32 c[16];
+    ntt_inverse_l4_i32(c, sum, lds.xbuf, lds.tw1i, L);
+#pragma unroll
+    for (int r = 0; r < 16; r++) lds.acc[W * 1024 + lane + 64 * r] += (i32)(r == 0 ? c[r] : 0u - c[r]);
+    WAVE_SYNC();
+}
+
+// Whole bootstrap body of wave W of a pair for one bit
+template <int W, class PairSync>
+FF_FN void brp_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSource &s1, i32 c0, long bit,
+                         const u64 *bk, int n, i32 mu, const BrPairLds &lds, const NttLane &L, PairSync &&pair_sync)
+{
+    const int tid = 64 * W + L.lane;
+    for (int i = tid; i < n; i += 128) {
+        u32 v = 0;
+        if (s0.p) v += (u32)s0.p * (u32)s0.a[bit * s0.a_stride + i];
+        if (s1.p) v += (u32)s1.p * (u32)s1.a[bit * s1.a_stride + i];
+        lds.bara[i] = (uint16_t)br_modswitch(v);
+    }
+    u32 vb = (u32)c0;
+    if (s0.p) vb += (u32)s0.p * (u32)s0.b[bit * s0.b_stride];
+    if (s1.p) vb += (u32)s1.p * (u32)s1.b[bit * s1.b_stride];
+    const u32 barb = br_modswitch(vb);
+    // ACC = (0, X^(2N - barb) * mu)  (bootstrap.py:176-182)
+    for (int j = tid; j < 1024; j += 128) {
+        const u32 t = ((u32)j + barb) & 2047u;
+        lds.acc[j] = 0;
+        lds.acc[1024 + j] = (t < 1024u) ? mu : (i32)(0u - (u32)mu);
+    }
+    WAVE_SYNC();
+    pair_sync();
+    for (int i = 0; i < n; i++) {
+        br_pace(lds.pace, (u32)i);
+        const u32 a = WAVE_UNIFORM((u32)lds.bara[i]);
+        if (a == 0) continue;
+        brp_step<W>(a, bk + (long)i * BK_ROW_ELEMS, lds, L, pair_sync);
+    }
+    br_pace_done(lds.pace);
+    pair_sync();
+    // sample extraction (tlwe_cpu.py:55-58)
+    for (int j = tid; j < 1024; j += 128) {
+        const u32 v = (u32)lds.acc[j];
+        out_a[(1024 - j) & 1023] = (i32)(j == 0 ? v : 0u - v);
+    }
+    if (tid == 0) *out_b = lds.acc[1024];
+}

@@ -72,7 +72,7 @@ struct LweView {
 
 hipError_t kernels_init_device(int *num_cus);
 // transform: 0 = NTT, 1 = FFT
-hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, long team_max_bits, int num_cus,
+hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, long team_max_bits, long pair_max_bits, int num_cus,
                             hipStream_t stream);
 hipError_t launch_ff_op(u64 *out, const u64 *a, const u64 *b, const u64 *c, const u64 *d, const u64 *e, int op,
                         int shift, long count, hipStream_t stream);

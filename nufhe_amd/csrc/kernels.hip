@@ -136,6 +136,51 @@ __global__ __launch_bounds__(64 * 3, 1) void k_bootstrap_team_k2(BrLaunch P)
 
 // Test hook / multi-kernel-style entry: blind rotate (or a single external product) on
 // accumulators held in global memory: accum int32 [batch][2][1024]
+// Medium batches (2 x CUs < bits <= 4 x CUs): two waves per bit, up to 4 pairs per work-group, see blind_rotate.h
+// (brp_*).  LDS: tables | progress / barrier words | per pair: ACC 8 KiB, bara 1 KiB, 2 exchange buffers
+#define PAIR_LDS_BYTES (2 * 1024 * 4 + WAVE_BARA_BYTES + 2 * WAVE_XBUF_BYTES)
+#define BRP_MAX_PAIRS 4
+__global__ __launch_bounds__(128 * BRP_MAX_PAIRS, 2) void k_bootstrap_pair(BrLaunch P)
+{
+    load_tables((const u64 *)P.tw_a, (const u64 *)P.tw_b);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int pair = wave >> 1;
+    const long gbit = (long)blockIdx.x * (blockDim.x >> 7) + pair;   // pairs per group chosen at launch
+    if (gbit >= P.nbits_total) return;                                // (both waves of the pair)
+    const int job = gbit >= P.bits_per_job ? 1 : 0;
+    const long bit = gbit - (job ? P.bits_per_job : 0);
+    unsigned char *base = g_smem + TABLE_LDS_BYTES + BR_PACE_BYTES + pair * PAIR_LDS_BYTES;
+    BrPairLds lds;
+    lds.acc = (i32 *)base;
+    lds.bara = (uint16_t *)(base + 2 * 1024 * 4);
+    lds.xbuf = (u64 *)(base + 2 * 1024 * 4 + WAVE_BARA_BYTES + (wave & 1) * WAVE_XBUF_BYTES);
+    lds.xbuf_other = (const u64 *)(base + 2 * 1024 * 4 + WAVE_BARA_BYTES + ((wave & 1) ^ 1) * WAVE_XBUF_BYTES);
+    lds.tw1x = (const u64 *)g_smem;
+    lds.tw1i = (const u64 *)g_smem + 1024;
+    lds.pace = carve_pace(g_smem + TABLE_LDS_BYTES, wave);
+    // pair barrier: arrival counters of the two waves behind the 8 progress words (zeroed by load_tables).  The
+    // release store orders this wave's earlier LDS traffic before its counter, the acquire load the partner's
+    // counter before this wave's later reads.
+    u32 *arrive = (u32 *)(g_smem + TABLE_LDS_BYTES) + 8;
+    u32 *mine = arrive + wave;
+    const u32 *other = arrive + (wave ^ 1);
+    u32 seq = 0;
+    auto pair_sync = [&] {
+        seq++;
+        __hip_atomic_store(mine, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while ((i32)((u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(other, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) - seq) < 0)
+            __builtin_amdgcn_s_sleep(1);
+    };
+    const NttLane L = ntt_lane_init(lane);
+    i32 *out_a = P.out_a + gbit * P.out_a_stride, *out_b = P.out_b + gbit * P.out_b_stride;
+    if ((wave & 1) == 0)
+        brp_bootstrap<0>(out_a, out_b, P.job[job].s0, P.job[job].s1, P.job[job].c0, bit, (const u64 *)P.bk, P.n, P.mu,
+                         lds, L, pair_sync);
+    else
+        brp_bootstrap<1>(out_a, out_b, P.job[job].s0, P.job[job].s1, P.job[job].c0, bit, (const u64 *)P.bk, P.n, P.mu,
+                         lds, L, pair_sync);
+}
+
 template <int K>
 __global__ __launch_bounds__(64 * BR_WAVES_K(K), K == 1 ? 2 : 1) void k_blind_rotate_accum(
     i32 *__restrict__ accum, const u64 *__restrict__ bk, const i32 *__restrict__ bara, long bara_stride,
@@ -909,6 +954,7 @@ static inline unsigned blocks_for(long n, int per) { return (unsigned)((n + per 
 
 static constexpr size_t br_lds_bytes(int K, int waves) { return TABLE_LDS_BYTES + BR_PACE_BYTES + (size_t)waves * WAVE_BR_LDS_BYTES_K(K); }
 static constexpr size_t br_lds_bytes(int K) { return br_lds_bytes(K, BR_WAVES_K(K)); }
+static constexpr size_t brp_lds_bytes(int pairs) { return TABLE_LDS_BYTES + BR_PACE_BYTES + (size_t)pairs * PAIR_LDS_BYTES; }
 static constexpr size_t brf_lds_bytes(int waves) { return FTABLE_LDS_BYTES + BR_PACE_BYTES + (size_t)waves * WAVE_BRF_LDS_BYTES; }
 static const size_t kBrfLds = brf_lds_bytes(BR_WAVES_PER_BLOCK);
 
@@ -950,6 +996,8 @@ hipError_t kernels_init_device(int *num_cus)
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap_team_k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAM2_LDS_BYTES);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_bootstrap_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)brp_lds_bytes(BRP_MAX_PAIRS));
+    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_blind_rotate_accum<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(1));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_blind_rotate_accum<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(2));
@@ -981,13 +1029,24 @@ hipError_t launch_l4_op(u32 *out, u32 *out2, const u32 *a, const u32 *b, const u
     return hipGetLastError();
 }
 
-hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, long team_max_bits, int num_cus,
-                            hipStream_t stream)
+hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, long team_max_bits, long pair_max_bits,
+                            int num_cus, hipStream_t stream)
 {
     if (P.nbits_total == 0) return hipSuccess;
+    // defaults of the batch-size switches (negative = default): NTT k = 1: team kernel up to 1 x CUs, pair kernel up
+    // to 4 x CUs; NTT k = 2: team kernel up to 2 x CUs; FFT: team kernel up to 1 x CUs (an explicit value counts
+    // half for the FFT kernels, see nufhe_hip.h)
+    if (pair_max_bits < 0) pair_max_bits = (long)BRP_MAX_PAIRS * num_cus;
+    if (team_max_bits < 0) team_max_bits = (transform == 0 && mask_size == 1) ? (long)num_cus : 2L * num_cus;
     if (transform == 0 && mask_size == 1 && P.nbits_total <= team_max_bits) {
         // small batch: 4 waves per bit, one bit per CU at a time
         hipLaunchKernelGGL(k_bootstrap_team, dim3((unsigned)P.nbits_total), dim3(64 * BRT_WAVES), TEAM_LDS_BYTES, stream, P);
+    } else if (transform == 0 && mask_size == 1 && P.nbits_total <= pair_max_bits) {
+        // medium batch: 2 waves per bit; as few pairs per work-group as still give one round
+        long pairs = (P.nbits_total + num_cus - 1) / num_cus;
+        if (pairs > BRP_MAX_PAIRS) pairs = BRP_MAX_PAIRS;
+        hipLaunchKernelGGL(k_bootstrap_pair, dim3(blocks_for(P.nbits_total, (int)pairs)), dim3(128 * (unsigned)pairs),
+                           brp_lds_bytes((int)pairs), stream, P);
     } else if (transform == 0 && mask_size == 1) {
         const int w = br_pick_waves(P.nbits_total, BR_WAVES_K(1), num_cus);
         hipLaunchKernelGGL(k_bootstrap<1>, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), br_lds_bytes(1, w), stream, P);

@@ -162,6 +162,25 @@ extern "C" void emu_bootstrap_bit_team(i32 *out_a, i32 *out_b, const u64 *bk_int
     });
 }
 
+// the 2-wave pair variant (blind_rotate.h, brp_*): 128 fibres, pair barrier = emu_team_sync
+extern "C" void emu_bootstrap_bit_pair(i32 *out_a, i32 *out_b, const u64 *bk_internal, int n,
+                                       const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,
+                                       i32 c0, i32 mu)
+{
+    tables();
+    std::vector<u64> xbuf(2 * NTT_XBUF_ELEMS);
+    std::vector<i32> accbuf(2 * 1024);
+    std::vector<uint16_t> bara(BR_MAX_LWE);
+    BrSource s0{a0, b0, 0, 0, p0}, s1{a1, b1, 0, 0, p1};
+    emu_run_team(2, [&](int w, int lane) {
+        BrPairLds lds{xbuf.data() + w * NTT_XBUF_ELEMS, xbuf.data() + (w ^ 1) * NTT_XBUF_ELEMS, accbuf.data(), bara.data(),
+                      g_tw1x, g_tw1i, {nullptr, nullptr}};
+        NttLane L = ntt_lane_init(lane);
+        if (w == 0) brp_bootstrap<0>(out_a, out_b, s0, s1, c0, 0, bk_internal, n, mu, lds, L, [] { emu_team_sync(); });
+        else brp_bootstrap<1>(out_a, out_b, s0, s1, c0, 0, bk_internal, n, mu, lds, L, [] { emu_team_sync(); });
+    });
+}
+
 // the 3-wave team variant for tlwe_mask_size = 2 (blind_rotate.h, brtk_*): 192 fibres
 extern "C" void emu_bootstrap_bit_team_k2(i32 *out_a, i32 *out_b, const u64 *bk_internal, int n,
                                           const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,

@@ -89,6 +89,10 @@ def test_bootstrap_wave_body_reduced(orc):
         ga, gb = emu.bootstrap_bit(bki, n, (a0, b0), -1, (a1, b1), -1, MU, MU, team=True)
         assert (ga == ea[0]).all()
         assert gb == eb[0]
+        # the 2-wave pair variant (medium batches): identical bits
+        ga, gb = emu.bootstrap_bit(bki, n, (a0, b0), -1, (a1, b1), -1, MU, MU, pair=True)
+        assert (ga == ea[0]).all()
+        assert gb == eb[0]
 
 
 @pytest.mark.slow

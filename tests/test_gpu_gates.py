@@ -217,9 +217,9 @@ def test_error_behaviour(env):
 
 
 def test_small_batch_team_kernel_equals_wave_kernel(env, orc):
-    """The 4-waves-per-bit kernel (batches <= 2 x CUs by default) and the wave-per-bit kernel give
-    bit-identical ciphertexts, both equal to the oracle; the switch is exercised on both sides of
-    its boundary (nufhe_ctx_set_team_max_bits)."""
+    """The 4-waves-per-bit kernel (batches <= CUs by default), the 2-waves-per-bit kernel (<= 4 x CUs) and the
+    wave-per-bit kernel give bit-identical ciphertexts, all equal to the oracle; the switches are exercised on both
+    sides of their boundaries (nufhe_ctx_set_team_max_bits / nufhe_ctx_set_pair_max_bits)."""
     from nufhe_amd import _lib
     H = env['H']; thr = env['thr']; vm = env['vm']; ck = env['ck']; lwe_key = env['lwe_key']
     rng = orc.DeterministicRNG(2024)
@@ -230,13 +230,47 @@ def test_small_batch_team_kernel_equals_wave_kernel(env, orc):
     exp_nand = orc.gate('gate_nand', ck, cs[0], cs[1])
     exp_mux = orc.gate_mux(ck, cs[0], cs[1], cs[2])
     try:
-        for limit in (0, 69, 70, 139, 140, -1):      # MUX launches 2 B = 140 bits in one bootstrap
-            _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, limit)
+        # MUX launches 2 B = 140 bits in one bootstrap.  (team limit, pair limit): (0, 0) = wave kernel only,
+        # (0, -1) = pair kernel, (69, 139): NAND pair / MUX wave, (70, 140): NAND team / MUX pair, ...
+        for team, pair in ((0, 0), (0, -1), (69, 139), (69, 140), (70, 140), (139, 0), (140, -1), (-1, -1)):
+            _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, team)
+            _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, pair)
             for got, exp in ((vm.gate_nand(ds[0], ds[1]), exp_nand), (vm.gate_mux(ds[0], ds[1], ds[2]), exp_mux)):
                 ra, rb, rcv = H.ct_arrays(got)
-                assert (ra == exp[0]).all() and (rb == exp[1]).all() and (rcv == exp[2]).all(), limit
+                assert (ra == exp[0]).all() and (rb == exp[1]).all() and (rcv == exp[2]).all(), (team, pair)
     finally:
         _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, -1)
+        _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, -1)
+
+
+def test_medium_batch_pair_kernel_every_group_size(env, orc):
+    """The 2-waves-per-bit kernel with 1, 2, 3 and 4 pairs per work-group (ragged last group included) against the
+    wave-per-bit kernel on the same ciphertexts: bit-identical; the first 24 bits also against the oracle."""
+    import torch
+    from nufhe_amd import _lib
+    H = env['H']; thr = env['thr']; vm = env['vm']; ck = env['ck']; lwe_key = env['lwe_key']
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    rng = orc.DeterministicRNG(77)
+    sizes = [cus - 3, 2 * cus - 5, 3 * cus - 1, 4 * cus]
+    B = max(sizes)
+    ms = [rng.uniform_bool((B,)).astype(bool) for _ in range(2)]
+    cs = [orc.encrypt(rng, lwe_key, m) for m in ms]
+    ds = [H.ciphertext_from_arrays(thr, c) for c in cs]
+    exp = orc.gate('gate_nand', ck, tuple(x[:24] for x in cs[0]), tuple(x[:24] for x in cs[1]))
+    try:
+        for size in sizes:
+            a, b = ds[0][:size], ds[1][:size]
+            _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, 0)
+            _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, 0)
+            wave = H.ct_arrays(vm.gate_nand(a, b))
+            _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, -1)
+            pair = H.ct_arrays(vm.gate_nand(a, b))
+            for x, y in zip(wave, pair):
+                assert (x == y).all(), size
+            assert (pair[0][:24] == exp[0]).all() and (pair[1][:24] == exp[1]).all() and (pair[2][:24] == exp[2]).all()
+    finally:
+        _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, -1)
+        _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, -1)
 
 
 @pytest.mark.parametrize('script', ['gate_nand.py', 'gate_nand_low_level.py', 'serialization.py'])
