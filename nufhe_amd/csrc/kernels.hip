@@ -1029,6 +1029,30 @@ hipError_t launch_l4_op(u32 *out, u32 *out2, const u32 *a, const u32 *b, const u
     return hipGetLastError();
 }
 
+// P restricted to the global bits [g0, g1): the same kernels run on it (sources and outputs moved to g0)
+static BrLaunch br_sub_launch(const BrLaunch &P, long g0, long g1)
+{
+    auto moved = [](BrSource s, long bits) {
+        if (s.p) { s.a += bits * s.a_stride; s.b += bits * s.b_stride; }
+        return s;
+    };
+    BrLaunch Q = P;
+    if (g0 >= P.bits_per_job) {          // entirely inside the second job
+        Q.job[0] = P.job[1];
+        Q.job[0].s0 = moved(P.job[1].s0, g0 - P.bits_per_job);
+        Q.job[0].s1 = moved(P.job[1].s1, g0 - P.bits_per_job);
+        Q.bits_per_job = g1 - g0;
+    } else {
+        Q.job[0].s0 = moved(P.job[0].s0, g0);
+        Q.job[0].s1 = moved(P.job[0].s1, g0);
+        Q.bits_per_job = P.bits_per_job - g0;
+    }
+    Q.nbits_total = g1 - g0;
+    Q.out_a = P.out_a + g0 * P.out_a_stride;
+    Q.out_b = P.out_b + g0 * P.out_b_stride;
+    return Q;
+}
+
 hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, long team_max_bits, long pair_max_bits,
                             int num_cus, hipStream_t stream)
 {
@@ -1048,6 +1072,20 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, lon
         hipLaunchKernelGGL(k_bootstrap_pair, dim3(blocks_for(P.nbits_total, (int)pairs)), dim3(128 * (unsigned)pairs),
                            brp_lds_bytes((int)pairs), stream, P);
     } else if (transform == 0 && mask_size == 1) {
+        // large batch: whole rounds of 8 waves per CU; a last partial round that the small- or medium-batch kernel
+        // finishes sooner than a round of the wave kernel (21 ms) goes to that kernel in a second launch
+        const long round_bits = (long)BR_WAVES_K(1) * num_cus;
+        const long tail = P.nbits_total % round_bits, head = P.nbits_total - tail;
+        const long tail_limit = pair_max_bits > team_max_bits ? pair_max_bits : team_max_bits;
+        if (head > 0 && tail > 0 && tail <= tail_limit) {
+            const BrLaunch H = br_sub_launch(P, 0, head);
+            hipLaunchKernelGGL(k_bootstrap<1>, dim3(blocks_for(head, BR_WAVES_K(1))), dim3(64 * BR_WAVES_K(1)), br_lds_bytes(1),
+                               stream, H);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            return launch_bootstrap(br_sub_launch(P, head, P.nbits_total), transform, mask_size, team_max_bits,
+                                    pair_max_bits, num_cus, stream);
+        }
         const int w = br_pick_waves(P.nbits_total, BR_WAVES_K(1), num_cus);
         hipLaunchKernelGGL(k_bootstrap<1>, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), br_lds_bytes(1, w), stream, P);
     } else if (transform == 0 && mask_size == 2 && P.nbits_total <= team_max_bits) {

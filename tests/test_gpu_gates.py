@@ -273,6 +273,51 @@ def test_medium_batch_pair_kernel_every_group_size(env, orc):
         _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, -1)
 
 
+def test_large_batch_tail_goes_to_the_small_batch_kernels(env, orc):
+    """A batch of whole rounds + a short last round is split into two launches (wave kernel for the rounds, team /
+    pair kernel for the tail, for MUX across the boundary of its two blind rotations): bit-identical to the single
+    wave-kernel launch on every bit, and to the oracle on the first and the last 12 bits."""
+    import torch
+    from nufhe_amd import _lib
+    H = env['H']; thr = env['thr']; vm = env['vm']; ck = env['ck']; lwe_key = env['lwe_key']
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    rng = orc.DeterministicRNG(99)
+    B = 10 * cus - 3
+    ms = [rng.uniform_bool((B,)).astype(bool) for _ in range(3)]
+    cs = [orc.encrypt(rng, lwe_key, m) for m in ms]
+    ds = [H.ciphertext_from_arrays(thr, c) for c in cs]
+
+    def both(fn):
+        _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, 0)
+        _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, 0)
+        single = H.ct_arrays(fn())
+        _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, -1)
+        _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, -1)
+        split = H.ct_arrays(fn())
+        for x, y in zip(single, split):
+            assert (x == y).all()
+        return split
+
+    def ends(c, size):
+        idx = numpy.r_[0:12, size - 12:size]
+        return tuple(x[idx] for x in c)
+
+    try:
+        for size in (8 * cus + 70, 10 * cus - 3):             # tails: team kernel, pair kernel
+            got = both(lambda: vm.gate_nand(ds[0][:size], ds[1][:size]))
+            exp = orc.gate('gate_nand', ck, ends(cs[0], size), ends(cs[1], size))
+            for g, e in zip(ends(got, size), exp):
+                assert (g == e).all(), size
+        for size in (4 * cus + 35, 5 * cus - 2):               # MUX: 2 x size bootstraps, the tail lies in the second job
+            got = both(lambda: vm.gate_mux(ds[0][:size], ds[1][:size], ds[2][:size]))
+            exp = orc.gate_mux(ck, ends(cs[0], size), ends(cs[1], size), ends(cs[2], size))
+            for g, e in zip(ends(got, size), exp):
+                assert (g == e).all(), size
+    finally:
+        _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, -1)
+        _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, -1)
+
+
 @pytest.mark.parametrize('script', ['gate_nand.py', 'gate_nand_low_level.py', 'serialization.py'])
 def test_examples_run(script):
     """The counterparts of the reference's examples/ run end to end on the GPU."""

@@ -1,7 +1,7 @@
 #!/bin/bash
 # sample_clocks.sh -- on the GPU box: rocm-smi sclk / power / temperature samples while bench.py runs (150 steps)
 cd "$(dirname "$0")/.."
-python bench.py --steps 150 --warmup 2 --no-extra --no-cpu-baseline > gpurun_out/clk_bench.json 2>/dev/null &
+python bench.py --steps ${STEPS:-150} --warmup 2 --no-extra --no-cpu-baseline "$@" > gpurun_out/clk_bench.json 2>/dev/null &
 BP=$!
 sleep 6
 for i in 1 2 3 4 5 6; do
