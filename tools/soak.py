@@ -1,5 +1,6 @@
 """Soak test: repeats gates many times and requires bit-identical ciphertexts every time
-(the kernels synchronise waves with fences only / work-group barriers in the team kernel; any race
+(the kernels synchronise waves with fences only / work-group barriers in the team kernel / LDS arrival
+counters in the pair kernel; any race
 would show up as a run-to-run difference) and correct decryptions."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -29,7 +30,7 @@ def main():
         sk, ck = ctx.make_key_pair(transform_type=tr)
         vm = ctx.make_virtual_machine(ck)
         print(tr)
-        for B, reps in ((4096, 60 if tr == 'NTT' else 200), (1000, 100), (200, 300), (7, 300)):
+        for B, reps in ((4096, 60 if tr == 'NTT' else 200), (2500, 60), (1000, 100), (400, 150), (200, 300), (7, 300)):
             total += soak(ctx, vm, sk, B, reps, 'nand')
         total += soak(ctx, vm, sk, 300, 100, 'mux')
     print("TOTAL differing runs:", total)
