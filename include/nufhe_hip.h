@@ -203,8 +203,8 @@ int nufhe_tlwe_encrypt_zero(nufhe_ctx *ctx, int32_t *d_result_a, const int32_t *
 /* Batch-size switches of the bootstrap.  A bootstrap of up to `bits` ciphertext bits (FFT: bits/2) runs the
  * small-batch kernel (4 wavefronts share a bit, 3 for tlwe_mask_size = 2; NTT ~2.7x, FFT ~1.4x shorter latency, one
  * bit per CU at a time), larger batches the throughput kernel (one wavefront per bit).  bits < 0 restores the
- * default (the CU count for k = 1, twice that for k = 2); 0 disables the small-batch kernel.  Results are
- * bit-identical either way.
+ * defaults (in ciphertext bits: the CU count for k = 1, twice that for k = 2, either transform); 0 disables the
+ * small-batch kernels.  Results are bit-identical either way (FFT: identical on every tested input).
  * No reference counterpart (the reference always splits a bit over 512+ threads, blind_rotate.py:89-187). */
 int nufhe_ctx_set_team_max_bits(nufhe_ctx *ctx, long bits);
 /* NTT, k = 1 only: batches above the small-batch limit and up to `bits` run the medium-batch kernel (2 wavefronts

@@ -455,3 +455,118 @@ FF_FN void brft_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSo
     }
     if (tid == 0) *out_b = lds.acc[1024];
 }
+
+// ------------------------------------------------------------------------------------------
+// Team variant for tlwe_mask_size = K > 1 with the FFT transform (small batches): K + 1 wavefronts per bit, as in
+// blind_rotate.h (brtk_*): wave m owns input polynomial m -- its two digit transforms (interleaved, fft_forward_n<2>)
+// and their products with BK_row[m][0..1][0..K] --, the (K+1) x (K+1) partial sums meet in LDS, wave mo adds the
+// K + 1 partial sums of output polynomial mo in the fixed order m = 0..K, transforms back, rounds and updates
+// ACC[mo].  2 forward + 1 inverse transform on the critical path instead of 2 (K+1) + (K+1).  The summation order
+// differs from the one-wave kernel (fp64 addition is not associative): covered by the path's stated tolerance, and
+// the rounded results are identical on every tested input.
+// ------------------------------------------------------------------------------------------
+#define BRFTK_PART_ELEMS(K) (((K) + 1) * ((K) + 1) * BKF_POLY_ELEMS)   /* complex: partial sums [wave m][mo][reg][lane] */
+
+struct BrFftTeamLdsK {
+    cplx *xbufA;         // this wave's two exchange buffers (FFT_XBUF_ELEMS complex each)
+    cplx *xbufB;
+    i32 *acc;            // [K+1][1024], shared by the team
+    uint16_t *bara;      // [BR_MAX_LWE], shared
+    cplx *part;          // [BRFTK_PART_ELEMS(K)], shared
+    const cplx *tw1;
+    const cplx *tw2;
+};
+
+template <int K, class TeamSync>
+FF_FN void brftk_step(u32 a, const cplx *row, const BrFftTeamLdsK &lds, const FftLane &L, int w, TeamSync &&team_sync)
+{
+    const int lane = L.lane;
+    cplx *const bufs[2] = {lds.xbufA, lds.xbufB};
+    {
+        u32 T[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const u32 j = (u32)(lane + 64 * r);
+            const u32 t = (j - a) & 2047u;
+            const u32 v = (u32)lds.acc[w * 1024 + (t & 1023u)];
+            T[r] = ((t & 1024u) ? 0u - v : v) - (u32)lds.acc[w * 1024 + j];     // (X^a - 1) ACC_w
+        }
+        cplx x[2][8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            x[0][r] = cplx{(double)br_digit<0>(T[r]), -(double)br_digit<0>(T[r + 8])};   // a_j - i a_{j+512}
+            x[1][r] = cplx{(double)br_digit<1>(T[r]), -(double)br_digit<1>(T[r + 8])};
+        }
+        fft_forward_n<2>(x, bufs, lds.tw1, lds.tw2, L);
+        cplx ps[K + 1][8];
+#pragma unroll
+        for (int mo = 0; mo <= K; mo++)
+#pragma unroll
+            for (int r = 0; r < 8; r++) ps[mo][r] = cplx{0.0, 0.0};
+        brfk_mac_pair<K>(ps, x, row, w, lane);
+#pragma unroll
+        for (int mo = 0; mo <= K; mo++)
+#pragma unroll
+            for (int r = 0; r < 8; r++) lds.part[((w * (K + 1) + mo) * 8 + r) * 64 + lane] = ps[mo][r];
+    }
+    team_sync();
+    cplx sum[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        cplx acc = lds.part[((0 * (K + 1) + w) * 8 + r) * 64 + lane];
+#pragma unroll
+        for (int src = 1; src <= K; src++) {
+            const cplx p = lds.part[((src * (K + 1) + w) * 8 + r) * 64 + lane];
+            acc.re += p.re;
+            acc.im += p.im;
+        }
+        sum[r] = acc;
+    }
+    fft_inverse(sum, lds.xbufA, lds.tw1, lds.tw2, L);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        lds.acc[w * 1024 + lane + 64 * r] += (i32)fft_round_to_u32(sum[r].re);
+        lds.acc[w * 1024 + lane + 64 * (r + 8)] += (i32)fft_round_to_u32(-sum[r].im);
+    }
+    team_sync();
+}
+
+// Whole bootstrap body of the (K+1)-wave FFT team for one bit; out_a has K * 1024 entries.
+template <int K, class TeamSync>
+FF_FN void brftk_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSource &s1, i32 c0, long bit,
+                           const cplx *bk, int n, i32 mu, const BrFftTeamLdsK &lds, const FftLane &L, int w,
+                           TeamSync &&team_sync)
+{
+    constexpr int THREADS = 64 * (K + 1);
+    const int tid = 64 * w + L.lane;
+    for (int i = tid; i < n; i += THREADS) {
+        u32 v = 0;
+        if (s0.p) v += (u32)s0.p * (u32)s0.a[bit * s0.a_stride + i];
+        if (s1.p) v += (u32)s1.p * (u32)s1.a[bit * s1.a_stride + i];
+        lds.bara[i] = (uint16_t)br_modswitch(v);
+    }
+    u32 vb = (u32)c0;
+    if (s0.p) vb += (u32)s0.p * (u32)s0.b[bit * s0.b_stride];
+    if (s1.p) vb += (u32)s1.p * (u32)s1.b[bit * s1.b_stride];
+    const u32 barb = br_modswitch(vb);
+    // ACC = (0, ..., 0, X^(2N - barb) * mu)  (bootstrap.py:176-182)
+    for (int j = tid; j < 1024; j += THREADS) {
+        const u32 t = ((u32)j + barb) & 2047u;
+#pragma unroll
+        for (int m = 0; m < K; m++) lds.acc[m * 1024 + j] = 0;
+        lds.acc[K * 1024 + j] = (t < 1024u) ? mu : (i32)(0u - (u32)mu);
+    }
+    team_sync();
+    for (int i = 0; i < n; i++) {
+        const u32 a = WAVE_UNIFORM((u32)lds.bara[i]);
+        if (a == 0) continue;
+        brftk_step<K>(a, bk + (long)i * BK_ROW_POLYS(K) * BKF_POLY_ELEMS, lds, L, w, team_sync);
+    }
+    // sample extraction (tlwe_cpu.py:55-58)
+    for (int j = tid; j < K * 1024; j += THREADS) {
+        const int m = j >> 10, jj = j & 1023;
+        const u32 v = (u32)lds.acc[j];
+        out_a[m * 1024 + ((1024 - jj) & 1023)] = (i32)(jj == 0 ? v : 0u - v);
+    }
+    if (tid == 0) *out_b = lds.acc[K * 1024];
+}

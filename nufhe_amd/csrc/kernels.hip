@@ -381,6 +381,31 @@ __global__ __launch_bounds__(64 * BRF2_WAVES, 1) void k_bootstrap_fft_k2(BrLaunc
     br_extract<2>(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, acc, lane);
 }
 
+// Small-batch variant of the k = 2 FFT path: 3 waves per bit (blind_rotate_fft.h, brftk_*).
+// LDS: tables | ACC 12 KiB | bara 1 KiB | partial sums 72 KiB | 3 x 2 exchange buffers
+#define TEAMF2_LDS_BYTES (FTABLE_LDS_BYTES + 3 * 1024 * 4 + WAVE_BARA_BYTES + BRFTK_PART_ELEMS(2) * 16 + 3 * 2 * WAVE_FXBUF_BYTES)
+__global__ __launch_bounds__(64 * 3, 1) void k_bootstrap_fft_team_k2(BrLaunch P)
+{
+    load_ftables((const cplx *)P.tw_a, (const cplx *)P.tw_b);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long gbit = blockIdx.x;
+    const int job = gbit >= P.bits_per_job ? 1 : 0;
+    const long bit = gbit - (job ? P.bits_per_job : 0);
+    unsigned char *base = g_smem + FTABLE_LDS_BYTES;
+    BrFftTeamLdsK lds;
+    lds.acc = (i32 *)base;
+    lds.bara = (uint16_t *)(base + 3 * 1024 * 4);
+    lds.part = (cplx *)(base + 3 * 1024 * 4 + WAVE_BARA_BYTES);
+    lds.xbufA = (cplx *)(base + 3 * 1024 * 4 + WAVE_BARA_BYTES + BRFTK_PART_ELEMS(2) * 16 + wave * 2 * WAVE_FXBUF_BYTES);
+    lds.xbufB = lds.xbufA + FFT_XBUF_ELEMS;
+    lds.tw1 = (const cplx *)g_smem;
+    lds.tw2 = (const cplx *)g_smem + FFT_TW1_ELEMS;
+    const FftLane L = fft_lane_init(lane);
+    brftk_bootstrap<2>(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, P.job[job].s0, P.job[job].s1,
+                       P.job[job].c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, WAVE_UNIFORM(wave),
+                       [] { __syncthreads(); });
+}
+
 __global__ __launch_bounds__(64 * BRF2_WAVES, 1) void k_blind_rotate_accum_fft_k2(
     i32 *__restrict__ accum, const cplx *__restrict__ bk, const i32 *__restrict__ bara, long bara_stride,
     int row0, int n_rows, int external_mul_only, long batch, const cplx *__restrict__ tw1,
@@ -998,6 +1023,8 @@ hipError_t kernels_init_device(int *num_cus)
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)brp_lds_bytes(BRP_MAX_PAIRS));
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_bootstrap_fft_team_k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAMF2_LDS_BYTES);
+    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_blind_rotate_accum<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(1));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_blind_rotate_accum<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(2));
@@ -1058,10 +1085,12 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, lon
 {
     if (P.nbits_total == 0) return hipSuccess;
     // defaults of the batch-size switches (negative = default): NTT k = 1: team kernel up to 1 x CUs, pair kernel up
-    // to 4 x CUs; NTT k = 2: team kernel up to 2 x CUs; FFT: team kernel up to 1 x CUs (an explicit value counts
-    // half for the FFT kernels, see nufhe_hip.h)
+    // to 4 x CUs; NTT k = 2: team kernel up to 2 x CUs; FFT k = 1: team kernel up to 1 x CUs, k = 2: up to 2 x CUs
+    // (an explicit value counts half for the FFT kernels, see nufhe_hip.h)
     if (pair_max_bits < 0) pair_max_bits = (long)BRP_MAX_PAIRS * num_cus;
-    if (team_max_bits < 0) team_max_bits = (transform == 0 && mask_size == 1) ? (long)num_cus : 2L * num_cus;
+    if (team_max_bits < 0)
+        team_max_bits = (transform == 0 && mask_size == 1) ? (long)num_cus
+                        : (transform == 1 && mask_size == 2) ? 4L * num_cus : 2L * num_cus;
     if (transform == 0 && mask_size == 1 && P.nbits_total <= team_max_bits) {
         // small batch: 4 waves per bit, one bit per CU at a time
         hipLaunchKernelGGL(k_bootstrap_team, dim3((unsigned)P.nbits_total), dim3(64 * BRT_WAVES), TEAM_LDS_BYTES, stream, P);
@@ -1101,6 +1130,9 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, lon
     } else if (transform == 1 && mask_size == 1) {
         const int w = br_pick_waves(P.nbits_total, BR_WAVES_PER_BLOCK, num_cus);
         hipLaunchKernelGGL(k_bootstrap_fft, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), brf_lds_bytes(w), stream, P);
+    } else if (transform == 1 && mask_size == 2 && P.nbits_total <= team_max_bits / 2) {
+        // small batch, FFT, k = 2: 3 waves per bit
+        hipLaunchKernelGGL(k_bootstrap_fft_team_k2, dim3((unsigned)P.nbits_total), dim3(64 * 3), TEAMF2_LDS_BYTES, stream, P);
     } else if (transform == 1 && mask_size == 2) {
         const int w = br_pick_waves(P.nbits_total, BRF2_WAVES, num_cus);
         hipLaunchKernelGGL(k_bootstrap_fft_k2, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w),

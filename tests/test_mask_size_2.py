@@ -287,16 +287,26 @@ def test_gpu_k2_fft_gates_vs_exact_path(k2_fft_env, thr, H, orc, golden_k2, k2_i
     msg = [rng.uniform_bool((B,)).astype(bool) for _ in range(3)]
     cs = [orc.encrypt(rng, lwe_key, m, env['oparams']) for m in msg]
     ds = [H.ciphertext_from_arrays(thr, c, params) for c in cs]
-    for name, got, exp, truth in (
-            ('nand', vm.gate_nand(ds[0], ds[1]), orc.gate('gate_nand', ck, cs[0], cs[1]), ~(msg[0] & msg[1])),
-            ('xor', vm.gate_xor(ds[0], ds[1]), orc.gate('gate_xor', ck, cs[0], cs[1]), msg[0] ^ msg[1]),
-            ('mux', vm.gate_mux(ds[0], ds[1], ds[2]), orc.gate_mux(ck, cs[0], cs[1], cs[2]),
-             numpy.where(msg[0], msg[1], msg[2]))):
-        ga, gb, gcv = H.ct_arrays(got)
-        assert dev(ga, exp[0]) <= FFT_TOLERANCE_LSB and dev(gb, exp[1]) <= FFT_TOLERANCE_LSB, name
-        assert (gcv == exp[2]).all(), name
-        assert (env['ctx'].decrypt(env['sk'], got) == truth).all(), name
-        print("k=2 FFT %s: words differing from the exact path: %d" % (name, int((ga != exp[0]).sum() + (gb != exp[1]).sum())))
+    from nufhe_amd import _lib
+    exp_all = {'nand': orc.gate('gate_nand', ck, cs[0], cs[1]), 'xor': orc.gate('gate_xor', ck, cs[0], cs[1]),
+               'mux': orc.gate_mux(ck, cs[0], cs[1], cs[2])}
+    truth_all = {'nand': ~(msg[0] & msg[1]), 'xor': msg[0] ^ msg[1], 'mux': numpy.where(msg[0], msg[1], msg[2])}
+    try:
+        # 0: one wave per bit (k_bootstrap_fft_k2); -1: default switch = 3 waves per bit for 37 / 74 bits
+        # (k_bootstrap_fft_team_k2)
+        for limit in (0, -1):
+            _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, limit)
+            for name, got in (('nand', vm.gate_nand(ds[0], ds[1])), ('xor', vm.gate_xor(ds[0], ds[1])),
+                              ('mux', vm.gate_mux(ds[0], ds[1], ds[2]))):
+                exp = exp_all[name]
+                ga, gb, gcv = H.ct_arrays(got)
+                assert dev(ga, exp[0]) <= FFT_TOLERANCE_LSB and dev(gb, exp[1]) <= FFT_TOLERANCE_LSB, (name, limit)
+                assert (gcv == exp[2]).all(), (name, limit)
+                assert (env['ctx'].decrypt(env['sk'], got) == truth_all[name]).all(), (name, limit)
+                print("k=2 FFT %s (team limit %d): words differing from the exact path: %d"
+                      % (name, limit, int((ga != exp[0]).sum() + (gb != exp[1]).sum())))
+    finally:
+        _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, -1)
 
 
 @pytest.mark.gpu
