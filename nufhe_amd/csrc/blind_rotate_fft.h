@@ -106,7 +106,7 @@ FF_FN void brf_mac_pair(cplx (&sum)[2][8], const cplx (&x)[2][8], const cplx *ro
 // T[m][r] = coefficient lane + 64 r of input polynomial m.  The two digit polynomials of each m are
 // transformed together, and so are the two output polynomials (fft_*_n<2>).
 FF_FN void brf_external_product(u32 (&res)[2][16], const u32 (&T)[2][16], const cplx *row, const BrFftLds &lds,
-                                const FftLane &L)
+                                const FftLane &L BR_PROBE_ARG)
 {
     cplx *const bufs[2] = {lds.xbufA, lds.xbufB};
     cplx sum[2][8];
@@ -121,13 +121,16 @@ FF_FN void brf_external_product(u32 (&res)[2][16], const u32 (&T)[2][16], const 
             x[1][r] = cplx{(double)br_digit<1>(T[m][r]), -(double)br_digit<1>(T[m][r + 8])};
         }
         fft_forward_n<2>(x, bufs, lds.tw1, lds.tw2, L);
+        BR_PROBE_MARK(2 * m);
         brf_mac_pair(sum, x, row, m, L.lane);
 #if defined(__HIP_DEVICE_COMPILE__)
         // keep the key loads of the next polynomial below this point (register pressure)
         asm volatile("" ::: "memory");
 #endif
+        BR_PROBE_MARK(2 * m + 1);
     }
     fft_inverse_n<2>(sum, bufs, lds.tw1, lds.tw2, L);
+    BR_PROBE_MARK(4);
 #pragma unroll
     for (int mo = 0; mo < 2; mo++)
 #pragma unroll
@@ -153,8 +156,9 @@ FF_FN void brf_init_acc(u32 (&acc)[2][16], u32 barb, i32 mu, const BrFftLds &lds
 }
 
 // One blind-rotate step: ACC += BK_row (.) ((X^a - 1) ACC)  (bootstrap.py:96-109)
-FF_FN void brf_step(u32 (&acc)[2][16], u32 a, const cplx *row, const BrFftLds &lds, const FftLane &L)
+FF_FN void brf_step(u32 (&acc)[2][16], u32 a, const cplx *row, const BrFftLds &lds, const FftLane &L BR_PROBE_ARG)
 {
+    BR_PROBE_BEGIN();
     const int lane = L.lane;
     i32 *mirror = brf_acc_mirror(lds);
     u32 T[2][16];
@@ -173,7 +177,8 @@ FF_FN void brf_step(u32 (&acc)[2][16], u32 a, const cplx *row, const BrFftLds &l
 #pragma unroll
     for (int r = 0; r < BRF_PARK; r++) *brf_park_slot(lds, r, lane) = acc[0][r];
     u32 res[2][16];
-    brf_external_product(res, T, row, lds, L);
+    BR_PROBE_MARK(5);
+    brf_external_product(res, T, row, lds, L BR_PROBE_PASS);
 #pragma unroll
     for (int r = 0; r < BRF_PARK; r++) acc[0][r] = *brf_park_slot(lds, r, lane);
 #pragma unroll
@@ -184,19 +189,35 @@ FF_FN void brf_step(u32 (&acc)[2][16], u32 a, const cplx *row, const BrFftLds &l
             mirror[mo * 1024 + lane + 64 * r] = (i32)acc[mo][r];
         }
     WAVE_SYNC();
+    BR_PROBE_MARK(6);
 }
 
 FF_FN void brf_blind_rotate(u32 (&acc)[2][16], const cplx *bk, int n, u32 barb, i32 mu, const BrFftLds &lds,
                             const FftLane &L)
 {
     brf_init_acc(acc, barb, mu, lds, L.lane);
+#if defined(BR_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+    BrProbe probe_ = {};
+    const long long probe_w0 = clock64(), probe_r0 = wall_clock64();
+#endif
     for (int i = 0; i < n; i++) {
         br_pace(lds.pace, (u32)i);
         const u32 a = WAVE_UNIFORM((u32)*brf_bara_slot(lds, i));
         if (a == 0) continue;
-        brf_step(acc, a, bk + (long)i * BKF_ROW_ELEMS, lds, L);
+        brf_step(acc, a, bk + (long)i * BKF_ROW_ELEMS, lds, L BR_PROBE_PASS);
     }
     br_pace_done(lds.pace);
+#if defined(BR_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+    if (L.lane == 0) {
+        for (int i = 0; i < 8; i++) atomicAdd(&g_br_probe[i], (unsigned long long)probe_.t[i]);
+        atomicAdd(&g_br_probe[14], (unsigned long long)(clock64() - probe_w0));
+        atomicAdd(&g_br_probe[13], 1ull);
+        atomicAdd(&g_br_probe[12], (unsigned long long)(wall_clock64() - probe_r0));
+        const unsigned gw = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 8191u;
+        g_br_probe_life[2 * gw] = (unsigned)probe_r0;
+        g_br_probe_life[2 * gw + 1] = (unsigned)wall_clock64();
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

@@ -327,9 +327,12 @@ __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_blind_rotate_accum_fft(
             mirror[m * 1024 + lane + 64 * r] = (i32)acc[m][r];
         }
     WAVE_SYNC();
+#if defined(BR_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+    BrProbe probe_ = {};
+#endif
     if (external_mul_only) {
         u32 res[2][16];
-        brf_external_product(res, acc, bk + (long)row0 * BKF_ROW_ELEMS, lds, L);
+        brf_external_product(res, acc, bk + (long)row0 * BKF_ROW_ELEMS, lds, L BR_PROBE_PASS);
 #pragma unroll
         for (int m = 0; m < 2; m++)
 #pragma unroll
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_blind_rotate_accum_fft(
         for (int i = 0; i < n_rows; i++) {
             const u32 a = WAVE_UNIFORM((u32)bara[bit * bara_stride + i]) & 2047u;
             if (a == 0) continue;
-            brf_step(acc, a, bk + (long)(row0 + i) * BKF_ROW_ELEMS, lds, L);
+            brf_step(acc, a, bk + (long)(row0 + i) * BKF_ROW_ELEMS, lds, L BR_PROBE_PASS);
         }
     }
 #pragma unroll

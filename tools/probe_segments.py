@@ -10,8 +10,9 @@ import numpy
 import nufhe_amd as nufhe
 from nufhe_amd import _lib
 
+TRANSFORM = sys.argv[1] if len(sys.argv) > 1 else 'NTT'
 ctx = nufhe.Context(rng=nufhe.DeterministicRNG(123))
-secret, cloud = ctx.make_key_pair(transform_type='NTT')
+secret, cloud = ctx.make_key_pair(transform_type=TRANSFORM)
 vm = ctx.make_virtual_machine(cloud)
 rs = numpy.random.RandomState(3)
 bits = 4096
@@ -26,8 +27,12 @@ reps = 3
 for _ in range(reps):
     vm.gate_nand(a, b)
 lib.nufhe_probe_read(buf)
+if TRANSFORM == 'FFT':
+    names_fft = ['fwd pair m=0', 'mac m=0', 'fwd pair m=1', 'mac m=1', 'inverse pair', 'rotate + park', 'round + update acc']
 names = ['digits+fwd x2 (m=0)', 'mac m=0 (canonical)', 'digits+fwd x2 (m=1)', 'mac_l4 mo=0', 'inverse mo=0 + acc',
          'mac_l4 mo=1', 'inverse mo=1 + acc', 'wave sync + loop']
+if TRANSFORM == 'FFT':
+    names = names_fft
 # block 0 hosts bits 0..7 in round one; its wave 0 runs ~500 iterations per gate (a == 0 skipped); blocks of the second
 # round have other indices, so the count is per gate
 tot = 0
