@@ -58,7 +58,7 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X vector fp64: 256 CUs x 128 flop/clk
                                     # at 4.2 cycles per wave64 instruction: profiles/r01_microbench_valu_rates.txt)
 
 
-def issue_roofline(transform, bits, rotations, n_iter, kernel_ms):
+def issue_roofline(transform, bits, rotations, n_iter, kernel_ms, live_clock_ghz=None):
     """What actually bounds the bootstrap kernel, from TRACKED files only:
     profiles/isa_mix.json (tools/isa_mix.py: instructions per blind-rotate iteration by issue class),
     profiles/valu_class_costs.json (tools/microbench_l4: measured cycles per class at this occupancy),
@@ -87,6 +87,11 @@ def issue_roofline(transform, bits, rotations, n_iter, kernel_ms):
                       "frac_wave_cycles_issuing": d.get("frac_SQ_ACTIVE_INST_ANY"),
                       "frac_wave_cycles_waiting_for_issue": d.get("frac_SQ_WAIT_INST_ANY"),
                       "frac_wave_cycles_at_waitcnt": d.get("frac_SQ_WAIT_ANY")}
+    if live_clock_ghz:
+        # measured inside the timed launches (nufhe_profile_clock: s_memtime / s_memrealtime of one wave): the
+        # ceiling of THIS run, whatever clock this box sustains
+        out["clock_ghz_in_kernel"] = live_clock_ghz
+        clock = live_clock_ghz
     simds = 1024
     if transform == "NTT" and costs is not None and clock:
         cyc = k.get("valu_full_rate", 0) * costs["full_rate_cycles"] + k.get("valu_half_rate", 0) * costs["half_rate_cycles"]
@@ -233,7 +238,7 @@ def main():
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
-    br_ms, ks_ms = [], []
+    br_ms, ks_ms, clock_ghz, wave_ms = [], [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -242,6 +247,9 @@ def main():
             a = ctypes.c_float(); b = ctypes.c_float()
             _lib.check(lib.nufhe_profile_last(thr.handle, ctypes.byref(a), ctypes.byref(b)))
             br_ms.append(a.value); ks_ms.append(b.value)
+            g = ctypes.c_double(); w = ctypes.c_double()
+            if lib.nufhe_profile_clock(thr.handle, ctypes.byref(g), ctypes.byref(w)) == 0:
+                clock_ghz.append(g.value); wave_ms.append(w.value)
     torch.cuda.synchronize()
     own_elapsed = time.perf_counter() - t0          # this rank alone (a straggler shows up here)
     if use_dist:
@@ -388,7 +396,12 @@ def main():
             "note": "BASELINE.json's HBM axis: every bit streams its 32.8 MB key once, no reuse (SURVEY §8d). The "
                     "kernel shares each key row between all resident waves through L2, so this is a model figure, "
                     "not traffic; the measured HBM bytes are in 'traffic'"}
-        roof = issue_roofline(args.transform, B, n_rot, 500, br_avg) or {}
+        live_clock = sum(clock_ghz) / len(clock_ghz) if clock_ghz else None
+        roof = issue_roofline(args.transform, B, n_rot, 500, br_avg, live_clock) or {}
+        if wave_ms:
+            # one wave's blind rotation (start to end) against the kernel: rounds x wave life time ~ kernel time when
+            # the waves of every SIMD finish together (pacing)
+            roof["wave_ms_in_kernel"] = sum(wave_ms) / len(wave_ms)
         if "bound" not in roof:        # profile files missing: fall back to the streaming model as the headline
             roof.update({k: streaming[k] for k in ("bound", "achieved", "peak", "unit", "frac")})
         roof.update({"kernel": "k_bootstrap%s (fused mod-switch + blind rotate + extract)" % (

@@ -216,6 +216,11 @@ int nufhe_ctx_set_pair_max_bits(nufhe_ctx *ctx, long bits);
  * context's stream (milliseconds; blind-rotate kernel and keyswitch kernels separately) ---- */
 int nufhe_profile_enable(nufhe_ctx *ctx, int enable);
 int nufhe_profile_last(nufhe_ctx *ctx, float *blind_rotate_ms, float *keyswitch_ms);
+/* Sustained shader clock of the last profiled bootstrap launch, measured inside the kernel: one wavefront of the
+ * wave-per-bit kernel reads the shader-clock counter and the constant 100 MHz counter around its blind rotation;
+ * *shader_ghz = their ratio, *wave_ms = how long that wavefront ran (the kernel runs ceil(bits / (8 x CUs)) such
+ * rounds).  Fails for batches that ran the small- or medium-batch kernels. */
+int nufhe_profile_clock(nufhe_ctx *ctx, double *shader_ghz, double *wave_ms);
 
 #ifdef __cplusplus
 }

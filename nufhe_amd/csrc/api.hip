@@ -50,6 +50,7 @@ struct nufhe_ctx {
     bool own_stream = false;
     u64 *d_tw1f = nullptr;
     u64 *d_tw1x = nullptr;    // forward table permuted for the limb-form transform (ntt_make_tw1x)
+    unsigned long long *d_clock = nullptr;   // BrLaunch::clock_probe target (2 words)
     u64 *d_tw1i = nullptr;
     cplx *d_ftw1 = nullptr;
     cplx *d_ftw2 = nullptr;
@@ -208,6 +209,8 @@ int nufhe_ctx_create(int device, void *stream, int own_stream, nufhe_ctx **out)
     std::vector<u64> fx(1024);
     ntt_make_tw1x(fx.data(), f.data());
     hipError_t e = hipMalloc((void **)&ctx->d_tw1f, 1024 * sizeof(u64));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_clock, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(ctx->d_clock, 0, 2 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_tw1x, 1024 * sizeof(u64));
     if (e == hipSuccess) e = hipMemcpy(ctx->d_tw1x, fx.data(), 1024 * sizeof(u64), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_tw1i, 1024 * sizeof(u64));
@@ -236,6 +239,7 @@ int nufhe_ctx_destroy(nufhe_ctx *ctx)
     hipStreamSynchronize(ctx->stream);
     if (ctx->d_tw1f) hipFree(ctx->d_tw1f);
     if (ctx->d_tw1x) hipFree(ctx->d_tw1x);
+    if (ctx->d_clock) hipFree(ctx->d_clock);
     if (ctx->d_tw1i) hipFree(ctx->d_tw1i);
     if (ctx->d_ftw1) hipFree(ctx->d_ftw1);
     if (ctx->d_ftw2) hipFree(ctx->d_ftw2);
@@ -546,6 +550,7 @@ static int run_gate(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result
     const bool fft = key->transform == NUFHE_TRANSFORM_FFT;
     P.tw_a = fft ? (const void *)ctx->d_ftw1 : (const void *)ctx->d_tw1x;
     P.tw_b = fft ? (const void *)ctx->d_ftw2 : (const void *)ctx->d_tw1i;
+    P.clock_probe = ctx->profile ? ctx->d_clock : nullptr;
     if (keyswitch) {
         const int ext = key->ext_size();
         int rc = ensure(ctx, ctx->ext_a, (size_t)total * ext * sizeof(i32));
@@ -558,7 +563,10 @@ static int run_gate(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result
         P.out_a = result.a; P.out_a_stride = result.a_stride;
         P.out_b = result.b; P.out_b_stride = result.b_stride;
     }
-    if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+    if (ctx->profile) {
+        HIP_TRY(hipMemsetAsync(ctx->d_clock, 0, 2 * sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+    }
     HIP_TRY(launch_bootstrap(P, key->transform, key->mask_size, ctx->team_max_bits, ctx->pair_max_bits, ctx->num_cus,
                              ctx->stream));
     if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
@@ -833,6 +841,20 @@ int nufhe_profile_last(nufhe_ctx *ctx, float *blind_rotate_ms, float *keyswitch_
     HIP_TRY(hipEventElapsedTime(&ks, ctx->ev[1], ctx->ev[2]));
     if (blind_rotate_ms) *blind_rotate_ms = br;
     if (keyswitch_ms) *keyswitch_ms = ks;
+    return NUFHE_OK;
+}
+
+int nufhe_profile_clock(nufhe_ctx *ctx, double *shader_ghz, double *wave_ms)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!ctx->ev_valid) return fail(NUFHE_EINVAL, "no profiled launch recorded");
+    HIP_TRY(hipEventSynchronize(ctx->ev[2]));
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(hipMemcpy(h, ctx->d_clock, sizeof(h), hipMemcpyDeviceToHost));
+    if (h[1] == 0) return fail(NUFHE_EINVAL, "the last profiled launch did not run a wave-per-bit kernel");
+    if (shader_ghz) *shader_ghz = (double)h[0] / ((double)h[1] * 10.0);     // 100 MHz ticks = 10 ns
+    if (wave_ms) *wave_ms = (double)h[1] * 1e-5;
     return NUFHE_OK;
 }
 

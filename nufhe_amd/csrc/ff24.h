@@ -110,6 +110,42 @@ FF_FN void l4_rot(L4 &r, const L4 &a)
 // r = e * 2^S, 0 < S < 24, for limbs of any size: e_i = hi_i 2^(24-S) + lo_i (floor split), so
 // e_i 2^S = hi_i 2^24 + lo_i 2^S: the high parts move one limb up (the top one wraps negated).
 // |r_i| < 2^24 + max|e| / 2^(24-S): the operation re-normalises.
+// (a << s) + c in ONE instruction on the device (v_lshl_add_u32, 4.4 cycles against 3.75 + 3.0 for the shift and
+// the add the compiler emits on its own)
+FF_FN u32 l4_lshl_add(u32 a, u32 s, u32 c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 d;
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(s), "v"(c));
+    return d;
+#else
+    return (a << s) + c;
+#endif
+}
+template <int S>
+FF_FN u32 l4_lshl_add_c(u32 a, u32 c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 d;
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(S), "v"(c));
+    return d;
+#else
+    return (a << S) + c;
+#endif
+}
+
+// (a - b) + c for a >= b in ONE instruction on the device (v_sad_u32 = |a - b| + c)
+FF_FN u32 l4_sub_add(u32 a, u32 b, u32 c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 d;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+#else
+    return (a - b) + c;
+#endif
+}
+
 template <int S>
 FF_FN void l4_shl(L4 &r, const L4 &e)
 {
@@ -119,9 +155,9 @@ FF_FN void l4_shl(L4 &r, const L4 &e)
               h3 = l4_sar(e.w[3], 24 - S);
     L4 t;
     t.w[0] = ((e.w[0] & m) << S) - h3;
-    t.w[1] = ((e.w[1] & m) << S) + h0;
-    t.w[2] = ((e.w[2] & m) << S) + h1;
-    t.w[3] = ((e.w[3] & m) << S) + h2;
+    t.w[1] = l4_lshl_add_c<S>(e.w[1] & m, h0);
+    t.w[2] = l4_lshl_add_c<S>(e.w[2] & m, h1);
+    t.w[3] = l4_lshl_add_c<S>(e.w[3] & m, h2);
     r = t;
 }
 
@@ -133,9 +169,9 @@ FF_FN void l4_shl_var(L4 &r, const L4 &e, u32 s, u32 s24, u32 m)
               h3 = (u32)((i32)e.w[3] >> s24);
     L4 t;
     t.w[0] = ((e.w[0] & m) << s) - h3;
-    t.w[1] = ((e.w[1] & m) << s) + h0;
-    t.w[2] = ((e.w[2] & m) << s) + h1;
-    t.w[3] = ((e.w[3] & m) << s) + h2;
+    t.w[1] = l4_lshl_add(e.w[1] & m, s, h0);
+    t.w[2] = l4_lshl_add(e.w[2] & m, s, h1);
+    t.w[3] = l4_lshl_add(e.w[3] & m, s, h2);
     r = t;
 }
 
@@ -230,8 +266,8 @@ FF_FN u64 l4_to_u64(const L4 &x)
 {
     const u32 u0 = x.w[0] + L4_Z0, u1 = x.w[1] + L4_Z1, u2 = x.w[2] + L4_Z2, u3 = x.w[3] + L4_Z3;
     const u32 u3h = u3 >> 16, u3l = u3 & 0xFFFFu;
-    const u32 t1 = (u1 - u3h) + (u0 >> 24);
-    const u32 t2 = (u2 + (u3h << 8)) + (t1 >> 24);
+    const u32 t1 = l4_sub_add(u1, u3h, u0 >> 24);          // u1 >= 2^30 > u3h
+    const u32 t2 = l4_lshl_add_c<8>(u3h, u2) + (t1 >> 24);
     const u32 t3 = u3l + (t2 >> 24);                       // < 2^16 + 2^8
     const u32 p0 = l4_pack<0, 3>(t1, u0);                  // digits 0, 1 (low byte)
     const u32 p1 = l4_pack<1, 2>(t2, t1);                  // digits 1 (high 2 bytes), 2 (low 2 bytes)

@@ -30,6 +30,9 @@ struct BrLaunch {
     long out_b_stride;
     const void *tw_a;     // NTT: tw1f u64[1024]; FFT: tw1 complex[512]
     const void *tw_b;     // NTT: tw1i u64[1024]; FFT: tw2 complex[64]
+    // profiling only (nufhe_profile_enable), else nullptr: wave 0 of work-group 0 of the wave-per-bit kernels stores
+    // how long it lived, {shader-clock ticks (s_memtime), constant 100 MHz ticks (s_memrealtime)}
+    unsigned long long *clock_probe;
 };
 
 struct KsLaunch {

@@ -64,6 +64,22 @@ __device__ __forceinline__ BrLds carve_br_lds(int wave)
     return lds;
 }
 
+// life time of one wave in both clocks (BrLaunch::clock_probe): the sustained shader clock of the launch is their ratio
+struct ClockProbe {
+    long long t0, r0;
+    __device__ __forceinline__ void begin(const BrLaunch &P)
+    {
+        if (P.clock_probe && blockIdx.x == 0 && threadIdx.x == 0) { t0 = clock64(); r0 = wall_clock64(); }
+    }
+    __device__ __forceinline__ void end(const BrLaunch &P) const
+    {
+        if (P.clock_probe && blockIdx.x == 0 && threadIdx.x == 0) {
+            P.clock_probe[0] = (unsigned long long)(clock64() - t0);
+            P.clock_probe[1] = (unsigned long long)(wall_clock64() - r0);
+        }
+    }
+};
+
 // ------------------------------------------------------------------------------------------
 // K1: fused bootstrap (prologue + blind rotate + extract), one wave per bit
 // ------------------------------------------------------------------------------------------
@@ -82,7 +98,10 @@ __global__ __launch_bounds__(64 * BR_WAVES_K(K), 2) void k_bootstrap(BrLaunch P)
     const u32 barb = br_prologue(P.job[job].s0, P.job[job].s1, P.job[job].c0, bit, P.n, lds, lane);
     WAVE_SYNC();
     u32 acc[K + 1][16];
+    ClockProbe probe;
+    probe.begin(P);
     br_blind_rotate<K>(acc, (const u64 *)P.bk, P.n, barb, P.mu, lds, L);
+    probe.end(P);
     br_extract<K>(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, acc, lane);
 }
 
@@ -277,7 +296,10 @@ __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_bootstrap_fft(BrLaunch 
     const u32 barb = brf_prologue(P.job[job].s0, P.job[job].s1, P.job[job].c0, bit, P.n, lds, lane);
     WAVE_SYNC();
     u32 acc[2][16];
+    ClockProbe probe;
+    probe.begin(P);
     brf_blind_rotate(acc, (const cplx *)P.bk, P.n, barb, P.mu, lds, L);
+    probe.end(P);
     br_extract<1>(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, acc, lane);
 }
 

@@ -161,7 +161,9 @@ def test_tracked_profile_inputs_of_the_bench_roofline_are_current():
     for kernel in ('k_bootstrap<1>', 'k_bootstrap_fft'):
         k = mix[kernel]
         assert k['valu'] > 1000 and k['vgprs'] <= 256
-    assert mix['k_bootstrap<1>']['scratch_bytes'] == 0
+    # the loop of the NTT kernel is allowed a handful of spilled dwords (5 stores + 5 loads per iteration measured
+    # faster than the spill-free code generation), not the hundreds of bytes of a lost allocation
+    assert mix['k_bootstrap<1>']['scratch_bytes'] <= 64 and mix['k_bootstrap<1>'].get('scratch', 0) <= 16
     costs = json.load(open(os.path.join(ROOT, 'profiles', 'valu_class_costs.json')))
     assert 2.0 <= costs['full_rate_cycles'] < costs['half_rate_cycles'] <= 6.0
     for name in ('pmc_NTT.json', 'pmc_FFT.json', 'pmc_traffic.json'):

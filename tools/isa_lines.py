@@ -54,9 +54,9 @@ def main():
     lines = open(asm).read().split('\n')
     files = {}
     for l in lines:
-        mm = re.match(r'\s+\.file\s+(\d+)\s+"([^"]*)"\s+"([^"]*)"', l)
+        mm = re.match(r'\s+\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', l)
         if mm:
-            d, f = mm.group(2), mm.group(3)
+            d, f = (mm.group(2), mm.group(3)) if mm.group(3) is not None else ('.', mm.group(2))
             files[int(mm.group(1))] = os.path.normpath(os.path.join(CSRC if d == '.' else d, f))
     fmaps = {}
     start = next(i for i, l in enumerate(lines) if l.startswith(sym + ':'))
@@ -76,6 +76,8 @@ def main():
         if not mm:
             continue
         op = isa_mix.strip(mm.group(1))
+        if mm.group(1).endswith(('_sdwa', '_dpp')):
+            op += '_sdwa'
         path, no = where
         if path not in fmaps:
             fmaps[path] = function_map(path) if os.path.exists(path) else {}

@@ -66,7 +66,10 @@ def count(body):
         mm = re.match(r'^\s+([a-z_0-9]+)', l)
         if not mm:
             continue
-        op = strip(mm.group(1))
+        raw = mm.group(1)
+        op = strip(raw)
+        if raw.endswith(('_sdwa', '_dpp')):
+            op += '_sdwa'          # sub-dword / cross-lane operand forms issue at the VOP3 rate (microbench: 4.4 cycles)
         if op == 's_nop':
             c['s_nop'] += 1
             c['nop_wait_states'] += int(l.split()[1]) + 1
