@@ -20,7 +20,7 @@
 #define WAVE_ACC_BYTES WAVE_ACC_BYTES_K(1)
 #define WAVE_BARA_BYTES (BR_MAX_LWE * 2)
 #define WAVE_BR_LDS_BYTES_K(K) (WAVE_XBUF_BYTES + WAVE_ACC_BYTES_K(K) + WAVE_BARA_BYTES)
-#define BR_PACE_BYTES 64                  /* one progress word per wave of the one-bit kernels (BrPace) */
+#define BR_PACE_BYTES 128                 /* pacing words of the one-bit kernels, see carve_pace */
 // waves (= bits) per work-group, one work-group per CU: mask size 1 runs 2 waves/SIMD (<= 256 VGPRs,
 // ~19 KiB of LDS each); mask size 2 has a 12 KiB accumulator mirror per wave, 6 waves fill the LDS
 #define BR_WAVES_K(K) ((K) == 1 ? 8 : 6)
@@ -38,15 +38,32 @@ __device__ __forceinline__ void load_tables(const u64 *__restrict__ g_tw1f, cons
     __syncthreads();
 }
 
-// progress words of wave `wave` and of the wave it shares its SIMD with (wave ^ 4), behind the tables at `base`
-__device__ __forceinline__ BrPace carve_pace(unsigned char *base, int wave)
+// Pacing words behind the tables at `base` (zeroed by load_tables / load_ftables): [0..7] progress counter of wave w,
+// [8..15] arrival counters of the pair kernel, [16..19] number of registered waves per SIMD, [20..27] their indices.
+// Every wave of the work-group must call this (it contains a work-group barrier); waves that will run a bit
+// (`active`) register under the SIMD they were placed on (HW_REG_HW_ID bits 5:4 -- observed: SIMDs are dealt in the
+// cyclic order 0, 2, 1, 3 from a varying start, so waves w and w + 4 meet, but nothing guarantees it), and a wave
+// that finds exactly one other active wave on its SIMD paces itself against it (BrPace, blind_rotate.h).
+__device__ __forceinline__ BrPace carve_pace(unsigned char *base, int wave, bool active)
 {
-    // (wave-uniform by construction; readfirstlane tells the compiler, so the two addresses live in SGPRs)
+    u32 *words = (u32 *)base;
     wave = __builtin_amdgcn_readfirstlane(wave);
-    const int waves = blockDim.x >> 6, other = wave ^ 4;
+    const int simd = (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));    // HW_ID.SIMD_ID
+    u32 slot = 0;
+    if (active && (threadIdx.x & 63) == 0) {
+        slot = atomicAdd(&words[16 + simd], 1u);
+        if (slot < 2) words[20 + 2 * simd + slot] = (u32)wave;
+    }
+    slot = (u32)__builtin_amdgcn_readfirstlane((int)slot);
+    __syncthreads();
     BrPace p;
-    p.mine = other < waves ? (u32 *)base + wave : nullptr;
-    p.other = (const u32 *)base + other;
+    p.mine = nullptr;
+    p.other = nullptr;
+    if (active && words[16 + simd] == 2u) {
+        const int other = __builtin_amdgcn_readfirstlane((int)words[20 + 2 * simd + (slot ^ 1u)]);
+        p.mine = words + wave;
+        p.other = words + other;
+    }
     return p;
 }
 
@@ -55,7 +72,8 @@ __device__ __forceinline__ BrLds carve_br_lds(int wave)
 {
     unsigned char *base = g_smem + TABLE_LDS_BYTES + BR_PACE_BYTES + wave * WAVE_BR_LDS_BYTES_K(K);
     BrLds lds;
-    lds.pace = carve_pace(g_smem + TABLE_LDS_BYTES, wave);
+    lds.pace.mine = nullptr;
+    lds.pace.other = nullptr;
     lds.xbuf = (u64 *)base;
     lds.acc = (i32 *)(base + WAVE_XBUF_BYTES);
     lds.bara = (uint16_t *)(base + WAVE_XBUF_BYTES + WAVE_ACC_BYTES_K(K));
@@ -89,11 +107,13 @@ __global__ __launch_bounds__(64 * BR_WAVES_K(K), 2) void k_bootstrap(BrLaunch P)
     load_tables((const u64 *)P.tw_a, (const u64 *)P.tw_b);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long gbit = (long)blockIdx.x * (blockDim.x >> 6) + wave;   // waves per group chosen at launch
+    const BrPace pace = carve_pace(g_smem + TABLE_LDS_BYTES, wave, gbit < P.nbits_total);
     if (gbit >= P.nbits_total) return;
     const int job = gbit >= P.bits_per_job ? 1 : 0;
     const long bit = gbit - (job ? P.bits_per_job : 0);
 
-    const BrLds lds = carve_br_lds<K>(wave);
+    BrLds lds = carve_br_lds<K>(wave);
+    lds.pace = pace;
     const NttLane L = ntt_lane_init(lane);
     const u32 barb = br_prologue(P.job[job].s0, P.job[job].s1, P.job[job].c0, bit, P.n, lds, lane);
     WAVE_SYNC();
@@ -165,6 +185,7 @@ __global__ __launch_bounds__(128 * BRP_MAX_PAIRS, 2) void k_bootstrap_pair(BrLau
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int pair = wave >> 1;
     const long gbit = (long)blockIdx.x * (blockDim.x >> 7) + pair;   // pairs per group chosen at launch
+    const BrPace pace = carve_pace(g_smem + TABLE_LDS_BYTES, wave, gbit < P.nbits_total);
     if (gbit >= P.nbits_total) return;                                // (both waves of the pair)
     const int job = gbit >= P.bits_per_job ? 1 : 0;
     const long bit = gbit - (job ? P.bits_per_job : 0);
@@ -176,7 +197,7 @@ __global__ __launch_bounds__(128 * BRP_MAX_PAIRS, 2) void k_bootstrap_pair(BrLau
     lds.xbuf_other = (const u64 *)(base + 2 * 1024 * 4 + WAVE_BARA_BYTES + ((wave & 1) ^ 1) * WAVE_XBUF_BYTES);
     lds.tw1x = (const u64 *)g_smem;
     lds.tw1i = (const u64 *)g_smem + 1024;
-    lds.pace = carve_pace(g_smem + TABLE_LDS_BYTES, wave);
+    lds.pace = pace;
     // pair barrier: arrival counters of the two waves behind the 8 progress words (zeroed by load_tables).  The
     // release store orders this wave's earlier LDS traffic before its counter, the acquire load the partner's
     // counter before this wave's later reads.
@@ -273,7 +294,8 @@ __device__ __forceinline__ BrFftLds carve_brf_lds(int wave)
 {
     unsigned char *base = g_smem + FTABLE_LDS_BYTES + BR_PACE_BYTES + wave * WAVE_BRF_LDS_BYTES;
     BrFftLds lds;
-    lds.pace = carve_pace(g_smem + FTABLE_LDS_BYTES, wave);
+    lds.pace.mine = nullptr;
+    lds.pace.other = nullptr;
     lds.xbufA = (cplx *)base;
     lds.xbufB = (cplx *)(base + WAVE_FXBUF_BYTES);
     lds.park = (u32 *)(base + 2 * WAVE_FXBUF_BYTES);
@@ -287,11 +309,13 @@ __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_bootstrap_fft(BrLaunch 
     load_ftables((const cplx *)P.tw_a, (const cplx *)P.tw_b);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long gbit = (long)blockIdx.x * (blockDim.x >> 6) + wave;   // waves per group chosen at launch
+    const BrPace pace = carve_pace(g_smem + FTABLE_LDS_BYTES, wave, gbit < P.nbits_total);
     if (gbit >= P.nbits_total) return;
     const int job = gbit >= P.bits_per_job ? 1 : 0;
     const long bit = gbit - (job ? P.bits_per_job : 0);
 
-    const BrFftLds lds = carve_brf_lds(wave);
+    BrFftLds lds = carve_brf_lds(wave);
+    lds.pace = pace;
     const FftLane L = fft_lane_init(lane);
     const u32 barb = brf_prologue(P.job[job].s0, P.job[job].s1, P.job[job].c0, bit, P.n, lds, lane);
     WAVE_SYNC();
