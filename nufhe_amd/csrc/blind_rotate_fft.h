@@ -105,8 +105,9 @@ FF_FN void brf_mac_pair(cplx (&sum)[2][8], const cplx (&x)[2][8], const cplx *ro
 // res[mo][r] = coefficient lane + 64 r of  sum_{m,d} digit_d(T_m) (*) BK_row[m][d][mo];
 // T[m][r] = coefficient lane + 64 r of input polynomial m.  The two digit polynomials of each m are
 // transformed together, and so are the two output polynomials (fft_*_n<2>).
+template <class TW2>
 FF_FN void brf_external_product(u32 (&res)[2][16], const u32 (&T)[2][16], const cplx *row, const BrFftLds &lds,
-                                const FftLane &L BR_PROBE_ARG)
+                                const TW2 &tw2, const FftLane &L BR_PROBE_ARG)
 {
     cplx *const bufs[2] = {lds.xbufA, lds.xbufB};
     cplx sum[2][8];
@@ -120,7 +121,7 @@ FF_FN void brf_external_product(u32 (&res)[2][16], const u32 (&T)[2][16], const 
             x[0][r] = cplx{(double)br_digit<0>(T[m][r]), -(double)br_digit<0>(T[m][r + 8])};   // a_j - i a_{j+512}
             x[1][r] = cplx{(double)br_digit<1>(T[m][r]), -(double)br_digit<1>(T[m][r + 8])};
         }
-        fft_forward_n<2>(x, bufs, lds.tw1, lds.tw2, L);
+        fft_forward_n<2>(x, bufs, lds.tw1, tw2, L);
         BR_PROBE_MARK(2 * m);
         brf_mac_pair(sum, x, row, m, L.lane);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -129,7 +130,7 @@ FF_FN void brf_external_product(u32 (&res)[2][16], const u32 (&T)[2][16], const 
 #endif
         BR_PROBE_MARK(2 * m + 1);
     }
-    fft_inverse_n<2>(sum, bufs, lds.tw1, lds.tw2, L);
+    fft_inverse_n<2>(sum, bufs, lds.tw1, tw2, L);
     BR_PROBE_MARK(4);
 #pragma unroll
     for (int mo = 0; mo < 2; mo++)
@@ -156,7 +157,8 @@ FF_FN void brf_init_acc(u32 (&acc)[2][16], u32 barb, i32 mu, const BrFftLds &lds
 }
 
 // One blind-rotate step: ACC += BK_row (.) ((X^a - 1) ACC)  (bootstrap.py:96-109)
-FF_FN void brf_step(u32 (&acc)[2][16], u32 a, const cplx *row, const BrFftLds &lds, const FftLane &L BR_PROBE_ARG)
+template <class TW2>
+FF_FN void brf_step(u32 (&acc)[2][16], u32 a, const cplx *row, const BrFftLds &lds, const TW2 &tw2, const FftLane &L BR_PROBE_ARG)
 {
     BR_PROBE_BEGIN();
     const int lane = L.lane;
@@ -178,7 +180,7 @@ FF_FN void brf_step(u32 (&acc)[2][16], u32 a, const cplx *row, const BrFftLds &l
     for (int r = 0; r < BRF_PARK; r++) *brf_park_slot(lds, r, lane) = acc[0][r];
     u32 res[2][16];
     BR_PROBE_MARK(5);
-    brf_external_product(res, T, row, lds, L BR_PROBE_PASS);
+    brf_external_product(res, T, row, lds, tw2, L BR_PROBE_PASS);
 #pragma unroll
     for (int r = 0; r < BRF_PARK; r++) acc[0][r] = *brf_park_slot(lds, r, lane);
 #pragma unroll
@@ -196,6 +198,8 @@ FF_FN void brf_blind_rotate(u32 (&acc)[2][16], const cplx *bk, int n, u32 barb, 
                             const FftLane &L)
 {
     brf_init_acc(acc, barb, mu, lds, L.lane);
+    FftTw2Regs tw2;           // 28 registers the kernel has to spare; saves the 35 LDS reads per iteration (K1 -2 %)
+    fft_tw2_load(tw2, lds.tw2, L);
 #if defined(BR_PROBE) && defined(__HIP_DEVICE_COMPILE__)
     BrProbe probe_ = {};
     const long long probe_w0 = clock64(), probe_r0 = wall_clock64();
@@ -204,7 +208,7 @@ FF_FN void brf_blind_rotate(u32 (&acc)[2][16], const cplx *bk, int n, u32 barb, 
         br_pace(lds.pace, (u32)i);
         const u32 a = WAVE_UNIFORM((u32)*brf_bara_slot(lds, i));
         if (a == 0) continue;
-        brf_step(acc, a, bk + (long)i * BKF_ROW_ELEMS, lds, L BR_PROBE_PASS);
+        brf_step(acc, a, bk + (long)i * BKF_ROW_ELEMS, lds, tw2, L BR_PROBE_PASS);
     }
     br_pace_done(lds.pace);
 #if defined(BR_PROBE) && defined(__HIP_DEVICE_COMPILE__)

@@ -118,8 +118,21 @@ FF_FN void dft8(cplx (&x)[8])
 //   in : x[i][j2] = (a_j, -a_{j+512}) for j = lane + 64 j2   (i.e. a_j - i a_{j+512})
 //   out: x[i][d]  = X_k, k = fft_freq_index(lane, d)
 // xbuf[i]: private exchange buffer of transform i (FFT_XBUF_ELEMS complex each)
-template <int NX>
-FF_FN void fft_forward_n(cplx (&x)[NX][8], cplx *const (&xbuf)[NX], const cplx *tw1, const cplx *tw2,
+// twiddle 2 of this lane: from the 64-entry table, or from 8 registers loaded once (the 7 values a lane needs never
+// change: V^(a c) for its a = lane & 7)
+struct FftTw2Regs {
+    cplx v[8];
+};
+FF_FN cplx fft_tw2(const cplx *tw2, int c, const FftLane &L) { return tw2[c * 8 + L.a]; }
+FF_FN cplx fft_tw2(const FftTw2Regs &t, int c, const FftLane &) { return t.v[c]; }
+FF_FN void fft_tw2_load(FftTw2Regs &t, const cplx *tw2, const FftLane &L)
+{
+#pragma unroll
+    for (int c = 0; c < 8; c++) t.v[c] = tw2[c * 8 + L.a];
+}
+
+template <int NX, class TW2>
+FF_FN void fft_forward_n(cplx (&x)[NX][8], cplx *const (&xbuf)[NX], const cplx *tw1, const TW2 &tw2,
                          const FftLane &L)
 {
 #pragma unroll
@@ -145,7 +158,7 @@ FF_FN void fft_forward_n(cplx (&x)[NX][8], cplx *const (&xbuf)[NX], const cplx *
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const int c = br3(i);
-            const cplx v = c == 0 ? x[t][i] : c_mul(x[t][i], tw2[c * 8 + L.a]);
+            const cplx v = c == 0 ? x[t][i] : c_mul(x[t][i], fft_tw2(tw2, c, L));
             xbuf[t][L.x2a + 8 * c + ((L.a + c) & 7)] = v;
         }
     }
@@ -170,8 +183,8 @@ FF_FN void fft_forward_n(cplx (&x)[NX][8], cplx *const (&xbuf)[NX], const cplx *
 // Inverse transform of NX polynomials at once (includes 1/512 and the conj(w^j) untwist).
 //   in : x[i][d]  = X_k, k = fft_freq_index(lane, d)
 //   out: x[i][j2] = y_j for j = lane + 64 j2:  a_j = Re y_j,  a_{j+512} = -Im y_j  (before rounding)
-template <int NX>
-FF_FN void fft_inverse_n(cplx (&x)[NX][8], cplx *const (&xbuf)[NX], const cplx *tw1, const cplx *tw2,
+template <int NX, class TW2>
+FF_FN void fft_inverse_n(cplx (&x)[NX][8], cplx *const (&xbuf)[NX], const cplx *tw1, const TW2 &tw2,
                          const FftLane &L)
 {
 #pragma unroll
@@ -189,7 +202,7 @@ FF_FN void fft_inverse_n(cplx (&x)[NX][8], cplx *const (&xbuf)[NX], const cplx *
 #pragma unroll
         for (int c = 0; c < 8; c++) {                       // lane = (k2, a): read c, * conj(V^(a c))
             const cplx v = xbuf[t][L.x2a + 8 * c + ((L.a + c) & 7)];
-            x[t][c] = c == 0 ? v : c_mul_conj(v, tw2[c * 8 + L.a]);
+            x[t][c] = c == 0 ? v : c_mul_conj(v, fft_tw2(tw2, c, L));
         }
     WAVE_SYNC();
 #pragma unroll

@@ -378,7 +378,7 @@ __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_blind_rotate_accum_fft(
 #endif
     if (external_mul_only) {
         u32 res[2][16];
-        brf_external_product(res, acc, bk + (long)row0 * BKF_ROW_ELEMS, lds, L BR_PROBE_PASS);
+        brf_external_product(res, acc, bk + (long)row0 * BKF_ROW_ELEMS, lds, lds.tw2, L BR_PROBE_PASS);
 #pragma unroll
         for (int m = 0; m < 2; m++)
 #pragma unroll
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_blind_rotate_accum_fft(
         for (int i = 0; i < n_rows; i++) {
             const u32 a = WAVE_UNIFORM((u32)bara[bit * bara_stride + i]) & 2047u;
             if (a == 0) continue;
-            brf_step(acc, a, bk + (long)(row0 + i) * BKF_ROW_ELEMS, lds, L BR_PROBE_PASS);
+            brf_step(acc, a, bk + (long)(row0 + i) * BKF_ROW_ELEMS, lds, lds.tw2, L BR_PROBE_PASS);
         }
     }
 #pragma unroll
