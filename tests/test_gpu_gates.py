@@ -273,6 +273,33 @@ def test_medium_batch_pair_kernel_every_group_size(env, orc):
         _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, -1)
 
 
+def test_profile_clock_of_the_wave_kernel(env, orc):
+    """nufhe_profile_clock: the shader clock measured inside a profiled wave-per-bit launch is a plausible MI355X
+    clock and the wave's life time is shorter than the launch; small batches (team kernel) report no measurement."""
+    import ctypes
+    import torch
+    from nufhe_amd import _lib
+    H = env['H']; thr = env['thr']; vm = env['vm']; lwe_key = env['lwe_key']
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    rng = orc.DeterministicRNG(5)
+    B = 8 * cus
+    m = [rng.uniform_bool((B,)).astype(bool) for _ in range(2)]
+    ds = [H.ciphertext_from_arrays(thr, orc.encrypt(rng, lwe_key, x)) for x in m]
+    lib = _lib.lib()
+    lib.nufhe_profile_enable(thr.handle, 1)
+    try:
+        vm.gate_nand(ds[0], ds[1])
+        br = ctypes.c_float(); ks = ctypes.c_float(); ghz = ctypes.c_double(); wave = ctypes.c_double()
+        _lib.check(lib.nufhe_profile_last(thr.handle, ctypes.byref(br), ctypes.byref(ks)))
+        _lib.check(lib.nufhe_profile_clock(thr.handle, ctypes.byref(ghz), ctypes.byref(wave)))
+        assert 1.0 < ghz.value < 3.0
+        assert 0.5 * br.value < wave.value <= br.value
+        vm.gate_nand(ds[0][:16], ds[1][:16])
+        assert lib.nufhe_profile_clock(thr.handle, ctypes.byref(ghz), ctypes.byref(wave)) != 0
+    finally:
+        lib.nufhe_profile_enable(thr.handle, 0)
+
+
 def test_large_batch_tail_goes_to_the_small_batch_kernels(env, orc):
     """A batch of whole rounds + a short last round is split into two launches (wave kernel for the rounds, team /
     pair kernel for the tail, for MUX across the boundary of its two blind rotations): bit-identical to the single
