@@ -102,7 +102,7 @@ struct ClockProbe {
 // K1: fused bootstrap (prologue + blind rotate + extract), one wave per bit
 // ------------------------------------------------------------------------------------------
 template <int K>
-__global__ __launch_bounds__(64 * BR_WAVES_K(K), 2) void k_bootstrap(BrLaunch P)
+__device__ __forceinline__ void bootstrap_wave_body(const BrLaunch &P)
 {
     load_tables((const u64 *)P.tw_a, (const u64 *)P.tw_b);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -123,6 +123,22 @@ __global__ __launch_bounds__(64 * BR_WAVES_K(K), 2) void k_bootstrap(BrLaunch P)
     br_blind_rotate<K>(acc, (const u64 *)P.bk, P.n, barb, P.mu, lds, L);
     probe.end(P);
     br_extract<K>(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, acc, lane);
+}
+
+template <int K>
+__global__ __launch_bounds__(64 * BR_WAVES_K(K), 2) void k_bootstrap(BrLaunch P)
+{
+    bootstrap_wave_body<K>(P);
+}
+
+// k = 2 with ONE wave per SIMD (4 per CU, up to 512 registers): the 3 x 16 field-element sums, two transforms' worth
+// of limbs and the pipelined key loads fit without the 360 bytes of scratch the 2-waves-per-SIMD build spills, and a
+// round of 4 x CUs bits takes 27 ms against 42 ms for 6 x CUs; launch_bootstrap picks whichever needs less time for
+// the batch.
+#define BR_K2_ROOMY_WAVES 4
+__global__ __launch_bounds__(64 * BR_K2_ROOMY_WAVES, 1) void k_bootstrap_k2_roomy(BrLaunch P)
+{
+    bootstrap_wave_body<2>(P);
 }
 
 // Small-batch variant: a team of 4 waves (one work-group) per bit, see blind_rotate.h (brt_*).
@@ -1062,6 +1078,8 @@ hipError_t kernels_init_device(int *num_cus)
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(2));
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_bootstrap_k2_roomy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(2, BR_K2_ROOMY_WAVES));
+    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_keyswitch_a, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KS_LDS_BYTES);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap_fft_team, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAMF_LDS_BYTES);
@@ -1170,8 +1188,16 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, lon
         // small batch, k = 2: 3 waves per bit (one team per CU at a time)
         hipLaunchKernelGGL(k_bootstrap_team_k2, dim3((unsigned)P.nbits_total), dim3(64 * 3), TEAM2_LDS_BYTES, stream, P);
     } else if (transform == 0 && mask_size == 2) {
-        const int w = br_pick_waves(P.nbits_total, BR_WAVES_K(2), num_cus);
-        hipLaunchKernelGGL(k_bootstrap<2>, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), br_lds_bytes(2, w), stream, P);
+        // rounds of 6 x CUs bits at 2 waves per SIMD (42 ms, spills) or rounds of 4 x CUs bits at 1 wave per SIMD
+        // (27 ms, no spills): measured ratio 1.56
+        const long r6 = (P.nbits_total + 6L * num_cus - 1) / (6L * num_cus), r4 = (P.nbits_total + 4L * num_cus - 1) / (4L * num_cus);
+        if (100 * r4 < 156 * r6) {
+            const int w = br_pick_waves(P.nbits_total, BR_K2_ROOMY_WAVES, num_cus);
+            hipLaunchKernelGGL(k_bootstrap_k2_roomy, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), br_lds_bytes(2, w), stream, P);
+        } else {
+            const int w = br_pick_waves(P.nbits_total, BR_WAVES_K(2), num_cus);
+            hipLaunchKernelGGL(k_bootstrap<2>, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), br_lds_bytes(2, w), stream, P);
+        }
     } else if (transform == 1 && mask_size == 1 && P.nbits_total <= team_max_bits / 2) {
         // small batch, FFT: 4 waves per bit (one bit per CU; the wave-per-bit kernel is ahead again
         // once the batch needs a second round of teams)

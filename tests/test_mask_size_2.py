@@ -165,6 +165,32 @@ def test_gpu_k2_gates_vs_oracle_ragged(k2_env, thr, H, orc):
 
 
 @pytest.mark.gpu
+def test_gpu_k2_both_wave_kernels(k2_env, thr, H, orc):
+    """k = 2, NTT, batches beyond the team kernel: between 4 x and 6 x CUs bits the launch takes the 6-waves-per-CU
+    build (k_bootstrap<2>), otherwise the one-wave-per-SIMD build (k_bootstrap_k2_roomy).  A 5 x CUs batch (first
+    kernel) must equal the same ciphertexts processed as two halves (second kernel) on every word, and the oracle
+    on its first and last 8 bits."""
+    import torch
+    vm = k2_env['vm']; ck = k2_env['ck']; lwe_key = k2_env['lwe_key']; params = k2_env['params']
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    rng = orc.DeterministicRNG(31)
+    B = 5 * cus - 3
+    ms = [rng.uniform_bool((B,)).astype(bool) for _ in range(2)]
+    cs = [orc.encrypt(rng, lwe_key, m, k2_env['oparams']) for m in ms]
+    ds = [H.ciphertext_from_arrays(thr, c, params) for c in cs]
+    whole = H.ct_arrays(vm.gate_nand(ds[0], ds[1]))
+    h = 3 * cus        # 3 x CUs and 2 x CUs - 3 bits: above the team limit (2 x CUs), one round of the roomy kernel
+    first = H.ct_arrays(vm.gate_nand(ds[0][:h], ds[1][:h]))
+    second = H.ct_arrays(vm.gate_nand(ds[0][h:], ds[1][h:]))
+    for w, a, b in zip(whole, first, second):
+        assert (w[:h] == a).all() and (w[h:] == b).all()
+    idx = numpy.r_[0:8, B - 8:B]
+    exp = orc.gate('gate_nand', ck, tuple(x[idx] for x in cs[0]), tuple(x[idx] for x in cs[1]))
+    for w, e in zip(whole, exp):
+        assert (w[idx] == e).all()
+
+
+@pytest.mark.gpu
 def test_gpu_k2_context_end_to_end(thr):
     """Public API with tlwe_mask_size=2 (test/test_gates.py:96-100): GPU key generation, all binary
     gates + MUX on 64 bits, serialization round trip of the k = 2 cloud key."""
