@@ -42,3 +42,19 @@ def test_uint_min_gate_chain():
     uint_min(ctx.thread, ck, answer, ca, cb)
     got = bitarray_to_uintarray(ctx.decrypt(sk, answer))
     assert (got == numpy.minimum(x, y)).all()
+
+    # the reference's schedule (operators_integer.py:66-95: XNOR and MUX alternate on one-bit slices) gives the same
+    # ciphertext, word for word, as the hoisted XNOR of nufhe_amd.operators_integer.uint_min
+    from nufhe_amd.gates import gate_constant, gate_xnor, gate_mux
+    thr = ctx.thread
+    carry = nufhe_amd.empty_ciphertext(thr, ck.params, (4, 1))
+    same = nufhe_amd.empty_ciphertext(thr, ck.params, (4, 1))
+    ref = nufhe_amd.empty_ciphertext(thr, ck.params, (4, 16))
+    gate_constant(thr, ck, carry, False)
+    for i in reversed(range(16)):
+        gate_xnor(thr, ck, same, ca[..., i:i + 1], cb[..., i:i + 1])
+        gate_mux(thr, ck, carry, same, carry, ca[..., i:i + 1])
+    gate_mux(thr, ck, ref, carry, cb, ca)
+    import torch
+    assert torch.equal(ref.a, answer.a) and torch.equal(ref.b, answer.b)
+    assert torch.equal(ref.current_variances, answer.current_variances)
