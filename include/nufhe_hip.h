@@ -207,9 +207,11 @@ int nufhe_tlwe_encrypt_zero(nufhe_ctx *ctx, int32_t *d_result_a, const int32_t *
  * small-batch kernels.  Results are bit-identical either way (FFT: identical on every tested input).
  * No reference counterpart (the reference always splits a bit over 512+ threads, blind_rotate.py:89-187). */
 int nufhe_ctx_set_team_max_bits(nufhe_ctx *ctx, long bits);
-/* NTT, k = 1 only: batches above the small-batch limit and up to `bits` run the medium-batch kernel (2 wavefronts
+/* k = 1 only.  NTT: batches above the small-batch limit and up to `bits` run the medium-batch kernel (2 wavefronts
  * per bit, up to 4 bits per CU at a time; ~1.5x shorter latency than one wavefront per bit while the batch cannot
- * give every SIMD two bits).  bits < 0 restores the default (4 x the CU count); 0 disables it. */
+ * give every SIMD two bits).  bits < 0 restores the default (4 x the CU count); 0 disables it.
+ * FFT: any non-zero value enables the 2-wavefront kernel for batches up to 3 x the CU count (it is ahead of the
+ * 4-wavefront kernel at every size, which then only runs when this switch is 0). */
 int nufhe_ctx_set_pair_max_bits(nufhe_ctx *ctx, long bits);
 
 /* ---- measurement: time of the last fused gate / bootstrap kernels, from HIP events on the

@@ -595,3 +595,117 @@ FF_FN void brftk_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrS
     }
     if (tid == 0) *out_b = lds.acc[K * 1024];
 }
+
+// ------------------------------------------------------------------------------------------
+// Pair variant of the FFT path (k = 1, medium batches: CUs < bits <= 3 x CUs), the counterpart of blind_rotate.h
+// (brp_*): two wavefronts per bit.  Wave W decomposes both digits of polynomial W, transforms them together
+// (fft_forward_n<2>) and multiplies them with its half of the row: partial sums of both output polynomials.  The partial
+// sum of the OTHER wave's output crosses through this wave's first exchange buffer (idle between the products and the
+// inverse transform), pair barrier, add, pair barrier, then wave W transforms output W back, rounds and updates ACC[W],
+// which only it reads and writes during the loop.  The two partial sums are added as (m = 0) + (m = 1) whichever wave
+// does it (fp64 addition commutes), a different association from the one-wave kernel's running sum: covered by the
+// path's stated tolerance, identical after rounding on every tested input.
+// ------------------------------------------------------------------------------------------
+struct BrFftPairLds {
+    cplx *xbufA;             // this wave's two exchange buffers (FFT_XBUF_ELEMS complex each)
+    cplx *xbufB;
+    const cplx *xbufA_other; // the other wave's first buffer
+    i32 *acc;                // [2][1024], shared by the pair
+    uint16_t *bara;          // [BR_MAX_LWE], shared
+    const cplx *tw1;
+    const cplx *tw2;
+    BrPace pace;
+};
+
+template <int W, class TW2, class PairSync>
+FF_FN void brfp_step(u32 a, const cplx *row, const BrFftPairLds &lds, const TW2 &tw2, const FftLane &L, PairSync &&pair_sync)
+{
+    const int lane = L.lane;
+    cplx *const bufs[2] = {lds.xbufA, lds.xbufB};
+    cplx sum[8];
+    {
+        u32 T[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const u32 j = (u32)(lane + 64 * r);
+            const u32 t = (j - a) & 2047u;
+            const u32 v = (u32)lds.acc[W * 1024 + (t & 1023u)];
+            T[r] = ((t & 1024u) ? 0u - v : v) - (u32)lds.acc[W * 1024 + j];     // (X^a - 1) ACC_W
+        }
+        cplx x[2][8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            x[0][r] = cplx{(double)br_digit<0>(T[r]), -(double)br_digit<0>(T[r + 8])};   // a_j - i a_{j+512}
+            x[1][r] = cplx{(double)br_digit<1>(T[r]), -(double)br_digit<1>(T[r + 8])};
+        }
+        fft_forward_n<2>(x, bufs, lds.tw1, tw2, L);
+        cplx ps[2][8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) { ps[0][r] = cplx{0.0, 0.0}; ps[1][r] = cplx{0.0, 0.0}; }
+        brf_mac_pair(ps, x, row, W, lane);
+        WAVE_SYNC();     // every lane is done with the exchange buffers
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            lds.xbufA[r * 64 + lane] = ps[1 - W][r];
+            sum[r] = ps[W][r];
+        }
+    }
+    pair_sync();
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const cplx o = lds.xbufA_other[r * 64 + lane];
+        sum[r].re += o.re;
+        sum[r].im += o.im;
+    }
+    pair_sync();
+    {
+        cplx (&one)[1][8] = reinterpret_cast<cplx (&)[1][8]>(sum);
+        cplx *const buf1[1] = {lds.xbufA};
+        fft_inverse_n<1>(one, buf1, lds.tw1, tw2, L);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        lds.acc[W * 1024 + lane + 64 * r] += (i32)fft_round_to_u32(sum[r].re);
+        lds.acc[W * 1024 + lane + 64 * (r + 8)] += (i32)fft_round_to_u32(-sum[r].im);
+    }
+    WAVE_SYNC();
+}
+
+template <int W, class PairSync>
+FF_FN void brfp_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSource &s1, i32 c0, long bit,
+                          const cplx *bk, int n, i32 mu, const BrFftPairLds &lds, const FftLane &L, PairSync &&pair_sync)
+{
+    const int tid = 64 * W + L.lane;
+    for (int i = tid; i < n; i += 128) {
+        u32 v = 0;
+        if (s0.p) v += (u32)s0.p * (u32)s0.a[bit * s0.a_stride + i];
+        if (s1.p) v += (u32)s1.p * (u32)s1.a[bit * s1.a_stride + i];
+        lds.bara[i] = (uint16_t)br_modswitch(v);
+    }
+    u32 vb = (u32)c0;
+    if (s0.p) vb += (u32)s0.p * (u32)s0.b[bit * s0.b_stride];
+    if (s1.p) vb += (u32)s1.p * (u32)s1.b[bit * s1.b_stride];
+    const u32 barb = br_modswitch(vb);
+    for (int j = tid; j < 1024; j += 128) {
+        const u32 t = ((u32)j + barb) & 2047u;
+        lds.acc[j] = 0;
+        lds.acc[1024 + j] = (t < 1024u) ? mu : (i32)(0u - (u32)mu);
+    }
+    FftTw2Regs tw2;
+    fft_tw2_load(tw2, lds.tw2, L);
+    WAVE_SYNC();
+    pair_sync();
+    for (int i = 0; i < n; i++) {
+        br_pace(lds.pace, (u32)i);
+        const u32 a = WAVE_UNIFORM((u32)lds.bara[i]);
+        if (a == 0) continue;
+        brfp_step<W>(a, bk + (long)i * BKF_ROW_ELEMS, lds, tw2, L, pair_sync);
+    }
+    br_pace_done(lds.pace);
+    pair_sync();
+    for (int j = tid; j < 1024; j += 128) {
+        const u32 v = (u32)lds.acc[j];
+        out_a[(1024 - j) & 1023] = (i32)(j == 0 ? v : 0u - v);
+    }
+    if (tid == 0) *out_b = lds.acc[1024];
+}

@@ -343,6 +343,53 @@ __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_bootstrap_fft(BrLaunch 
     br_extract<1>(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, acc, lane);
 }
 
+// Medium batches, FFT (CUs < bits <= 3 x CUs): two waves per bit, up to 3 pairs per work-group (blind_rotate_fft.h,
+// brfp_*).  LDS: tables | pacing / barrier words | per pair: ACC 8 KiB, bara 1 KiB, 2 x 2 exchange buffers
+#define FPAIR_LDS_BYTES (2 * 1024 * 4 + WAVE_BARA_BYTES + 4 * WAVE_FXBUF_BYTES)
+#define BRFP_MAX_PAIRS 3
+static_assert(FTABLE_LDS_BYTES + BR_PACE_BYTES + BRFP_MAX_PAIRS * FPAIR_LDS_BYTES <= 160 * 1024, "LDS budget of the FFT pair kernel");
+__global__ __launch_bounds__(128 * BRFP_MAX_PAIRS, 2) void k_bootstrap_fft_pair(BrLaunch P)
+{
+    load_ftables((const cplx *)P.tw_a, (const cplx *)P.tw_b);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int pair = wave >> 1;
+    const long gbit = (long)blockIdx.x * (blockDim.x >> 7) + pair;   // pairs per group chosen at launch
+    const BrPace pace = carve_pace(g_smem + FTABLE_LDS_BYTES, wave, gbit < P.nbits_total);
+    if (gbit >= P.nbits_total) return;                                // (both waves of the pair)
+    const int job = gbit >= P.bits_per_job ? 1 : 0;
+    const long bit = gbit - (job ? P.bits_per_job : 0);
+    unsigned char *base = g_smem + FTABLE_LDS_BYTES + BR_PACE_BYTES + pair * FPAIR_LDS_BYTES;
+    unsigned char *xb = base + 2 * 1024 * 4 + WAVE_BARA_BYTES;
+    BrFftPairLds lds;
+    lds.acc = (i32 *)base;
+    lds.bara = (uint16_t *)(base + 2 * 1024 * 4);
+    lds.xbufA = (cplx *)(xb + (wave & 1) * 2 * WAVE_FXBUF_BYTES);
+    lds.xbufB = lds.xbufA + FFT_XBUF_ELEMS;
+    lds.xbufA_other = (const cplx *)(xb + ((wave & 1) ^ 1) * 2 * WAVE_FXBUF_BYTES);
+    lds.tw1 = (const cplx *)g_smem;
+    lds.tw2 = (const cplx *)g_smem + FFT_TW1_ELEMS;
+    lds.pace = pace;
+    // pair barrier: arrival counters in LDS (see k_bootstrap_pair)
+    u32 *arrive = (u32 *)(g_smem + FTABLE_LDS_BYTES) + 8;
+    u32 *mine = arrive + wave;
+    const u32 *other = arrive + (wave ^ 1);
+    u32 seq = 0;
+    auto pair_sync = [&] {
+        seq++;
+        __hip_atomic_store(mine, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while ((i32)((u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(other, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) - seq) < 0)
+            __builtin_amdgcn_s_sleep(1);
+    };
+    const FftLane L = fft_lane_init(lane);
+    i32 *out_a = P.out_a + gbit * P.out_a_stride, *out_b = P.out_b + gbit * P.out_b_stride;
+    if ((wave & 1) == 0)
+        brfp_bootstrap<0>(out_a, out_b, P.job[job].s0, P.job[job].s1, P.job[job].c0, bit, (const cplx *)P.bk, P.n, P.mu,
+                          lds, L, pair_sync);
+    else
+        brfp_bootstrap<1>(out_a, out_b, P.job[job].s0, P.job[job].s1, P.job[job].c0, bit, (const cplx *)P.bk, P.n, P.mu,
+                          lds, L, pair_sync);
+}
+
 // Small-batch FFT variant: 4 waves per bit (blind_rotate_fft.h, brft_*).
 // LDS: tables 9 KiB | ACC 8 KiB | bara 1 KiB | partial sums 64 KiB | 4 exchange buffers
 #define TEAMF_LDS_BYTES (FTABLE_LDS_BYTES + 2 * 1024 * 4 + WAVE_BARA_BYTES + BRFT_PART_ELEMS * 16 + BRT_WAVES * WAVE_FXBUF_BYTES)
@@ -1092,6 +1139,9 @@ hipError_t kernels_init_device(int *num_cus)
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap_fft_team_k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAMF2_LDS_BYTES);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_bootstrap_fft_pair, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(FTABLE_LDS_BYTES + BR_PACE_BYTES + BRFP_MAX_PAIRS * FPAIR_LDS_BYTES));
+    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_blind_rotate_accum<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(1));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_blind_rotate_accum<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(2));
@@ -1198,9 +1248,16 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, lon
             const int w = br_pick_waves(P.nbits_total, BR_WAVES_K(2), num_cus);
             hipLaunchKernelGGL(k_bootstrap<2>, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), br_lds_bytes(2, w), stream, P);
         }
+    } else if (transform == 1 && mask_size == 1 && pair_max_bits > 0 && P.nbits_total <= (long)BRFP_MAX_PAIRS * num_cus) {
+        // small and medium batches, FFT: 2 waves per bit, 1 to 3 pairs per work-group (ahead of the 4-wave team kernel at
+        // every size: 2.9 vs 3.0 ms up to 1 x CUs bits, 3.1 ms up to 2 x CUs, 3.7 ms up to 3 x CUs); any non-zero pair
+        // limit enables it
+        long pairs = (P.nbits_total + num_cus - 1) / num_cus;
+        if (pairs > BRFP_MAX_PAIRS) pairs = BRFP_MAX_PAIRS;
+        hipLaunchKernelGGL(k_bootstrap_fft_pair, dim3(blocks_for(P.nbits_total, (int)pairs)), dim3(128 * (unsigned)pairs),
+                           FTABLE_LDS_BYTES + BR_PACE_BYTES + (size_t)pairs * FPAIR_LDS_BYTES, stream, P);
     } else if (transform == 1 && mask_size == 1 && P.nbits_total <= team_max_bits / 2) {
-        // small batch, FFT: 4 waves per bit (one bit per CU; the wave-per-bit kernel is ahead again
-        // once the batch needs a second round of teams)
+        // (pair kernel switched off:) small batch, FFT: 4 waves per bit, one bit per CU
         hipLaunchKernelGGL(k_bootstrap_fft_team, dim3((unsigned)P.nbits_total), dim3(64 * BRT_WAVES), TEAMF_LDS_BYTES, stream, P);
     } else if (transform == 1 && mask_size == 1) {
         const int w = br_pick_waves(P.nbits_total, BR_WAVES_PER_BLOCK, num_cus);

@@ -284,6 +284,26 @@ void emu_bootstrap_bit_fft_team(i32 *out_a, i32 *out_b, const double *bk_interna
     });
 }
 
+// 2-wave pair variant of the FFT body (brfp_*): 128 fibres
+void emu_bootstrap_bit_fft_pair(i32 *out_a, i32 *out_b, const double *bk_internal, int n,
+                                const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,
+                                i32 c0, i32 mu)
+{
+    ftables();
+    std::vector<cplx> xbuf(4 * FFT_XBUF_ELEMS);
+    std::vector<i32> accbuf(2 * 1024);
+    std::vector<uint16_t> bara(BR_MAX_LWE);
+    BrSource s0{a0, b0, 0, 0, p0}, s1{a1, b1, 0, 0, p1};
+    emu_run_team(2, [&](int w, int lane) {
+        BrFftPairLds lds{xbuf.data() + w * 2 * FFT_XBUF_ELEMS, xbuf.data() + (w * 2 + 1) * FFT_XBUF_ELEMS,
+                         xbuf.data() + (w ^ 1) * 2 * FFT_XBUF_ELEMS, accbuf.data(), bara.data(), g_ftw1, g_ftw2,
+                         {nullptr, nullptr}};
+        FftLane L = fft_lane_init(lane);
+        if (w == 0) brfp_bootstrap<0>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bk_internal, n, mu, lds, L, [] { emu_team_sync(); });
+        else brfp_bootstrap<1>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bk_internal, n, mu, lds, L, [] { emu_team_sync(); });
+    });
+}
+
 // tlwe_mask_size = 2 with the FFT transform (brfk_*): out_a has 2048 entries
 void emu_bootstrap_bit_fft_k2(i32 *out_a, i32 *out_b, const double *bk_internal, int n,
                               const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,

@@ -162,6 +162,29 @@ def test_bootstrap_wave_body_fft_full_key(orc, oracle_keys):
     assert (ga == ea[0]).all() and gb == eb[0]
 
 
+def test_bootstrap_fft_bodies_reduced_key(orc):
+    """The three FFT bodies for k = 1 (one wave per bit, the 4-wave team, the 2-wave pair) on a reduced number of rows of
+    a full-range int32 TGSW key == the EXACT (NTT) oracle on the same key (their fp64 sums associate differently; all of
+    them round to the exact integers)."""
+    from oracle import oracle_fft as of
+    rs = numpy.random.RandomState(63)
+    n = 6
+    tgsw = rs.randint(-2**31, 2**31, size=(n, 2, 2, 2, 1024), dtype=numpy.int32)
+    bk_ntt = orc.tlwe_transform_samples(tgsw)
+    bkf = emu.bkf_from_reference(of.fft_forward(tgsw))
+    MU = 2**29
+    a0 = rs.randint(-2**31, 2**31, size=n, dtype=numpy.int32)
+    a1 = rs.randint(-2**31, 2**31, size=n, dtype=numpy.int32)
+    a0[3] = 0; a1[3] = 0                                           # bara = 0 -> skipped iteration
+    b0 = rs.randint(-2**31, 2**31, size=1, dtype=numpy.int32)
+    b1 = rs.randint(-2**31, 2**31, size=1, dtype=numpy.int32)
+    ta = (a0 + a1).astype(numpy.int32); tb = (numpy.int32(-MU) + b0 + b1).astype(numpy.int32)
+    ea, eb = orc.bootstrap_extract(bk_ntt, ta[None, :], tb, MU)
+    for kw in ({}, {'team': True}, {'pair': True}):
+        ga, gb = emu.bootstrap_bit_fft(bkf, n, (a0, b0), 1, (a1, b1), 1, -MU, MU, **kw)
+        assert (ga == ea[0]).all() and gb == eb[0], kw
+
+
 def test_bootstrap_wave_body_mask_size_2(orc):
     """tlwe_mask_size = 2 (test/test_gates.py:96-100 of the reference): the K = 2 instantiation of
     the fused body == oracle, reduced number of rows, random transformed-domain key."""

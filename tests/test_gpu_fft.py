@@ -179,8 +179,9 @@ def test_config5_fft_context_end_to_end_4096(thr):
 
 
 def test_fft_small_batch_team_kernel(fft_env, thr, H, orc):
-    """The 4-waves-per-bit FFT kernel (batches <= CUs bits) vs the wave-per-bit FFT kernel and vs the
-    exact (NTT) oracle: within the path's tolerance; observed: identical words."""
+    """The three FFT kernels on a small batch -- one wave per bit, the 4-wave team (taken when the pair kernel is
+    switched off), the 2-wave pair (default) -- vs the exact (NTT) oracle: within the path's tolerance; observed:
+    identical words."""
     from nufhe_amd import _lib
     vm = fft_env['vm']; ck = fft_env['ck']; lwe_key = fft_env['lwe_key']
     rng = orc.DeterministicRNG(31337)
@@ -191,18 +192,56 @@ def test_fft_small_batch_team_kernel(fft_env, thr, H, orc):
     exp = {'nand': orc.gate('gate_nand', ck, cs[0], cs[1]), 'mux': orc.gate_mux(ck, cs[0], cs[1], cs[2])}
     got = {}
     try:
-        for limit in (0, -1):                       # 0: wave-per-bit kernel, -1: default switch (team kernel here)
-            _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, limit)
+        # (team limit, pair limit): wave-per-bit kernel; team kernel; default switches = pair kernel
+        for limit in ((0, 0), (-1, 0), (-1, -1)):
+            _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, limit[0])
+            _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, limit[1])
             got[limit] = {'nand': H.ct_arrays(vm.gate_nand(ds[0], ds[1])), 'mux': H.ct_arrays(vm.gate_mux(ds[0], ds[1], ds[2]))}
     finally:
         _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, -1)
+        _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, -1)
     for name in ('nand', 'mux'):
-        for limit in (0, -1):
+        for limit in ((0, 0), (-1, 0), (-1, -1)):
             ra, rb, rcv = got[limit][name]
             da = (ra.astype(numpy.int64) - exp[name][0].astype(numpy.int64) + 2**31) % 2**32 - 2**31
             db = (rb.astype(numpy.int64) - exp[name][1].astype(numpy.int64) + 2**31) % 2**32 - 2**31
             assert numpy.abs(da).max() <= FFT_TOLERANCE_LSB and numpy.abs(db).max() <= FFT_TOLERANCE_LSB, (name, limit)
             assert (rcv == exp[name][2]).all()
-        same = all((x == y).all() for x, y in zip(got[0][name], got[-1][name]))
-        print("FFT %s: team kernel == wave kernel: %s; words differing from the exact path: %d" % (
-            name, same, int((got[-1][name][0] != exp[name][0]).sum())))
+        same = all((x == y).all() for k in ((-1, 0), (-1, -1)) for x, y in zip(got[(0, 0)][name], got[k][name]))
+        print("FFT %s: team and pair kernels == wave kernel: %s; words differing from the exact path: %d" % (
+            name, same, int((got[(-1, -1)][name][0] != exp[name][0]).sum())))
+
+
+def test_fft_medium_batch_pair_kernel(fft_env, thr, H, orc):
+    """The 2-waves-per-bit FFT kernel (bits <= 3 x CUs) with 1, 2 and 3 pairs per work-group (ragged last group)
+    vs the wave-per-bit FFT kernel on the same ciphertexts and vs the exact (NTT) oracle on the first 24 bits: within
+    the path's tolerance; observed: identical words."""
+    import torch
+    from nufhe_amd import _lib
+    vm = fft_env['vm']; ck = fft_env['ck']; lwe_key = fft_env['lwe_key']
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    rng = orc.DeterministicRNG(909)
+    sizes = [cus - 7, 2 * cus - 5, 3 * cus - 1]
+    B = max(sizes)
+    ms = [rng.uniform_bool((B,)).astype(bool) for _ in range(2)]
+    cs = [orc.encrypt(rng, lwe_key, m) for m in ms]
+    ds = [H.ciphertext_from_arrays(thr, c, fft_env['params']) for c in cs]
+    exp = orc.gate('gate_nand', ck, tuple(x[:24] for x in cs[0]), tuple(x[:24] for x in cs[1]))
+
+    def dev(x, y):
+        return numpy.abs((x.astype(numpy.int64) - y.astype(numpy.int64) + 2**31) % 2**32 - 2**31).max()
+    try:
+        for size in sizes:
+            a, b = ds[0][:size], ds[1][:size]
+            _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, 0)
+            _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, 0)
+            wave = H.ct_arrays(vm.gate_nand(a, b))
+            _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, -1)
+            pair = H.ct_arrays(vm.gate_nand(a, b))
+            assert dev(wave[0], pair[0]) <= FFT_TOLERANCE_LSB and dev(wave[1], pair[1]) <= FFT_TOLERANCE_LSB, size
+            assert (wave[2] == pair[2]).all()
+            assert dev(pair[0][:24], exp[0]) <= FFT_TOLERANCE_LSB and dev(pair[1][:24], exp[1]) <= FFT_TOLERANCE_LSB
+            print("FFT pair vs wave kernel, %d bits: differing words: %d" % (size, int((wave[0] != pair[0]).sum() + (wave[1] != pair[1]).sum())))
+    finally:
+        _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, -1)
+        _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, -1)
