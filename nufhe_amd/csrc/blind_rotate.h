@@ -750,3 +750,139 @@ FF_FN void brp_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSou
     }
     if (tid == 0) *out_b = lds.acc[1024];
 }
+
+// ------------------------------------------------------------------------------------------
+// Team variant WITHOUT a partial-sum buffer, any K (used for K = 2): K + 1 wavefronts per bit, wave w owns input
+// polynomial w (two forward transforms, its products with BK_row[w][0..1][0..K]) and output polynomial w (one inverse
+// transform, ACC[w], which only it reads and writes during the loop).  The partial sum of every OTHER wave's output is
+// handed over through this wave's exchange buffer, one output per phase: in phase p = 1..K wave w writes its partial
+// sum of output (w + p) mod (K + 1), team barrier, reads the one meant for it from wave (w - p) mod (K + 1), team
+// barrier.  Only one partial sum is in registers at a time (brtk_* holds all K + 1 and needs a 72 KiB buffer for K = 2),
+// so the team needs 39 KiB of LDS and two teams share a CU.  K = 1 is k_bootstrap_pair's scheme (brp_*).  Canonical
+// partial sums, exact field additions: bit-identical to the other kernels.  team_sync() is a barrier over the K + 1
+// waves of the team (LDS arrival counters, see kernels.hip).
+// ------------------------------------------------------------------------------------------
+struct BrRingLds {
+    u64 *xbuf_team;          // K + 1 exchange buffers, NTT_XBUF_ELEMS u64 each; wave w uses number w
+    i32 *acc;                // [K+1][1024], shared by the team
+    uint16_t *bara;          // [BR_MAX_LWE], shared
+    const u64 *tw1x;
+    const u64 *tw1i;
+    BrPace pace;
+};
+
+// out = x0 (*) poly0 + x1 (*) poly1 (one output polynomial; key loads one step ahead)
+FF_FN void br_mac2_one(u64 (&out)[16], const u64 (&x0)[16], const u64 (&x1)[16], const u64 *poly0, const u64 *poly1, int lane)
+{
+    const u64 *p = poly0 + lane * 2, *pd = poly1 + lane * 2;
+    u64 q0 = p[0], q1 = p[1], q2 = pd[0], q3 = pd[1];
+#pragma unroll
+    for (int h = 0; h < 8; h++) {
+        u64 n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+        if (h + 1 < 8) {
+            n0 = p[(h + 1) * 128]; n1 = p[(h + 1) * 128 + 1]; n2 = pd[(h + 1) * 128]; n3 = pd[(h + 1) * 128 + 1];
+            BR_ISSUE_FENCE();
+        }
+        out[2 * h] = ff_dot2<false>(x0[2 * h], q0, x1[2 * h], q2, 0);
+        out[2 * h + 1] = ff_dot2<false>(x0[2 * h + 1], q1, x1[2 * h + 1], q3, 0);
+        q0 = n0; q1 = n1; q2 = n2; q3 = n3;
+    }
+}
+
+template <int K, class TeamSync>
+FF_FN void brr_step(u32 a, const u64 *row, const BrRingLds &lds, const NttLane &L, int w, TeamSync &&team_sync)
+{
+    const int lane = L.lane;
+    u64 *xbuf = lds.xbuf_team + w * NTT_XBUF_ELEMS;
+    u64 x0[16], x1[16];
+    {
+        u32 T[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const u32 j = (u32)(lane + 64 * r);
+            const u32 t = (j - a) & 2047u;
+            const u32 v = (u32)lds.acc[w * 1024 + (t & 1023u)];
+            T[r] = ((t & 1024u) ? 0u - v : v) - (u32)lds.acc[w * 1024 + j];     // (X^a - 1) ACC_w
+        }
+        i32 dg[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) dg[r] = br_digit<0>(T[r]);
+        ntt_forward_small_l4(x0, dg, xbuf, lds.tw1x, L);
+#pragma unroll
+        for (int r = 0; r < 16; r++) dg[r] = br_digit<1>(T[r]);
+        ntt_forward_small_l4(x1, dg, xbuf, lds.tw1x, L);
+    }
+    // polynomial (w, d, mo) of the row: ((w * 2 + d) * (K + 1) + mo)
+    const u64 *rw = row + (long)w * 2 * (K + 1) * BK_POLY_ELEMS;
+    auto partial = [&](u64 (&out)[16], int mo) {
+        br_mac2_one(out, x0, x1, rw + (long)mo * BK_POLY_ELEMS, rw + (long)(K + 1 + mo) * BK_POLY_ELEMS, lane);
+    };
+    u64 sum[16];
+    WAVE_SYNC();                 // every lane is done with the exchange buffer
+#pragma unroll 1
+    for (int p = 1; p <= K; p++) {
+        int to = w + p, from = w - p;
+        if (to > K) to -= K + 1;
+        if (from < 0) from += K + 1;
+        {
+            u64 ps[16];
+            partial(ps, to);
+#pragma unroll
+            for (int r = 0; r < 16; r++) xbuf[r * 64 + lane] = ps[r];
+        }
+        if (p == 1) partial(sum, w);      // own share, while the others finish theirs
+        team_sync();
+        const u64 *src = lds.xbuf_team + from * NTT_XBUF_ELEMS;
+#pragma unroll
+        for (int r = 0; r < 16; r++) sum[r] = ff_add(sum[r], src[r * 64 + lane]);
+        team_sync();
+    }
+    u32 c[16];
+    ntt_inverse_l4_i32(c, sum, xbuf, lds.tw1i, L);
+#pragma unroll
+    for (int r = 0; r < 16; r++) lds.acc[w * 1024 + lane + 64 * r] += (i32)(r == 0 ? c[r] : 0u - c[r]);
+    WAVE_SYNC();
+}
+
+// Whole bootstrap body of wave w of a (K+1)-wave ring team for one bit; out_a has K * 1024 entries.
+template <int K, class TeamSync>
+FF_FN void brr_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSource &s1, i32 c0, long bit,
+                         const u64 *bk, int n, i32 mu, const BrRingLds &lds, const NttLane &L, int w, TeamSync &&team_sync)
+{
+    constexpr int THREADS = 64 * (K + 1);
+    const int tid = 64 * w + L.lane;
+    for (int i = tid; i < n; i += THREADS) {
+        u32 v = 0;
+        if (s0.p) v += (u32)s0.p * (u32)s0.a[bit * s0.a_stride + i];
+        if (s1.p) v += (u32)s1.p * (u32)s1.a[bit * s1.a_stride + i];
+        lds.bara[i] = (uint16_t)br_modswitch(v);
+    }
+    u32 vb = (u32)c0;
+    if (s0.p) vb += (u32)s0.p * (u32)s0.b[bit * s0.b_stride];
+    if (s1.p) vb += (u32)s1.p * (u32)s1.b[bit * s1.b_stride];
+    const u32 barb = br_modswitch(vb);
+    // ACC = (0, ..., 0, X^(2N - barb) * mu)  (bootstrap.py:176-182)
+    for (int j = tid; j < 1024; j += THREADS) {
+        const u32 t = ((u32)j + barb) & 2047u;
+#pragma unroll
+        for (int m = 0; m < K; m++) lds.acc[m * 1024 + j] = 0;
+        lds.acc[K * 1024 + j] = (t < 1024u) ? mu : (i32)(0u - (u32)mu);
+    }
+    WAVE_SYNC();
+    team_sync();
+    for (int i = 0; i < n; i++) {
+        br_pace(lds.pace, (u32)i);
+        const u32 a = WAVE_UNIFORM((u32)lds.bara[i]);
+        if (a == 0) continue;
+        brr_step<K>(a, bk + (long)i * BK_ROW_ELEMS_K(K), lds, L, w, team_sync);
+    }
+    br_pace_done(lds.pace);
+    team_sync();
+    // sample extraction (tlwe_cpu.py:55-58)
+    for (int j = tid; j < K * 1024; j += THREADS) {
+        const int m = j >> 10, jj = j & 1023;
+        const u32 v = (u32)lds.acc[j];
+        out_a[m * 1024 + ((1024 - jj) & 1023)] = (i32)(jj == 0 ? v : 0u - v);
+    }
+    if (tid == 0) *out_b = lds.acc[K * 1024];
+}

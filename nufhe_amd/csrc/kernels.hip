@@ -237,6 +237,44 @@ __global__ __launch_bounds__(128 * BRP_MAX_PAIRS, 2) void k_bootstrap_pair(BrLau
                          lds, L, pair_sync);
 }
 
+// k = 2 without the partial-sum buffer: 3 waves per bit handing their partial sums round through the exchange buffers
+// (blind_rotate.h, brr_*), up to 2 teams per work-group.  LDS: tables | pacing / barrier words | per team: ACC 12 KiB,
+// bara 1 KiB, 3 exchange buffers
+#define RING2_LDS_BYTES (3 * 1024 * 4 + WAVE_BARA_BYTES + 3 * WAVE_XBUF_BYTES)
+#define BRR_MAX_TEAMS 2
+__global__ __launch_bounds__(192 * BRR_MAX_TEAMS, 2) void k_bootstrap_ring_k2(BrLaunch P)
+{
+    load_tables((const u64 *)P.tw_a, (const u64 *)P.tw_b);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int team = wave / 3, w = wave - 3 * team;
+    const long gbit = (long)blockIdx.x * (blockDim.x / 192) + team;   // teams per group chosen at launch
+    const BrPace pace = carve_pace(g_smem + TABLE_LDS_BYTES, wave, gbit < P.nbits_total);
+    if (gbit >= P.nbits_total) return;                                 // (all three waves of the team)
+    const int job = gbit >= P.bits_per_job ? 1 : 0;
+    const long bit = gbit - (job ? P.bits_per_job : 0);
+    unsigned char *base = g_smem + TABLE_LDS_BYTES + BR_PACE_BYTES + team * RING2_LDS_BYTES;
+    BrRingLds lds;
+    lds.acc = (i32 *)base;
+    lds.bara = (uint16_t *)(base + 3 * 1024 * 4);
+    lds.xbuf_team = (u64 *)(base + 3 * 1024 * 4 + WAVE_BARA_BYTES);
+    lds.tw1x = (const u64 *)g_smem;
+    lds.tw1i = (const u64 *)g_smem + 1024;
+    lds.pace = pace;
+    // team barrier over 3 waves: arrival counters in LDS (words 8..13 of the pacing block, zeroed by load_tables)
+    u32 *arrive = (u32 *)(g_smem + TABLE_LDS_BYTES) + 8 + 3 * team;
+    u32 seq = 0;
+    auto team_sync = [&] {
+        seq++;
+        __hip_atomic_store(arrive + w, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int o = 0; o < 3; o++)
+            while ((i32)((u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(arrive + o, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) - seq) < 0)
+                __builtin_amdgcn_s_sleep(1);
+    };
+    const NttLane L = ntt_lane_init(lane);
+    brr_bootstrap<2>(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, P.job[job].s0, P.job[job].s1,
+                     P.job[job].c0, bit, (const u64 *)P.bk, P.n, P.mu, lds, L, w, team_sync);
+}
+
 template <int K>
 __global__ __launch_bounds__(64 * BR_WAVES_K(K), K == 1 ? 2 : 1) void k_blind_rotate_accum(
     i32 *__restrict__ accum, const u64 *__restrict__ bk, const i32 *__restrict__ bara, long bara_stride,
@@ -1125,6 +1163,9 @@ hipError_t kernels_init_device(int *num_cus)
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(2));
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_bootstrap_ring_k2, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(TABLE_LDS_BYTES + BR_PACE_BYTES + BRR_MAX_TEAMS * RING2_LDS_BYTES));
+    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap_k2_roomy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(2, BR_K2_ROOMY_WAVES));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_keyswitch_a, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KS_LDS_BYTES);
@@ -1201,13 +1242,13 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, lon
                             int num_cus, hipStream_t stream)
 {
     if (P.nbits_total == 0) return hipSuccess;
-    // defaults of the batch-size switches (negative = default): NTT k = 1: team kernel up to 1 x CUs, pair kernel up
-    // to 4 x CUs; NTT k = 2: team kernel up to 2 x CUs; FFT k = 1: team kernel up to 1 x CUs, k = 2: up to 2 x CUs
-    // (an explicit value counts half for the FFT kernels, see nufhe_hip.h)
+    // defaults of the batch-size switches (negative = default): NTT: team kernel up to 1 x CUs bits, then the pair
+    // (k = 1, up to 4 x CUs) / ring (k = 2, any size) kernel; FFT k = 1: pair kernel up to 3 x CUs (team kernel up to
+    // 1 x CUs when the pair switch is 0), k = 2: team kernel up to 2 x CUs (an explicit team value counts half for the FFT
+    // kernels, see nufhe_hip.h)
     if (pair_max_bits < 0) pair_max_bits = (long)BRP_MAX_PAIRS * num_cus;
     if (team_max_bits < 0)
-        team_max_bits = (transform == 0 && mask_size == 1) ? (long)num_cus
-                        : (transform == 1 && mask_size == 2) ? 4L * num_cus : 2L * num_cus;
+        team_max_bits = (transform == 0) ? (long)num_cus : (mask_size == 2 ? 4L * num_cus : 2L * num_cus);
     if (transform == 0 && mask_size == 1 && P.nbits_total <= team_max_bits) {
         // small batch: 4 waves per bit, one bit per CU at a time
         hipLaunchKernelGGL(k_bootstrap_team, dim3((unsigned)P.nbits_total), dim3(64 * BRT_WAVES), TEAM_LDS_BYTES, stream, P);
@@ -1237,6 +1278,13 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, lon
     } else if (transform == 0 && mask_size == 2 && P.nbits_total <= team_max_bits) {
         // small batch, k = 2: 3 waves per bit (one team per CU at a time)
         hipLaunchKernelGGL(k_bootstrap_team_k2, dim3((unsigned)P.nbits_total), dim3(64 * 3), TEAM2_LDS_BYTES, stream, P);
+    } else if (transform == 0 && mask_size == 2 && pair_max_bits > 0) {
+        // k = 2 beyond the team kernel: 3 waves per bit without the partial-sum buffer, 2 teams per work-group: rounds of
+        // 2 x CUs bits in 12.3 ms (the wave kernels below: 4 x CUs in 27 ms / 6 x CUs in 43 ms); any non-zero pair limit
+        // enables it
+        const long teams = P.nbits_total > num_cus ? BRR_MAX_TEAMS : 1;
+        hipLaunchKernelGGL(k_bootstrap_ring_k2, dim3(blocks_for(P.nbits_total, (int)teams)), dim3(192 * (unsigned)teams),
+                           TABLE_LDS_BYTES + BR_PACE_BYTES + (size_t)teams * RING2_LDS_BYTES, stream, P);
     } else if (transform == 0 && mask_size == 2) {
         // rounds of 6 x CUs bits at 2 waves per SIMD (42 ms, spills) or rounds of 4 x CUs bits at 1 wave per SIMD
         // (27 ms, no spills): measured ratio 1.56

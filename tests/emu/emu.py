@@ -94,7 +94,7 @@ def bk_from_reference(bk):
     return out
 
 
-def bootstrap_bit(bk_internal, n, src0, p0, src1, p1, c0, mu, mask_size=1, team=False, pair=False):
+def bootstrap_bit(bk_internal, n, src0, p0, src1, p1, c0, mu, mask_size=1, team=False, pair=False, ring=False):
     """src = (a [n], b scalar array [1]); returns (ext_a [1024 * mask_size], ext_b).
     team=True runs the 4-wave (k = 2: 3-wave) team variant of the body, pair=True the 2-wave variant (k = 1)."""
     a0 = numpy.ascontiguousarray(src0[0], numpy.int32); b0 = numpy.ascontiguousarray(src0[1], numpy.int32).reshape(1)
@@ -105,6 +105,8 @@ def bootstrap_bit(bk_internal, n, src0, p0, src1, p1, c0, mu, mask_size=1, team=
         fn = lib().emu_bootstrap_bit_team if mask_size == 1 else lib().emu_bootstrap_bit_team_k2
     if pair:
         fn = lib().emu_bootstrap_bit_pair
+    if ring:
+        fn = lib().emu_bootstrap_bit_ring_k2          # mask_size 2 only
     fn(_p(out_a, c_i32p), _p(out_b, c_i32p), _p(bk_internal, c_u64p), ctypes.c_int(n),
                             _p(a0, c_i32p), _p(b0, c_i32p), ctypes.c_int32(p0),
                             _p(a1, c_i32p), _p(b1, c_i32p), ctypes.c_int32(p1),

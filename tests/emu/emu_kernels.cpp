@@ -198,6 +198,24 @@ extern "C" void emu_bootstrap_bit_team_k2(i32 *out_a, i32 *out_b, const u64 *bk_
     });
 }
 
+// the 3-wave ring variant for tlwe_mask_size = 2 (blind_rotate.h, brr_*): partial sums handed round through the
+// exchange buffers
+extern "C" void emu_bootstrap_bit_ring_k2(i32 *out_a, i32 *out_b, const u64 *bk_internal, int n,
+                                          const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,
+                                          i32 c0, i32 mu)
+{
+    tables();
+    std::vector<u64> xbuf(3 * NTT_XBUF_ELEMS);
+    std::vector<i32> accbuf(3 * 1024);
+    std::vector<uint16_t> bara(BR_MAX_LWE);
+    BrSource s0{a0, b0, 0, 0, p0}, s1{a1, b1, 0, 0, p1};
+    emu_run_team(3, [&](int w, int lane) {
+        BrRingLds lds{xbuf.data(), accbuf.data(), bara.data(), g_tw1x, g_tw1i, {nullptr, nullptr}};
+        NttLane L = ntt_lane_init(lane);
+        brr_bootstrap<2>(out_a, out_b, s0, s1, c0, 0, bk_internal, n, mu, lds, L, w, [] { emu_team_sync(); });
+    });
+}
+
 extern "C" void emu_bootstrap_bit(i32 *out_a, i32 *out_b, const u64 *bk_internal, int n,
                                   const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,
                                   i32 c0, i32 mu)

@@ -165,12 +165,14 @@ def test_gpu_k2_gates_vs_oracle_ragged(k2_env, thr, H, orc):
 
 
 @pytest.mark.gpu
-def test_gpu_k2_both_wave_kernels(k2_env, thr, H, orc):
-    """k = 2, NTT, batches beyond the team kernel: between 4 x and 6 x CUs bits the launch takes the 6-waves-per-CU
-    build (k_bootstrap<2>), otherwise the one-wave-per-SIMD build (k_bootstrap_k2_roomy).  A 5 x CUs batch (first
-    kernel) must equal the same ciphertexts processed as two halves (second kernel) on every word, and the oracle
-    on its first and last 8 bits."""
+def test_gpu_k2_large_batch_kernels(k2_env, thr, H, orc):
+    """k = 2, NTT, batches beyond the team kernel.  Default: the ring kernel (3 waves per bit, 2 teams per work-group,
+    ragged last group).  With the pair switch at 0: between 4 x and 6 x CUs bits the 6-waves-per-CU build
+    (k_bootstrap<2>), otherwise the one-wave-per-SIMD build (k_bootstrap_k2_roomy).  A 5 x CUs batch through the ring
+    kernel and through k_bootstrap<2> must equal the same ciphertexts processed as two halves by the roomy kernel on
+    every word, and the oracle on its first and last 8 bits."""
     import torch
+    from nufhe_amd import _lib
     vm = k2_env['vm']; ck = k2_env['ck']; lwe_key = k2_env['lwe_key']; params = k2_env['params']
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     rng = orc.DeterministicRNG(31)
@@ -178,15 +180,20 @@ def test_gpu_k2_both_wave_kernels(k2_env, thr, H, orc):
     ms = [rng.uniform_bool((B,)).astype(bool) for _ in range(2)]
     cs = [orc.encrypt(rng, lwe_key, m, k2_env['oparams']) for m in ms]
     ds = [H.ciphertext_from_arrays(thr, c, params) for c in cs]
-    whole = H.ct_arrays(vm.gate_nand(ds[0], ds[1]))
-    h = 3 * cus        # 3 x CUs and 2 x CUs - 3 bits: above the team limit (2 x CUs), one round of the roomy kernel
-    first = H.ct_arrays(vm.gate_nand(ds[0][:h], ds[1][:h]))
-    second = H.ct_arrays(vm.gate_nand(ds[0][h:], ds[1][h:]))
-    for w, a, b in zip(whole, first, second):
-        assert (w[:h] == a).all() and (w[h:] == b).all()
+    h = 3 * cus        # 3 x CUs and 2 x CUs - 3 bits: one round of the roomy kernel each
+    try:
+        ring = H.ct_arrays(vm.gate_nand(ds[0], ds[1]))
+        _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, 0)
+        whole = H.ct_arrays(vm.gate_nand(ds[0], ds[1]))
+        first = H.ct_arrays(vm.gate_nand(ds[0][:h], ds[1][:h]))
+        second = H.ct_arrays(vm.gate_nand(ds[0][h:], ds[1][h:]))
+    finally:
+        _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, -1)
+    for r, w, a, b in zip(ring, whole, first, second):
+        assert (w[:h] == a).all() and (w[h:] == b).all() and (r == w).all()
     idx = numpy.r_[0:8, B - 8:B]
     exp = orc.gate('gate_nand', ck, tuple(x[idx] for x in cs[0]), tuple(x[idx] for x in cs[1]))
-    for w, e in zip(whole, exp):
+    for w, e in zip(ring, exp):
         assert (w[idx] == e).all()
 
 
@@ -213,8 +220,9 @@ def test_gpu_k2_context_end_to_end(thr):
 
 @pytest.mark.gpu
 def test_gpu_k2_small_batch_team_kernel_equals_wave_kernel(k2_env, thr, H, orc):
-    """k = 2 on a small batch: the 3-waves-per-bit kernel (k_bootstrap_team_k2, batches <= 2 x CUs bits) gives
-    exactly the ciphertexts of the wave-per-bit kernel and of the oracle (NAND and MUX, 70 bits)."""
+    """k = 2 on a small batch: the 3-waves-per-bit kernels (k_bootstrap_team_k2 with its partial-sum buffer, batches <=
+    CUs bits by default; k_bootstrap_ring_k2 without it) give exactly the ciphertexts of the wave-per-bit kernel and of
+    the oracle (NAND and MUX, 70 bits)."""
     from nufhe_amd import _lib
     vm = k2_env['vm']; ck = k2_env['ck']; lwe_key = k2_env['lwe_key']; params = k2_env['params']
     rng = orc.DeterministicRNG(777)
@@ -225,14 +233,17 @@ def test_gpu_k2_small_batch_team_kernel_equals_wave_kernel(k2_env, thr, H, orc):
     exp = {'nand': orc.gate('gate_nand', ck, cs[0], cs[1]), 'mux': orc.gate_mux(ck, cs[0], cs[1], cs[2])}
     got = {}
     try:
-        for limit in (0, -1):            # 0: wave-per-bit kernel; -1: default switch (team kernel for 70 bits)
-            _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, limit)
+        # (team limit, pair limit): (0, 0) wave-per-bit kernel; (0, -1) ring kernel; (-1, -1) default = team kernel
+        for limit in ((0, 0), (0, -1), (-1, -1)):
+            _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, limit[0])
+            _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, limit[1])
             got[limit] = {'nand': H.ct_arrays(vm.gate_nand(ds[0], ds[1])),
                           'mux': H.ct_arrays(vm.gate_mux(ds[0], ds[1], ds[2]))}
     finally:
         _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, -1)
+        _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, -1)
     for name in ('nand', 'mux'):
-        for limit in (0, -1):
+        for limit in ((0, 0), (0, -1), (-1, -1)):
             ra, rb, rcv = got[limit][name]
             assert (ra == exp[name][0]).all() and (rb == exp[name][1]).all() and (rcv == exp[name][2]).all(), (name, limit)
 
