@@ -203,7 +203,7 @@ int nufhe_tlwe_encrypt_zero(nufhe_ctx *ctx, int32_t *d_result_a, const int32_t *
 /* Batch-size switches of the bootstrap.  A bootstrap of up to `bits` ciphertext bits (FFT: bits/2) runs the
  * small-batch kernel (4 wavefronts share a bit, 3 for tlwe_mask_size = 2; NTT ~2.7x, FFT ~1.4x shorter latency, one
  * bit per CU at a time), larger batches the throughput kernel (one wavefront per bit).  bits < 0 restores the
- * defaults (in ciphertext bits: the CU count; twice that for k = 2 with the FFT); 0 disables the
+ * defaults (in ciphertext bits: the CU count); 0 disables the
  * small-batch kernels.  Results are bit-identical either way (FFT: identical on every tested input).
  * No reference counterpart (the reference always splits a bit over 512+ threads, blind_rotate.py:89-187). */
 int nufhe_ctx_set_team_max_bits(nufhe_ctx *ctx, long bits);
@@ -212,8 +212,8 @@ int nufhe_ctx_set_team_max_bits(nufhe_ctx *ctx, long bits);
  * give every SIMD two bits).  bits < 0 restores the default (4 x the CU count); 0 disables it.
  * FFT: any non-zero value enables the 2-wavefront kernel for batches up to 3 x the CU count (it is ahead of the
  * 4-wavefront kernel at every size, which then only runs when this switch is 0).
- * NTT, k = 2: any non-zero value enables the 3-wavefront kernel without a partial-sum buffer for every batch above
- * the small-batch limit (rounds of 2 x CUs bits; with 0 the one-wavefront-per-bit kernels run instead). */
+ * k = 2, either transform: any non-zero value enables the 3-wavefront kernel without a partial-sum buffer for every
+ * batch above the small-batch limit (rounds of 2 x CUs bits; with 0 the one-wavefront-per-bit kernels run instead). */
 int nufhe_ctx_set_pair_max_bits(nufhe_ctx *ctx, long bits);
 
 /* ---- measurement: time of the last fused gate / bootstrap kernels, from HIP events on the

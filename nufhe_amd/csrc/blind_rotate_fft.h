@@ -709,3 +709,158 @@ FF_FN void brfp_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSo
     }
     if (tid == 0) *out_b = lds.acc[1024];
 }
+
+// ------------------------------------------------------------------------------------------
+// Ring variant of the FFT path for tlwe_mask_size = K > 1 (the counterpart of blind_rotate.h, brr_*): K + 1 wavefronts
+// per bit, wave w owns input polynomial w (its two interleaved digit transforms and their products with
+// BK_row[w][0..1][0..K]) and output polynomial w.  No partial-sum buffer: in phase p = 1..K wave w writes its partial sum
+// of output (w + p) mod (K + 1) into its first exchange buffer, team barrier, adds the one wave (w - p) mod (K + 1)
+// wrote for it, team barrier.  67 KiB of LDS per team for K = 2, two teams per CU.  fp64 sums: own share first, then the
+// received ones in phase order -- another association than the other kernels', covered by the path's tolerance and
+// identical after rounding on every tested input.
+// ------------------------------------------------------------------------------------------
+struct BrFftRingLds {
+    cplx *xbuf_team;         // K + 1 pairs of exchange buffers (2 x FFT_XBUF_ELEMS complex per wave); wave w: pair w
+    i32 *acc;                // [K+1][1024], shared by the team
+    uint16_t *bara;          // [BR_MAX_LWE], shared
+    const cplx *tw1;
+    const cplx *tw2;
+    BrPace pace;
+};
+
+// out = x[0] (*) poly0 + x[1] (*) poly1 (one output polynomial; key loads in groups of 4, one group ahead)
+FF_FN void brf_mac_one(cplx (&out)[8], const cplx (&x)[2][8], const cplx *poly0, const cplx *poly1, int lane)
+{
+    auto addr = [&](int g, int i) { return ((g >> 1) ? poly1 : poly0) + lane + (4 * (g & 1) + i) * 64; };   // g = 2 d + half
+    cplx k[4], n[4];
+#pragma unroll
+    for (int r = 0; r < 8; r++) out[r] = cplx{0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < 4; i++) k[i] = *addr(0, i);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        if (g + 1 < 4) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) n[i] = *addr(g + 1, i);
+            BR_ISSUE_FENCE();
+        }
+        const int d = g >> 1;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = 4 * (g & 1) + i;
+            out[r].re += x[d][r].re * k[i].re - x[d][r].im * k[i].im;
+            out[r].im += x[d][r].re * k[i].im + x[d][r].im * k[i].re;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) k[i] = n[i];
+    }
+}
+
+template <int K, class TW2, class TeamSync>
+FF_FN void brfr_step(u32 a, const cplx *row, const BrFftRingLds &lds, const TW2 &tw2, const FftLane &L, int w,
+                     TeamSync &&team_sync)
+{
+    const int lane = L.lane;
+    cplx *xbufA = lds.xbuf_team + (long)w * 2 * FFT_XBUF_ELEMS;
+    cplx *const bufs[2] = {xbufA, xbufA + FFT_XBUF_ELEMS};
+    cplx x[2][8];
+    {
+        u32 T[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const u32 j = (u32)(lane + 64 * r);
+            const u32 t = (j - a) & 2047u;
+            const u32 v = (u32)lds.acc[w * 1024 + (t & 1023u)];
+            T[r] = ((t & 1024u) ? 0u - v : v) - (u32)lds.acc[w * 1024 + j];     // (X^a - 1) ACC_w
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            x[0][r] = cplx{(double)br_digit<0>(T[r]), -(double)br_digit<0>(T[r + 8])};   // a_j - i a_{j+512}
+            x[1][r] = cplx{(double)br_digit<1>(T[r]), -(double)br_digit<1>(T[r + 8])};
+        }
+    }
+    fft_forward_n<2>(x, bufs, lds.tw1, tw2, L);
+    // polynomial (w, d, mo) of the row: ((w * 2 + d) * (K + 1) + mo)
+    const cplx *rw = row + (long)w * 2 * (K + 1) * BKF_POLY_ELEMS;
+    auto partial = [&](cplx (&out)[8], int mo) {
+        brf_mac_one(out, x, rw + (long)mo * BKF_POLY_ELEMS, rw + (long)(K + 1 + mo) * BKF_POLY_ELEMS, lane);
+    };
+    cplx sum[8];
+    WAVE_SYNC();                 // every lane is done with the exchange buffers
+#pragma unroll 1
+    for (int p = 1; p <= K; p++) {
+        int to = w + p, from = w - p;
+        if (to > K) to -= K + 1;
+        if (from < 0) from += K + 1;
+        {
+            cplx ps[8];
+            partial(ps, to);
+#pragma unroll
+            for (int r = 0; r < 8; r++) xbufA[r * 64 + lane] = ps[r];
+        }
+        if (p == 1) partial(sum, w);      // own share, while the others finish theirs
+        team_sync();
+        const cplx *src = lds.xbuf_team + (long)from * 2 * FFT_XBUF_ELEMS;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const cplx o = src[r * 64 + lane];
+            sum[r].re += o.re;
+            sum[r].im += o.im;
+        }
+        team_sync();
+    }
+    {
+        cplx (&one)[1][8] = reinterpret_cast<cplx (&)[1][8]>(sum);
+        cplx *const buf1[1] = {xbufA};
+        fft_inverse_n<1>(one, buf1, lds.tw1, tw2, L);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        lds.acc[w * 1024 + lane + 64 * r] += (i32)fft_round_to_u32(sum[r].re);
+        lds.acc[w * 1024 + lane + 64 * (r + 8)] += (i32)fft_round_to_u32(-sum[r].im);
+    }
+    WAVE_SYNC();
+}
+
+template <int K, class TeamSync>
+FF_FN void brfr_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSource &s1, i32 c0, long bit,
+                          const cplx *bk, int n, i32 mu, const BrFftRingLds &lds, const FftLane &L, int w,
+                          TeamSync &&team_sync)
+{
+    constexpr int THREADS = 64 * (K + 1);
+    const int tid = 64 * w + L.lane;
+    for (int i = tid; i < n; i += THREADS) {
+        u32 v = 0;
+        if (s0.p) v += (u32)s0.p * (u32)s0.a[bit * s0.a_stride + i];
+        if (s1.p) v += (u32)s1.p * (u32)s1.a[bit * s1.a_stride + i];
+        lds.bara[i] = (uint16_t)br_modswitch(v);
+    }
+    u32 vb = (u32)c0;
+    if (s0.p) vb += (u32)s0.p * (u32)s0.b[bit * s0.b_stride];
+    if (s1.p) vb += (u32)s1.p * (u32)s1.b[bit * s1.b_stride];
+    const u32 barb = br_modswitch(vb);
+    for (int j = tid; j < 1024; j += THREADS) {
+        const u32 t = ((u32)j + barb) & 2047u;
+#pragma unroll
+        for (int m = 0; m < K; m++) lds.acc[m * 1024 + j] = 0;
+        lds.acc[K * 1024 + j] = (t < 1024u) ? mu : (i32)(0u - (u32)mu);
+    }
+    FftTw2Regs tw2;
+    fft_tw2_load(tw2, lds.tw2, L);
+    WAVE_SYNC();
+    team_sync();
+    for (int i = 0; i < n; i++) {
+        br_pace(lds.pace, (u32)i);
+        const u32 a = WAVE_UNIFORM((u32)lds.bara[i]);
+        if (a == 0) continue;
+        brfr_step<K>(a, bk + (long)i * BK_ROW_POLYS(K) * BKF_POLY_ELEMS, lds, tw2, L, w, team_sync);
+    }
+    br_pace_done(lds.pace);
+    team_sync();
+    for (int j = tid; j < K * 1024; j += THREADS) {
+        const int m = j >> 10, jj = j & 1023;
+        const u32 v = (u32)lds.acc[j];
+        out_a[m * 1024 + ((1024 - jj) & 1023)] = (i32)(jj == 0 ? v : 0u - v);
+    }
+    if (tid == 0) *out_b = lds.acc[K * 1024];
+}

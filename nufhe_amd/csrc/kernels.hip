@@ -531,6 +531,44 @@ __global__ __launch_bounds__(64 * BRF2_WAVES, 1) void k_bootstrap_fft_k2(BrLaunc
     br_extract<2>(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, acc, lane);
 }
 
+// k = 2, FFT, without the partial-sum buffer: 3 waves per bit handing their partial sums round through the exchange
+// buffers (blind_rotate_fft.h, brfr_*), up to 2 teams per work-group.  LDS: tables | pacing / barrier words | per team:
+// ACC 12 KiB, bara 1 KiB, 3 x 2 exchange buffers
+#define FRING2_LDS_BYTES (3 * 1024 * 4 + WAVE_BARA_BYTES + 3 * 2 * WAVE_FXBUF_BYTES)
+#define BRFR_MAX_TEAMS 2
+static_assert(FTABLE_LDS_BYTES + BR_PACE_BYTES + BRFR_MAX_TEAMS * FRING2_LDS_BYTES <= 160 * 1024, "LDS budget of the FFT ring kernel");
+__global__ __launch_bounds__(192 * BRFR_MAX_TEAMS, 2) void k_bootstrap_fft_ring_k2(BrLaunch P)
+{
+    load_ftables((const cplx *)P.tw_a, (const cplx *)P.tw_b);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int team = wave / 3, w = wave - 3 * team;
+    const long gbit = (long)blockIdx.x * (blockDim.x / 192) + team;   // teams per group chosen at launch
+    const BrPace pace = carve_pace(g_smem + FTABLE_LDS_BYTES, wave, gbit < P.nbits_total);
+    if (gbit >= P.nbits_total) return;                                 // (all three waves of the team)
+    const int job = gbit >= P.bits_per_job ? 1 : 0;
+    const long bit = gbit - (job ? P.bits_per_job : 0);
+    unsigned char *base = g_smem + FTABLE_LDS_BYTES + BR_PACE_BYTES + team * FRING2_LDS_BYTES;
+    BrFftRingLds lds;
+    lds.acc = (i32 *)base;
+    lds.bara = (uint16_t *)(base + 3 * 1024 * 4);
+    lds.xbuf_team = (cplx *)(base + 3 * 1024 * 4 + WAVE_BARA_BYTES);
+    lds.tw1 = (const cplx *)g_smem;
+    lds.tw2 = (const cplx *)g_smem + FFT_TW1_ELEMS;
+    lds.pace = pace;
+    u32 *arrive = (u32 *)(g_smem + FTABLE_LDS_BYTES) + 8 + 3 * team;   // team barrier: see k_bootstrap_ring_k2
+    u32 seq = 0;
+    auto team_sync = [&] {
+        seq++;
+        __hip_atomic_store(arrive + w, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int o = 0; o < 3; o++)
+            while ((i32)((u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(arrive + o, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) - seq) < 0)
+                __builtin_amdgcn_s_sleep(1);
+    };
+    const FftLane L = fft_lane_init(lane);
+    brfr_bootstrap<2>(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, P.job[job].s0, P.job[job].s1,
+                      P.job[job].c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, w, team_sync);
+}
+
 // Small-batch variant of the k = 2 FFT path: 3 waves per bit (blind_rotate_fft.h, brftk_*).
 // LDS: tables | ACC 12 KiB | bara 1 KiB | partial sums 72 KiB | 3 x 2 exchange buffers
 #define TEAMF2_LDS_BYTES (FTABLE_LDS_BYTES + 3 * 1024 * 4 + WAVE_BARA_BYTES + BRFTK_PART_ELEMS(2) * 16 + 3 * 2 * WAVE_FXBUF_BYTES)
@@ -1180,6 +1218,9 @@ hipError_t kernels_init_device(int *num_cus)
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap_fft_team_k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAMF2_LDS_BYTES);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_bootstrap_fft_ring_k2, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(FTABLE_LDS_BYTES + BR_PACE_BYTES + BRFR_MAX_TEAMS * FRING2_LDS_BYTES));
+    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap_fft_pair, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(FTABLE_LDS_BYTES + BR_PACE_BYTES + BRFP_MAX_PAIRS * FPAIR_LDS_BYTES));
     if (e != hipSuccess) return e;
@@ -1244,11 +1285,11 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, lon
     if (P.nbits_total == 0) return hipSuccess;
     // defaults of the batch-size switches (negative = default): NTT: team kernel up to 1 x CUs bits, then the pair
     // (k = 1, up to 4 x CUs) / ring (k = 2, any size) kernel; FFT k = 1: pair kernel up to 3 x CUs (team kernel up to
-    // 1 x CUs when the pair switch is 0), k = 2: team kernel up to 2 x CUs (an explicit team value counts half for the FFT
-    // kernels, see nufhe_hip.h)
+    // 1 x CUs when the pair switch is 0), k = 2: team kernel up to 1 x CUs, then the ring kernel (an explicit team value
+    // counts half for the FFT kernels, see nufhe_hip.h)
     if (pair_max_bits < 0) pair_max_bits = (long)BRP_MAX_PAIRS * num_cus;
     if (team_max_bits < 0)
-        team_max_bits = (transform == 0) ? (long)num_cus : (mask_size == 2 ? 4L * num_cus : 2L * num_cus);
+        team_max_bits = (transform == 0) ? (long)num_cus : 2L * num_cus;
     if (transform == 0 && mask_size == 1 && P.nbits_total <= team_max_bits) {
         // small batch: 4 waves per bit, one bit per CU at a time
         hipLaunchKernelGGL(k_bootstrap_team, dim3((unsigned)P.nbits_total), dim3(64 * BRT_WAVES), TEAM_LDS_BYTES, stream, P);
@@ -1313,6 +1354,12 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, lon
     } else if (transform == 1 && mask_size == 2 && P.nbits_total <= team_max_bits / 2) {
         // small batch, FFT, k = 2: 3 waves per bit
         hipLaunchKernelGGL(k_bootstrap_fft_team_k2, dim3((unsigned)P.nbits_total), dim3(64 * 3), TEAMF2_LDS_BYTES, stream, P);
+    } else if (transform == 1 && mask_size == 2 && pair_max_bits > 0) {
+        // k = 2, FFT, beyond the team kernel: 3 waves per bit without the partial-sum buffer, 2 teams per work-group: rounds
+        // of 2 x CUs bits in 4.2 ms (one wave per bit: 4 x CUs in 9.3 ms); any non-zero pair limit enables it
+        const long teams = P.nbits_total > num_cus ? BRFR_MAX_TEAMS : 1;
+        hipLaunchKernelGGL(k_bootstrap_fft_ring_k2, dim3(blocks_for(P.nbits_total, (int)teams)), dim3(192 * (unsigned)teams),
+                           FTABLE_LDS_BYTES + BR_PACE_BYTES + (size_t)teams * FRING2_LDS_BYTES, stream, P);
     } else if (transform == 1 && mask_size == 2) {
         const int w = br_pick_waves(P.nbits_total, BRF2_WAVES, num_cus);
         hipLaunchKernelGGL(k_bootstrap_fft_k2, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w),

@@ -139,7 +139,7 @@ def bkf_from_reference(bk):
     return out
 
 
-def bootstrap_bit_fft(bk_internal, n, src0, p0, src1, p1, c0, mu, team=False, mask_size=1, pair=False):
+def bootstrap_bit_fft(bk_internal, n, src0, p0, src1, p1, c0, mu, team=False, mask_size=1, pair=False, ring=False):
     a0 = numpy.ascontiguousarray(src0[0], numpy.int32); b0 = numpy.ascontiguousarray(src0[1], numpy.int32).reshape(1)
     a1 = numpy.ascontiguousarray(src1[0], numpy.int32); b1 = numpy.ascontiguousarray(src1[1], numpy.int32).reshape(1)
     out_a = numpy.empty(1024 * mask_size, numpy.int32); out_b = numpy.empty(1, numpy.int32)
@@ -148,6 +148,8 @@ def bootstrap_bit_fft(bk_internal, n, src0, p0, src1, p1, c0, mu, team=False, ma
         fn = lib().emu_bootstrap_bit_fft_pair
     if mask_size == 2:
         fn = lib().emu_bootstrap_bit_fft_team_k2 if team else lib().emu_bootstrap_bit_fft_k2
+        if ring:
+            fn = lib().emu_bootstrap_bit_fft_ring_k2
     fn(_p(out_a, c_i32p), _p(out_b, c_i32p), _p(bk_internal.view(numpy.float64), c_f64p),
                                 ctypes.c_int(n), _p(a0, c_i32p), _p(b0, c_i32p), ctypes.c_int32(p0),
                                 _p(a1, c_i32p), _p(b1, c_i32p), ctypes.c_int32(p1),

@@ -340,6 +340,23 @@ void emu_bootstrap_bit_fft_k2(i32 *out_a, i32 *out_b, const double *bk_internal,
     });
 }
 
+// the 3-wave ring variant of the k = 2 FFT body (brfr_*): no partial-sum buffer
+void emu_bootstrap_bit_fft_ring_k2(i32 *out_a, i32 *out_b, const double *bk_internal, int n,
+                                   const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,
+                                   i32 c0, i32 mu)
+{
+    ftables();
+    std::vector<cplx> xbuf(3 * 2 * FFT_XBUF_ELEMS);
+    std::vector<i32> accbuf(3 * 1024);
+    std::vector<uint16_t> bara(BR_MAX_LWE);
+    BrSource s0{a0, b0, 0, 0, p0}, s1{a1, b1, 0, 0, p1};
+    emu_run_team(3, [&](int w, int lane) {
+        BrFftRingLds lds{xbuf.data(), accbuf.data(), bara.data(), g_ftw1, g_ftw2, {nullptr, nullptr}};
+        FftLane L = fft_lane_init(lane);
+        brfr_bootstrap<2>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bk_internal, n, mu, lds, L, w, [] { emu_team_sync(); });
+    });
+}
+
 // the 3-wave team variant of the k = 2 FFT body (brftk_*): 192 fibres
 void emu_bootstrap_bit_fft_team_k2(i32 *out_a, i32 *out_b, const double *bk_internal, int n,
                                    const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,

@@ -232,3 +232,6 @@ def test_bootstrap_wave_body_fft_mask_size_2(orc):
     # the 3-wave team variant (small batches; different fp64 summation order): still the exact result
     ga, gb = emu.bootstrap_bit_fft(bkf, n, (a0, b0), 1, (a1, b1), 1, -MU, MU, mask_size=2, team=True)
     assert (ga == ea[0]).all() and gb == eb[0]
+    # the 3-wave ring variant (no partial-sum buffer, yet another summation order)
+    ga, gb = emu.bootstrap_bit_fft(bkf, n, (a0, b0), 1, (a1, b1), 1, -MU, MU, mask_size=2, ring=True)
+    assert (ga == ea[0]).all() and gb == eb[0]

@@ -329,10 +329,11 @@ def test_gpu_k2_fft_gates_vs_exact_path(k2_fft_env, thr, H, orc, golden_k2, k2_i
                'mux': orc.gate_mux(ck, cs[0], cs[1], cs[2])}
     truth_all = {'nand': ~(msg[0] & msg[1]), 'xor': msg[0] ^ msg[1], 'mux': numpy.where(msg[0], msg[1], msg[2])}
     try:
-        # 0: one wave per bit (k_bootstrap_fft_k2); -1: default switch = 3 waves per bit for 37 / 74 bits
-        # (k_bootstrap_fft_team_k2)
-        for limit in (0, -1):
-            _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, limit)
+        # (team, pair) limits: (0, 0) one wave per bit (k_bootstrap_fft_k2); (0, -1) ring kernel
+        # (k_bootstrap_fft_ring_k2); (-1, -1) default switches = team kernel for 37 / 74 bits (k_bootstrap_fft_team_k2)
+        for limit in ((0, 0), (0, -1), (-1, -1)):
+            _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, limit[0])
+            _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, limit[1])
             for name, got in (('nand', vm.gate_nand(ds[0], ds[1])), ('xor', vm.gate_xor(ds[0], ds[1])),
                               ('mux', vm.gate_mux(ds[0], ds[1], ds[2]))):
                 exp = exp_all[name]
@@ -340,10 +341,43 @@ def test_gpu_k2_fft_gates_vs_exact_path(k2_fft_env, thr, H, orc, golden_k2, k2_i
                 assert dev(ga, exp[0]) <= FFT_TOLERANCE_LSB and dev(gb, exp[1]) <= FFT_TOLERANCE_LSB, (name, limit)
                 assert (gcv == exp[2]).all(), (name, limit)
                 assert (env['ctx'].decrypt(env['sk'], got) == truth_all[name]).all(), (name, limit)
-                print("k=2 FFT %s (team limit %d): words differing from the exact path: %d"
+                print("k=2 FFT %s (team, pair limits %s): words differing from the exact path: %d"
                       % (name, limit, int((ga != exp[0]).sum() + (gb != exp[1]).sum())))
     finally:
         _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, -1)
+        _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, -1)
+
+
+@pytest.mark.gpu
+def test_gpu_k2_fft_ring_kernel_two_teams(k2_fft_env, thr, H, orc):
+    """k = 2, FFT, a batch of 2 x CUs - 5 bits: the ring kernel (2 teams per work-group, ragged last group) vs the
+    one-wave-per-bit kernel on every word and vs the exact oracle on the first 16 bits (tolerance; observed: 0)."""
+    import torch
+    from nufhe_amd import _lib
+    env = k2_fft_env
+    vm = env['vm']; params = env['params']; ck = env['ck']; lwe_key = env['lwe_key']
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    rng = orc.DeterministicRNG(515)
+    B = 2 * cus - 5
+    msg = [rng.uniform_bool((B,)).astype(bool) for _ in range(2)]
+    cs = [orc.encrypt(rng, lwe_key, m, env['oparams']) for m in msg]
+    ds = [H.ciphertext_from_arrays(thr, c, params) for c in cs]
+
+    def dev(x, y):
+        return numpy.abs((x.astype(numpy.int64) - y.astype(numpy.int64) + 2**31) % 2**32 - 2**31).max()
+    try:
+        ring = H.ct_arrays(vm.gate_nand(ds[0], ds[1]))
+        _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, 0)
+        _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, 0)
+        wave = H.ct_arrays(vm.gate_nand(ds[0], ds[1]))
+    finally:
+        _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, -1)
+        _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, -1)
+    assert dev(ring[0], wave[0]) <= FFT_TOLERANCE_LSB and dev(ring[1], wave[1]) <= FFT_TOLERANCE_LSB
+    assert (ring[2] == wave[2]).all()
+    exp = orc.gate('gate_nand', ck, tuple(x[:16] for x in cs[0]), tuple(x[:16] for x in cs[1]))
+    assert dev(ring[0][:16], exp[0]) <= FFT_TOLERANCE_LSB and dev(ring[1][:16], exp[1]) <= FFT_TOLERANCE_LSB
+    print("k=2 FFT ring vs wave kernel, %d bits: differing words: %d" % (B, int((ring[0] != wave[0]).sum() + (ring[1] != wave[1]).sum())))
 
 
 @pytest.mark.gpu
