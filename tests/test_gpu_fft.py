@@ -245,3 +245,26 @@ def test_fft_medium_batch_pair_kernel(fft_env, thr, H, orc):
     finally:
         _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, -1)
         _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, -1)
+
+
+def test_fft_mux_job_boundary_inside_a_multi_pair_group(fft_env, thr, H, orc):
+    """FFT MUX on 301 bits = 602 bootstraps: pair kernel with 3 pairs per work-group, one group straddling the two
+    blind rotations; vs the wave kernel (tolerance; observed identical)."""
+    from nufhe_amd import _lib
+    vm = fft_env['vm']; lwe_key = fft_env['lwe_key']
+    rng = orc.DeterministicRNG(607)
+    B = 301
+    ms = [rng.uniform_bool((B,)).astype(bool) for _ in range(3)]
+    ds = [H.ciphertext_from_arrays(thr, orc.encrypt(rng, lwe_key, m), fft_env['params']) for m in ms]
+    try:
+        pair = H.ct_arrays(vm.gate_mux(ds[0], ds[1], ds[2]))
+        _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, 0)
+        _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, 0)
+        wave = H.ct_arrays(vm.gate_mux(ds[0], ds[1], ds[2]))
+    finally:
+        _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, -1)
+        _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, -1)
+    for x, y in zip(pair[:2], wave[:2]):
+        d = numpy.abs((x.astype(numpy.int64) - y.astype(numpy.int64) + 2**31) % 2**32 - 2**31).max()
+        assert d <= FFT_TOLERANCE_LSB
+    assert (pair[2] == wave[2]).all()

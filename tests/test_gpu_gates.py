@@ -273,6 +273,33 @@ def test_medium_batch_pair_kernel_every_group_size(env, orc):
         _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, -1)
 
 
+def test_mux_job_boundary_inside_a_multi_pair_group(env, orc):
+    """MUX on 301 bits = 602 bootstraps in one launch of the pair kernel with 3 pairs per work-group: one group holds
+    the last bit of the first blind rotation and the first two of the second.  Bit-identical to the wave kernel; first
+    and last 8 bits vs the oracle."""
+    from nufhe_amd import _lib
+    H = env['H']; thr = env['thr']; vm = env['vm']; ck = env['ck']; lwe_key = env['lwe_key']
+    rng = orc.DeterministicRNG(606)
+    B = 301
+    ms = [rng.uniform_bool((B,)).astype(bool) for _ in range(3)]
+    cs = [orc.encrypt(rng, lwe_key, m) for m in ms]
+    ds = [H.ciphertext_from_arrays(thr, c) for c in cs]
+    try:
+        pair = H.ct_arrays(vm.gate_mux(ds[0], ds[1], ds[2]))
+        _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, 0)
+        _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, 0)
+        wave = H.ct_arrays(vm.gate_mux(ds[0], ds[1], ds[2]))
+    finally:
+        _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, -1)
+        _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, -1)
+    for x, y in zip(pair, wave):
+        assert (x == y).all()
+    idx = numpy.r_[0:8, B - 8:B]
+    exp = orc.gate_mux(ck, *[tuple(x[idx] for x in c) for c in cs])
+    for g, e in zip(pair, exp):
+        assert (g[idx] == e).all()
+
+
 def test_profile_clock_of_the_wave_kernel(env, orc):
     """nufhe_profile_clock: the shader clock measured inside a profiled wave-per-bit launch is a plausible MI355X
     clock and the wave's life time is shorter than the launch; small batches (team kernel) report no measurement."""

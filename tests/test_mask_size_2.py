@@ -198,6 +198,29 @@ def test_gpu_k2_large_batch_kernels(k2_env, thr, H, orc):
 
 
 @pytest.mark.gpu
+def test_gpu_k2_mux_job_boundary_inside_a_two_team_group(k2_env, thr, H, orc):
+    """k = 2 MUX on 301 bits = 602 bootstraps through the ring kernel with 2 teams per work-group: one group holds the
+    last bit of the first blind rotation and the first of the second.  Bit-identical to the wave kernels."""
+    from nufhe_amd import _lib
+    vm = k2_env['vm']; lwe_key = k2_env['lwe_key']; params = k2_env['params']
+    rng = orc.DeterministicRNG(608)
+    B = 301
+    ms = [rng.uniform_bool((B,)).astype(bool) for _ in range(3)]
+    ds = [H.ciphertext_from_arrays(thr, orc.encrypt(rng, lwe_key, m, k2_env['oparams']), params) for m in ms]
+    try:
+        ring = H.ct_arrays(vm.gate_mux(ds[0], ds[1], ds[2]))
+        _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, 0)
+        _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, 0)
+        wave = H.ct_arrays(vm.gate_mux(ds[0], ds[1], ds[2]))
+    finally:
+        _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, -1)
+        _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, -1)
+    for x, y in zip(ring, wave):
+        assert (x == y).all()
+    assert (k2_env['ctx'].decrypt(k2_env['sk'], vm.gate_mux(ds[0], ds[1], ds[2])) == numpy.where(ms[0], ms[1], ms[2])).all()
+
+
+@pytest.mark.gpu
 def test_gpu_k2_context_end_to_end(thr):
     """Public API with tlwe_mask_size=2 (test/test_gates.py:96-100): GPU key generation, all binary
     gates + MUX on 64 bits, serialization round trip of the k = 2 cloud key."""
