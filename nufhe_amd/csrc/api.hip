@@ -57,6 +57,7 @@ struct nufhe_ctx {
     Scratch ext_a, ext_b, ks_acc;
     long team_max_bits = -1;   // batches up to this size use the 4-waves-per-bit kernel; -1 = default (launch_bootstrap)
     long pair_max_bits = -1;   // above that and up to this size: the 2-waves-per-bit kernel; -1 = 4 x CUs
+    int ks_mfma = 1;           // keyswitch on the matrix cores (k_keyswitch_mfma): 0 never, 1 batches >= 4 x CUs, 2 always
     bool profile = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
@@ -71,6 +72,7 @@ struct nufhe_cloudkey {
     int ext_size() const { return mask_size * 1024; }
     void *d_bk = nullptr;     // wave layout: u64 [n][8][1024] or complex128 [n][8][512] (same bytes)
     i32 *d_ks_a3 = nullptr;   // [k*1024][8][3][n]
+    signed char *d_ks_planes = nullptr;   // the same key as signed byte planes in MFMA operand order (k_ks_planes)
     i32 *d_ks_b = nullptr;    // [k*1024][8][4]
     float *d_ks_cv = nullptr; // [k*1024][8][4]
     float *d_cv_table = nullptr;   // [k*1024*8 + 1] for uniform-variance keys (KsFinal::cv_table), else NULL
@@ -142,6 +144,9 @@ int run_keyswitch(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result, 
     P.n = key->n;
     P.input_size = key->ext_size();
     P.j_per_block = pick_j_per_block(nbits, P.input_size, ctx->num_cus);
+    // the matrix-core kernel walks the whole key per 64-bit tile (0.31 ms at any size); the LDS-window kernel is ahead
+    // below about 1000 bits (0.08 ms for one bit, 0.36 ms at 1000)
+    P.ks_planes = (ctx->ks_mfma == 2 || (ctx->ks_mfma == 1 && nbits >= 4L * ctx->num_cus)) ? key->d_ks_planes : nullptr;
     KsFinal F;
     F.acc = P.acc;
     F.ks_b = key->d_ks_b; F.ks_cv = key->d_ks_cv;
@@ -335,6 +340,7 @@ int nufhe_cloudkey_destroy(nufhe_cloudkey *key)
     hipStreamSynchronize(key->ctx->stream);
     if (key->d_bk) hipFree(key->d_bk);
     if (key->d_ks_a3) hipFree(key->d_ks_a3);
+    if (key->d_ks_planes) hipFree(key->d_ks_planes);
     if (key->d_ks_b) hipFree(key->d_ks_b);
     if (key->d_ks_cv) hipFree(key->d_ks_cv);
     if (key->d_cv_table) hipFree(key->d_cv_table);
@@ -429,6 +435,16 @@ static int alloc_ks(nufhe_cloudkey *key)
     return NUFHE_OK;
 }
 
+// (re)build the byte planes of the keyswitch key for the matrix-core kernel
+static int build_ks_planes(nufhe_cloudkey *key)
+{
+    nufhe_ctx *ctx = key->ctx;
+    if (key->n > KSM_COLS) return NUFHE_OK;          // wider keys keep the LDS-window kernel
+    if (!key->d_ks_planes) HIP_TRY(hipMalloc((void **)&key->d_ks_planes, ks_planes_bytes(key->ext_size())));
+    HIP_TRY(launch_ks_planes(key->d_ks_planes, key->d_ks_a3, key->ext_size(), key->n, ctx->stream));
+    return NUFHE_OK;
+}
+
 int nufhe_ks_upload(nufhe_cloudkey *key, const int32_t *h_ks_a, const int32_t *h_ks_b, const float *h_ks_cv)
 {
     if (!key || !h_ks_a || !h_ks_b || !h_ks_cv) return fail(NUFHE_EINVAL, "null argument");
@@ -460,6 +476,8 @@ int nufhe_ks_upload(nufhe_cloudkey *key, const int32_t *h_ks_a, const int32_t *h
     HIP_TRY(hipMemcpyAsync(key->d_ks_a3, packed.data(), packed.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(key->d_ks_b, h_ks_b, rows * 4 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(key->d_ks_cv, h_ks_cv, rows * 4 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    rc = build_ks_planes(key);
+    if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return NUFHE_OK;
 }
@@ -479,6 +497,8 @@ int nufhe_ks_make(nufhe_cloudkey *key, const int32_t *d_noises_a, const int32_t 
                            ctx->stream));
     HIP_TRY(launch_ks_make(key->d_ks_b, key->d_ks_cv, key->d_ks_a3, d_noises_b, d_in_key, d_out_key, variance, rows,
                            key->n, ctx->stream));
+    int rcp = build_ks_planes(key);
+    if (rcp) return rcp;
     return set_cv_table(key, variance >= 0.0f, variance);
 }
 
@@ -811,6 +831,15 @@ int nufhe_ctx_set_team_max_bits(nufhe_ctx *ctx, long bits)
     int rc = check_ctx(ctx);
     if (rc) return rc;
     ctx->team_max_bits = bits;
+    return NUFHE_OK;
+}
+
+int nufhe_ctx_set_keyswitch_mfma(nufhe_ctx *ctx, int enable)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (enable < 0 || enable > 2) return fail(NUFHE_EINVAL, "keyswitch mode must be 0, 1 or 2");
+    ctx->ks_mfma = enable;
     return NUFHE_OK;
 }
 

@@ -45,6 +45,8 @@ struct KsLaunch {
     int n;
     int j_per_block;
     int input_size;       // mask_size * 1024
+    // optional: the key as signed byte planes in MFMA operand order (k_ks_planes); non-null selects k_keyswitch_mfma
+    const signed char *ks_planes;
 };
 
 struct KsFinal {
@@ -108,6 +110,10 @@ hipError_t launch_bk_from_reference(u64 *out, const u64 *in, long polys, hipStre
 hipError_t launch_bk_to_reference(u64 *out, const u64 *in, long polys, hipStream_t stream);
 hipError_t launch_bk_from_coeffs(u64 *out, const i32 *in, long polys, const u64 *tw1f, const u64 *tw1i,
                                  hipStream_t stream);
+// byte planes of the keyswitch key for k_keyswitch_mfma: planes[4][input_size][2][KSM_COLS][16]
+#define KSM_COLS 512
+static inline size_t ks_planes_bytes(int input_size) { return (size_t)4 * input_size * 2 * KSM_COLS * 16; }
+hipError_t launch_ks_planes(signed char *planes, const i32 *ks_a3, int input_size, int n, hipStream_t stream);
 hipError_t launch_keyswitch(const KsLaunch &P, const KsFinal &F, hipStream_t stream);
 hipError_t launch_lwe_linear(const LweView &res, const LweView &src, i32 p, int add_result, long nbits, int size,
                              hipStream_t stream);

@@ -1490,10 +1490,187 @@ hipError_t launch_bk_from_coeffs(u64 *out, const i32 *in, long polys, const u64 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// K2 on the matrix cores.  The keyswitch sum is a matrix product: out[bit][c] = - sum_K A[bit][K] B[K][c] with
+// K = (j, k, d), A one-hot in d (the digit k of coefficient j of the bit; digit 0 selects the all-zero row) and B the
+// keyswitch key.  MFMA multiplies int8, so B is split into four signed byte planes, B = sum_p B_p 2^(8p) (balanced
+// digits: exact mod 2^32), each |plane sum| <= 8192 x 128 < 2^21 in the int32 accumulators, and the planes are
+// recombined with shifts at the end: bit-exact, like every integer reformulation of this sum.
+//   v_mfma_i32_16x16x64_i8: lane l holds 16 bytes of A for row l % 16 and of B for column l % 16, both for the
+//   K-slots 16 (l / 16) .. + 15; one instruction = 2 coefficients j: slot = 32 (j & 1) + 4 k + d.  The A operand of a
+//   lane is therefore 4 dwords, each 1 << (8 digit) -- built from the source coefficient with 3 instructions -- and
+//   the B operand one 16-byte load from the plane array laid out for it (k_ks_planes).
+// One wave owns 64 bits x 32 columns x all four planes (128 accumulator registers), a work-group of 4 waves 256 bits of
+// the same columns (the B loads of its waves hit L1).  4096 bits: 256 work-groups x 4 waves, 32 MFMAs per step of 2
+// coefficients.
+// ------------------------------------------------------------------------------------------
+typedef int ksm_v4i __attribute__((ext_vector_type(4)));
+
+// planes[p][j][h][c][16]: byte 4 m + d = plane p of KS[j][4 h + m][d][c] (d = 0 and c >= n: 0)
+__global__ void k_ks_planes(signed char *__restrict__ planes, const i32 *__restrict__ ks_a3, int input_size, int n)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;          // (j, h, c)
+    const long total = (long)input_size * 2 * KSM_COLS;
+    if (idx >= total) return;
+    const int c = (int)(idx % KSM_COLS), h = (int)((idx / KSM_COLS) & 1);
+    const long j = idx / (2 * KSM_COLS);
+    signed char b[4][16];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            i32 v = 0;
+            if (d > 0 && c < n) v = ks_a3[((j * 8 + 4 * h + m) * 3 + (d - 1)) * n + c];
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const signed char s8 = (signed char)(v & 0xFF);      // balanced byte: value in [-128, 127]
+                b[p][4 * m + d] = s8;
+                v = (v - (i32)s8) >> 8;
+            }
+        }
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        ksm_v4i *dst = (ksm_v4i *)(planes + ((((long)p * input_size + j) * 2 + h) * KSM_COLS + c) * 16);
+        *dst = *(const ksm_v4i *)b[p];
+    }
+}
+
+#define NUFHE_KS_MIN_INPUT 1024     /* input sizes are multiples of 1024 (mask_size x N) */
+#define KSM_WAVE_BITS 64
+#define KSM_WAVE_COLS 32
+#define KSM_DEPTH 2
+static_assert((NUFHE_KS_MIN_INPUT / 2) % KSM_DEPTH == 0, "steps must be a multiple of the prefetch depth");
+__global__ __launch_bounds__(256, 1) void k_keyswitch_mfma(KsLaunch P)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const long bit0 = ((long)blockIdx.x * 4 + wave) * KSM_WAVE_BITS;
+    if (bit0 >= P.nbits) return;
+    const int col0 = blockIdx.y * KSM_WAVE_COLS;
+    const int jj = g >> 1, h = g & 1;                 // this lane group's coefficient within the step, half of the digits
+    ksm_v4i acc[4][4][2];
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) acc[p][mt][nt] = ksm_v4i{0, 0, 0, 0};
+    // source rows of this lane: bits bit0 + 16 mt + r (clamped; rows beyond the batch are computed and dropped).  A lane
+    // fetches 8 consecutive coefficients of its rows at a time (2 x 16 bytes: every cache line of the source is requested
+    // 4 times instead of 16) and picks coefficient 2 u + (g >> 1) of the chunk in step u.
+    const i32 *s1[4], *s2[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) {
+        long b = bit0 + 16 * mt + r;
+        if (b >= P.nbits) b = P.nbits - 1;
+        s1[mt] = P.src1_a + b * P.src1_stride;
+        s2[mt] = P.src2_a ? P.src2_a + b * P.src2_stride : nullptr;
+    }
+    const long plane_stride = (long)P.input_size * 2 * KSM_COLS * 16;
+    const signed char *bbase = P.ks_planes + (((long)jj * 2 + h) * KSM_COLS + col0 + r) * 16;
+    constexpr int CH = 4, CQ = CH / 2;                // steps per source chunk (8 coefficients = 2 vectors of 4)
+    auto load_chunk = [&](ksm_v4i (&a)[4][CQ], int chunk) {
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int q = 0; q < CQ; q++) {
+                ksm_v4i v = *(const ksm_v4i *)(s1[mt] + chunk * (2 * CH) + 4 * q);
+                if (s2[mt]) v += *(const ksm_v4i *)(s2[mt] + chunk * (2 * CH) + 4 * q);
+                a[mt][q] = v + (int)(1u << 15);
+            }
+    };
+    auto load_b = [&](ksm_v4i (&bf)[4][2], int s) {
+        const signed char *q = bbase + (long)s * (2 * 2 * KSM_COLS * 16);
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) bf[p][nt] = *(const ksm_v4i *)(q + p * plane_stride + nt * 16 * 16);
+    };
+    const int steps = P.input_size / 2, chunks = steps / CH;
+    // one wave per SIMD (128 accumulator registers): the key loads run KSM_DEPTH steps ahead of the multiplications in
+    // a ring of register slots, the source loads one chunk ahead
+    constexpr int D = KSM_DEPTH;
+    static_assert(CH % D == 0, "the ring must divide a chunk");
+    ksm_v4i bf[D][4][2];
+    ksm_v4i ac[4][CQ], an[4][CQ];
+#pragma unroll
+    for (int u = 0; u < D; u++) load_b(bf[u], u);
+    load_chunk(ac, 0);
+    for (int ch = 0; ch < chunks; ch++) {
+        if (ch + 1 < chunks) load_chunk(an, ch + 1);
+#pragma unroll
+        for (int u8 = 0; u8 < CH; u8++) {
+            const int u = u8 % D, s = ch * CH + u8;
+            ksm_v4i af[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; mt++) {
+                // coefficient 2 u8 + jj of the chunk: element (2 u8 + jj) & 3 of vector (2 u8 + jj) >> 2; jj is 0 or 1
+                const int e = (2 * u8) & 3, q = (2 * u8) >> 2;
+                const u32 v = jj ? (u32)ac[mt][q][e + 1] : (u32)ac[mt][q][e];
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const u32 dgt = (v >> (30 - 2 * (4 * h + m))) & 3u;          // digit k = 4 h + m (lwe_cpu.py:76)
+                    af[mt][m] = (int)(1u << (8 * dgt));
+                }
+            }
+            ksm_v4i bcur[4][2];
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++) bcur[p][nt] = bf[u][p][nt];
+            if (s + D < steps) load_b(bf[u], s + D);
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+#pragma unroll
+                for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+                    for (int nt = 0; nt < 2; nt++)
+                        acc[p][mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[mt], bcur[p][nt], acc[p][mt][nt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int q = 0; q < CQ; q++) ac[mt][q] = an[mt][q];
+    }
+    // C layout: column l % 16, rows 4 (l / 16) + i
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const long bit = bit0 + 16 * mt + 4 * g + i;
+                const int c = col0 + 16 * nt + r;
+                if (bit < P.nbits && c < P.n) {
+                    const u32 total = (u32)acc[0][mt][nt][i] + ((u32)acc[1][mt][nt][i] << 8) + ((u32)acc[2][mt][nt][i] << 16) +
+                                      ((u32)acc[3][mt][nt][i] << 24);
+                    P.acc[bit * P.n + c] = 0u - total;
+                }
+            }
+}
+
+hipError_t launch_ks_planes(signed char *planes, const i32 *ks_a3, int input_size, int n, hipStream_t stream)
+{
+    if (n > KSM_COLS) return hipErrorInvalidValue;
+    const long total = (long)input_size * 2 * KSM_COLS;
+    hipLaunchKernelGGL(k_ks_planes, dim3(blocks_for(total, 256)), dim3(256), 0, stream, planes, ks_a3, input_size, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_keyswitch(const KsLaunch &P, const KsFinal &F, hipStream_t stream)
 {
     if (P.nbits == 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(P.acc, 0, (size_t)P.nbits * P.n * sizeof(u32), stream);
+    hipError_t e;
+    if (P.ks_planes) {
+        // every accumulator word is written exactly once: no zero fill, no atomics
+        const dim3 grid(blocks_for(P.nbits, 4 * KSM_WAVE_BITS), (KSM_COLS + KSM_WAVE_COLS - 1) / KSM_WAVE_COLS);
+        hipLaunchKernelGGL(k_keyswitch_mfma, grid, dim3(256), 0, stream, P);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_keyswitch_finalize, dim3((unsigned)P.nbits), dim3(256), 0, stream, F);
+        return hipGetLastError();
+    }
+    e = hipMemsetAsync(P.acc, 0, (size_t)P.nbits * P.n * sizeof(u32), stream);
     if (e != hipSuccess) return e;
     const dim3 grid(blocks_for(P.nbits, KS_TILE_BITS), P.input_size / P.j_per_block);
     hipLaunchKernelGGL(k_keyswitch_a, grid, dim3(KS_BLOCK_THREADS), KS_LDS_BYTES, stream, P);

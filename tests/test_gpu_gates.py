@@ -300,6 +300,36 @@ def test_mux_job_boundary_inside_a_multi_pair_group(env, orc):
         assert (g[idx] == e).all()
 
 
+def test_keyswitch_on_the_matrix_cores_equals_lds_kernel(env, orc):
+    """The two keyswitch kernels (one-hot int8 MFMA product over byte planes of the key / LDS row gather) give the same
+    ciphertexts word for word, for NAND and for MUX (second source added on the fly), on ragged batches that exercise
+    partly filled 64-bit tiles and 16-bit row groups; both equal the oracle."""
+    from nufhe_amd import _lib
+    H = env['H']; thr = env['thr']; vm = env['vm']; ck = env['ck']; lwe_key = env['lwe_key']
+    rng = orc.DeterministicRNG(4242)
+    B = 333
+    ms = [rng.uniform_bool((B,)).astype(bool) for _ in range(3)]
+    cs = [orc.encrypt(rng, lwe_key, m) for m in ms]
+    ds = [H.ciphertext_from_arrays(thr, c) for c in cs]
+    got = {}
+    try:
+        for mode in (0, 2):
+            _lib.call("nufhe_ctx_set_keyswitch_mfma", thr.handle, mode)
+            got[mode] = [H.ct_arrays(vm.gate_nand(ds[0][:n], ds[1][:n])) for n in (1, 17, 64, 65, B)]
+            got[mode].append(H.ct_arrays(vm.gate_mux(ds[0], ds[1], ds[2])))
+    finally:
+        _lib.call("nufhe_ctx_set_keyswitch_mfma", thr.handle, 1)
+    for a, b in zip(got[0], got[2]):
+        for x, y in zip(a, b):
+            assert (x == y).all()
+    exp = orc.gate('gate_nand', ck, tuple(x[:65] for x in cs[0]), tuple(x[:65] for x in cs[1]))
+    for g, e in zip(got[2][3], exp):
+        assert (g == e).all()
+    exp = orc.gate_mux(ck, *[tuple(x[:40] for x in c) for c in cs])
+    for g, e in zip(got[2][5], exp):
+        assert (g[:40] == e).all()
+
+
 def test_profile_clock_of_the_wave_kernel(env, orc):
     """nufhe_profile_clock: the shader clock measured inside a profiled wave-per-bit launch is a plausible MI355X
     clock and the wave's life time is shorter than the launch; small batches (team kernel) report no measurement."""

@@ -221,6 +221,28 @@ def test_gpu_k2_mux_job_boundary_inside_a_two_team_group(k2_env, thr, H, orc):
 
 
 @pytest.mark.gpu
+def test_gpu_k2_keyswitch_on_the_matrix_cores(k2_env, thr, H, orc):
+    """k = 2 (keyswitch input LWE(2048)): matrix-core keyswitch == LDS-window keyswitch == oracle on a ragged batch."""
+    from nufhe_amd import _lib
+    vm = k2_env['vm']; ck = k2_env['ck']; lwe_key = k2_env['lwe_key']; params = k2_env['params']
+    rng = orc.DeterministicRNG(4243)
+    B = 70
+    ms = [rng.uniform_bool((B,)).astype(bool) for _ in range(2)]
+    cs = [orc.encrypt(rng, lwe_key, m, k2_env['oparams']) for m in ms]
+    ds = [H.ciphertext_from_arrays(thr, c, params) for c in cs]
+    got = {}
+    try:
+        for mode in (0, 2):
+            _lib.call("nufhe_ctx_set_keyswitch_mfma", thr.handle, mode)
+            got[mode] = H.ct_arrays(vm.gate_nand(ds[0], ds[1]))
+    finally:
+        _lib.call("nufhe_ctx_set_keyswitch_mfma", thr.handle, 1)
+    exp = orc.gate('gate_nand', ck, cs[0], cs[1])
+    for x, y, e in zip(got[0], got[2], exp):
+        assert (x == y).all() and (y == e).all()
+
+
+@pytest.mark.gpu
 def test_gpu_k2_context_end_to_end(thr):
     """Public API with tlwe_mask_size=2 (test/test_gates.py:96-100): GPU key generation, all binary
     gates + MUX on 64 bits, serialization round trip of the k = 2 cloud key."""
