@@ -54,7 +54,7 @@ struct nufhe_ctx {
     u64 *d_tw1i = nullptr;
     cplx *d_ftw1 = nullptr;
     cplx *d_ftw2 = nullptr;
-    Scratch ext_a, ext_b, ks_acc;
+    Scratch ext_a, ext_b, ks_acc, ks_digits;
     long team_max_bits = -1;   // batches up to this size use the 4-waves-per-bit kernel; -1 = default (launch_bootstrap)
     long pair_max_bits = -1;   // above that and up to this size: the 2-waves-per-bit kernel; -1 = 4 x CUs
     int ks_mfma = 1;           // keyswitch on the matrix cores (k_keyswitch_mfma): 0 never, 1 batches >= 4 x CUs, 2 always
@@ -147,6 +147,12 @@ int run_keyswitch(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result, 
     // the matrix-core kernel walks the whole key per 64-bit tile (0.31 ms at any size); the LDS-window kernel is ahead
     // below about 1000 bits (0.08 ms for one bit, 0.36 ms at 1000)
     P.ks_planes = (ctx->ks_mfma == 2 || (ctx->ks_mfma == 1 && nbits >= 4L * ctx->num_cus)) ? key->d_ks_planes : nullptr;
+    P.digits_t = nullptr;
+    if (P.ks_planes) {
+        rc = ensure(ctx, ctx->ks_digits, (size_t)P.input_size * ((nbits + 63) & ~63L) * sizeof(unsigned short));
+        if (rc) return rc;
+        P.digits_t = (unsigned short *)ctx->ks_digits.ptr;
+    }
     KsFinal F;
     F.acc = P.acc;
     F.ks_b = key->d_ks_b; F.ks_cv = key->d_ks_cv;
@@ -251,6 +257,7 @@ int nufhe_ctx_destroy(nufhe_ctx *ctx)
     if (ctx->ext_a.ptr) hipFree(ctx->ext_a.ptr);
     if (ctx->ext_b.ptr) hipFree(ctx->ext_b.ptr);
     if (ctx->ks_acc.ptr) hipFree(ctx->ks_acc.ptr);
+    if (ctx->ks_digits.ptr) hipFree(ctx->ks_digits.ptr);
     for (int k = 0; k < 4; k++)
         if (ctx->ev[k]) hipEventDestroy(ctx->ev[k]);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);

@@ -47,6 +47,8 @@ struct KsLaunch {
     int input_size;       // mask_size * 1024
     // optional: the key as signed byte planes in MFMA operand order (k_ks_planes); non-null selects k_keyswitch_mfma
     const signed char *ks_planes;
+    // scratch of k_keyswitch_mfma: the digits of the source, transposed: u16 [input_size][nbits rounded up to 64]
+    unsigned short *digits_t;
 };
 
 struct KsFinal {

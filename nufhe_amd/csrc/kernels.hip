@@ -1535,10 +1535,39 @@ __global__ void k_ks_planes(signed char *__restrict__ planes, const i32 *__restr
     }
 }
 
+// The 8 base-4 digits of a source coefficient are the top 16 bits of a' + 2^15 (lwe_cpu.py:76).  k_keyswitch_mfma
+// wants them by (coefficient, bit) -- 64 consecutive bits of one coefficient are one 128-byte line -- while the
+// extracted samples lie by (bit, coefficient): this pre-pass adds the two sources of a MUX, takes the top half and
+// transposes through LDS (4096 bits: 16 MB in, 8 MB out, a few microseconds).
+__global__ __launch_bounds__(256) void k_ks_digits_t(unsigned short *__restrict__ out, KsLaunch P, long nbits_pad)
+{
+    __shared__ unsigned short tile[64][66];                 // [j][bit], padded
+    const long bit0 = (long)blockIdx.x * 64;
+    const int j0 = blockIdx.y * 64;
+    const int tj = threadIdx.x & 63, tb = threadIdx.x >> 6;  // read: 64 coefficients of a row are contiguous
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int b = tb + 4 * q;
+        u32 v = 0;
+        if (bit0 + b < P.nbits) {
+            v = (u32)P.src1_a[(bit0 + b) * P.src1_stride + j0 + tj];
+            if (P.src2_a) v += (u32)P.src2_a[(bit0 + b) * P.src2_stride + j0 + tj];
+        }
+        tile[tj][b] = (unsigned short)((v + (1u << 15)) >> 16);
+    }
+    __syncthreads();
+    const int ob = threadIdx.x & 63, oj = threadIdx.x >> 6;  // write: 64 bits of a coefficient are contiguous
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int j = oj + 4 * q;
+        out[(long)(j0 + j) * nbits_pad + bit0 + ob] = tile[j][ob];
+    }
+}
+
 #define NUFHE_KS_MIN_INPUT 1024     /* input sizes are multiples of 1024 (mask_size x N) */
 #define KSM_WAVE_BITS 64
 #define KSM_WAVE_COLS 32
-#define KSM_DEPTH 2
+#define KSM_DEPTH 4                 /* 2: L2 latency exposed (K2 0.35 ms); 8: spills (0.43 ms) */
 static_assert((NUFHE_KS_MIN_INPUT / 2) % KSM_DEPTH == 0, "steps must be a multiple of the prefetch depth");
 __global__ __launch_bounds__(256, 1) void k_keyswitch_mfma(KsLaunch P)
 {
@@ -1555,29 +1584,15 @@ __global__ __launch_bounds__(256, 1) void k_keyswitch_mfma(KsLaunch P)
         for (int mt = 0; mt < 4; mt++)
 #pragma unroll
             for (int nt = 0; nt < 2; nt++) acc[p][mt][nt] = ksm_v4i{0, 0, 0, 0};
-    // source rows of this lane: bits bit0 + 16 mt + r (clamped; rows beyond the batch are computed and dropped).  A lane
-    // fetches 8 consecutive coefficients of its rows at a time (2 x 16 bytes: every cache line of the source is requested
-    // 4 times instead of 16) and picks coefficient 2 u + (g >> 1) of the chunk in step u.
-    const i32 *s1[4], *s2[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; mt++) {
-        long b = bit0 + 16 * mt + r;
-        if (b >= P.nbits) b = P.nbits - 1;
-        s1[mt] = P.src1_a + b * P.src1_stride;
-        s2[mt] = P.src2_a ? P.src2_a + b * P.src2_stride : nullptr;
-    }
+    // digits of this lane's rows (bits bit0 + 16 mt + r) for coefficient 2 s + jj of step s, from the transposed array
+    // (k_ks_digits_t): the 64 bits of the wave are one cache line per coefficient
+    const long nbits_pad = (P.nbits + 63) & ~63L;
+    const unsigned short *dsrc = P.digits_t + (long)jj * nbits_pad + bit0 + r;
     const long plane_stride = (long)P.input_size * 2 * KSM_COLS * 16;
     const signed char *bbase = P.ks_planes + (((long)jj * 2 + h) * KSM_COLS + col0 + r) * 16;
-    constexpr int CH = 4, CQ = CH / 2;                // steps per source chunk (8 coefficients = 2 vectors of 4)
-    auto load_chunk = [&](ksm_v4i (&a)[4][CQ], int chunk) {
+    auto load_a = [&](u32 (&aj)[4], int s) {
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-            for (int q = 0; q < CQ; q++) {
-                ksm_v4i v = *(const ksm_v4i *)(s1[mt] + chunk * (2 * CH) + 4 * q);
-                if (s2[mt]) v += *(const ksm_v4i *)(s2[mt] + chunk * (2 * CH) + 4 * q);
-                a[mt][q] = v + (int)(1u << 15);
-            }
+        for (int mt = 0; mt < 4; mt++) aj[mt] = dsrc[(long)(2 * s) * nbits_pad + 16 * mt];
     };
     auto load_b = [&](ksm_v4i (&bf)[4][2], int s) {
         const signed char *q = bbase + (long)s * (2 * 2 * KSM_COLS * 16);
@@ -1586,39 +1601,38 @@ __global__ __launch_bounds__(256, 1) void k_keyswitch_mfma(KsLaunch P)
 #pragma unroll
             for (int nt = 0; nt < 2; nt++) bf[p][nt] = *(const ksm_v4i *)(q + p * plane_stride + nt * 16 * 16);
     };
-    const int steps = P.input_size / 2, chunks = steps / CH;
-    // one wave per SIMD (128 accumulator registers): the key loads run KSM_DEPTH steps ahead of the multiplications in
-    // a ring of register slots, the source loads one chunk ahead
+    const int steps = P.input_size / 2;
+    // one wave per SIMD (128 accumulator registers): the loads run KSM_DEPTH steps ahead of the multiplications in a ring
+    // of register slots
     constexpr int D = KSM_DEPTH;
-    static_assert(CH % D == 0, "the ring must divide a chunk");
+    u32 aj[D][4];
     ksm_v4i bf[D][4][2];
-    ksm_v4i ac[4][CQ], an[4][CQ];
 #pragma unroll
-    for (int u = 0; u < D; u++) load_b(bf[u], u);
-    load_chunk(ac, 0);
-    for (int ch = 0; ch < chunks; ch++) {
-        if (ch + 1 < chunks) load_chunk(an, ch + 1);
+    for (int u = 0; u < D; u++) {
+        load_a(aj[u], u);
+        load_b(bf[u], u);
+    }
+    for (int s0 = 0; s0 < steps; s0 += D) {
 #pragma unroll
-        for (int u8 = 0; u8 < CH; u8++) {
-            const int u = u8 % D, s = ch * CH + u8;
+        for (int u = 0; u < D; u++) {
+            const int s = s0 + u;
             ksm_v4i af[4];
 #pragma unroll
-            for (int mt = 0; mt < 4; mt++) {
-                // coefficient 2 u8 + jj of the chunk: element (2 u8 + jj) & 3 of vector (2 u8 + jj) >> 2; jj is 0 or 1
-                const int e = (2 * u8) & 3, q = (2 * u8) >> 2;
-                const u32 v = jj ? (u32)ac[mt][q][e + 1] : (u32)ac[mt][q][e];
+            for (int mt = 0; mt < 4; mt++)
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
-                    const u32 dgt = (v >> (30 - 2 * (4 * h + m))) & 3u;          // digit k = 4 h + m (lwe_cpu.py:76)
+                    const u32 dgt = (aj[u][mt] >> (14 - 2 * (4 * h + m))) & 3u;     // digit k = 4 h + m (lwe_cpu.py:76)
                     af[mt][m] = (int)(1u << (8 * dgt));
                 }
-            }
             ksm_v4i bcur[4][2];
 #pragma unroll
             for (int p = 0; p < 4; p++)
 #pragma unroll
                 for (int nt = 0; nt < 2; nt++) bcur[p][nt] = bf[u][p][nt];
-            if (s + D < steps) load_b(bf[u], s + D);
+            if (s + D < steps) {
+                load_a(aj[u], s + D);
+                load_b(bf[u], s + D);
+            }
 #pragma unroll
             for (int p = 0; p < 4; p++)
 #pragma unroll
@@ -1627,10 +1641,6 @@ __global__ __launch_bounds__(256, 1) void k_keyswitch_mfma(KsLaunch P)
                     for (int nt = 0; nt < 2; nt++)
                         acc[p][mt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[mt], bcur[p][nt], acc[p][mt][nt], 0, 0, 0);
         }
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-            for (int q = 0; q < CQ; q++) ac[mt][q] = an[mt][q];
     }
     // C layout: column l % 16, rows 4 (l / 16) + i
 #pragma unroll
@@ -1663,6 +1673,9 @@ hipError_t launch_keyswitch(const KsLaunch &P, const KsFinal &F, hipStream_t str
     hipError_t e;
     if (P.ks_planes) {
         // every accumulator word is written exactly once: no zero fill, no atomics
+        const long nbits_pad = (P.nbits + 63) & ~63L;
+        hipLaunchKernelGGL(k_ks_digits_t, dim3(blocks_for(P.nbits, 64), P.input_size / 64), dim3(256), 0, stream, P.digits_t, P,
+                           nbits_pad);
         const dim3 grid(blocks_for(P.nbits, 4 * KSM_WAVE_BITS), (KSM_COLS + KSM_WAVE_COLS - 1) / KSM_WAVE_COLS);
         hipLaunchKernelGGL(k_keyswitch_mfma, grid, dim3(256), 0, stream, P);
         e = hipGetLastError();
