@@ -1519,13 +1519,13 @@ __global__ void k_ks_planes(signed char *__restrict__ planes, const i32 *__restr
     for (int m = 0; m < 4; m++)
 #pragma unroll
         for (int d = 0; d < 4; d++) {
-            i32 v = 0;
-            if (d > 0 && c < n) v = ks_a3[((j * 8 + 4 * h + m) * 3 + (d - 1)) * n + c];
+            u32 v = 0;
+            if (d > 0 && c < n) v = (u32)ks_a3[((j * 8 + 4 * h + m) * 3 + (d - 1)) * n + c];
 #pragma unroll
             for (int p = 0; p < 4; p++) {
-                const signed char s8 = (signed char)(v & 0xFF);      // balanced byte: value in [-128, 127]
+                const signed char s8 = (signed char)(v & 0xFFu);     // balanced byte: value in [-128, 127]
                 b[p][4 * m + d] = s8;
-                v = (v - (i32)s8) >> 8;
+                v = (u32)((i32)(v - (u32)(i32)s8) >> 8);            // (mod 2^32 throughout: the carry out of plane 3 is dropped)
             }
         }
 #pragma unroll
