@@ -168,3 +168,39 @@ def test_tracked_profile_inputs_of_the_bench_roofline_are_current():
     assert 2.0 <= costs['full_rate_cycles'] < costs['half_rate_cycles'] <= 6.0
     for name in ('pmc_NTT.json', 'pmc_FFT.json', 'pmc_traffic.json'):
         assert os.path.isfile(os.path.join(ROOT, 'profiles', name))
+
+
+def test_keyswitch_byte_plane_formulation_is_exact():
+    """The arithmetic behind k_keyswitch_mfma / k_ks_planes (kernels.hip), restated in numpy: the keyswitch sum as a
+    one-hot matrix product against the key split into four balanced signed byte planes, recombined with shifts, equals
+    the direct row gather mod 2^32 -- including key words at the int32 extremes, where the balanced split carries."""
+    rs = numpy.random.RandomState(12)
+    J, n, bits = 16, 24, 20                        # coefficients, output columns, ciphertext bits (reduced sizes)
+    ks = rs.randint(-2**31, 2**31, size=(J, 8, 4, n), dtype=numpy.int64)
+    ks[:, :, 0, :] = 0                             # digit 0 selects the all-zero row (lwe_cpu.py:30-33)
+    ks[0, 0, 1, :6] = [2**31 - 1, -2**31, -1, 127, 128, -129]
+    a = rs.randint(-2**31, 2**31, size=(bits, J), dtype=numpy.int64)
+    ap = (a + 2**15) % 2**32
+    digits = numpy.stack([(ap >> (30 - 2 * k)) & 3 for k in range(8)], axis=-1)          # [bits, J, 8]
+    direct = numpy.zeros((bits, n), numpy.int64)
+    for b in range(bits):
+        for j in range(J):
+            for k in range(8):
+                direct[b] += ks[j, k, digits[b, j, k]]
+    direct = (-direct) % 2**32
+    # balanced byte planes, as k_ks_planes builds them (everything mod 2^32)
+    v = ks % 2**32
+    planes = []
+    for p in range(4):
+        s8 = ((v & 0xFF) ^ 0x80) - 0x80                                                    # sign-extended low byte
+        planes.append(s8)
+        v = (((v - s8) % 2**32) ^ 2**31) - 2**31 >> 8                                      # arithmetic shift of the int32
+        v = v % 2**32
+    assert all(abs(pl).max() <= 128 for pl in planes)
+    onehot = (digits[..., None] == numpy.arange(4)).astype(numpy.int64)                    # [bits, J, 8, 4]
+    total = numpy.zeros((bits, n), numpy.int64)
+    for p, pl in enumerate(planes):
+        cp = numpy.einsum('bjkd,jkdn->bn', onehot, pl)                                     # what the MFMAs accumulate
+        assert abs(cp).max() < 2**21 * (J * 8) // 8192 + 2**12                             # far inside int32
+        total += cp << (8 * p)
+    assert ((-total) % 2**32 == direct).all()
