@@ -217,8 +217,8 @@ int nufhe_ctx_set_team_max_bits(nufhe_ctx *ctx, long bits);
 int nufhe_ctx_set_pair_max_bits(nufhe_ctx *ctx, long bits);
 /* Keyswitch kernel.  The matrix-core kernel writes the digit selection as a one-hot int8 matrix product against the
  * key split into four signed byte planes (v_mfma_i32_16x16x64_i8); the LDS-window kernel gathers key rows by digit.
- * mode 1 (default): matrix cores for batches of at least 4 x CUs bits (0.38 vs 1.15 ms at 4096 bits), the LDS-window
- * kernel below (it is ahead under ~1000 bits); 0: never; 2: always.  Both are exact integer sums mod 2^32:
+ * mode 1 (default): matrix cores for batches of more than 2 x CUs bits (0.30 vs 1.15 ms at 4096 bits), the LDS-window
+ * kernel below (it is ahead up to there); 0: never; 2: always.  Both are exact integer sums mod 2^32:
  * identical results. */
 int nufhe_ctx_set_keyswitch_mfma(nufhe_ctx *ctx, int mode);
 

@@ -57,7 +57,7 @@ struct nufhe_ctx {
     Scratch ext_a, ext_b, ks_acc, ks_digits;
     long team_max_bits = -1;   // batches up to this size use the 4-waves-per-bit kernel; -1 = default (launch_bootstrap)
     long pair_max_bits = -1;   // above that and up to this size: the 2-waves-per-bit kernel; -1 = 4 x CUs
-    int ks_mfma = 1;           // keyswitch on the matrix cores (k_keyswitch_mfma): 0 never, 1 batches >= 4 x CUs, 2 always
+    int ks_mfma = 1;           // keyswitch on the matrix cores (k_keyswitch_mfma): 0 never, 1 batches > 2 x CUs bits, 2 always
     bool profile = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
@@ -144,9 +144,9 @@ int run_keyswitch(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result, 
     P.n = key->n;
     P.input_size = key->ext_size();
     P.j_per_block = pick_j_per_block(nbits, P.input_size, ctx->num_cus);
-    // the matrix-core kernel walks the whole key per 64-bit tile (0.31 ms at any size); the LDS-window kernel is ahead
-    // below about 1000 bits (0.08 ms for one bit, 0.36 ms at 1000)
-    P.ks_planes = (ctx->ks_mfma == 2 || (ctx->ks_mfma == 1 && nbits >= 4L * ctx->num_cus)) ? key->d_ks_planes : nullptr;
+    // the matrix-core kernel walks the whole key per 64-bit tile (0.23 ms at any size up to 1024 bits, 0.30 ms at 4096);
+    // the LDS-window kernel is ahead up to 2 x CUs bits (0.08 ms for one bit, 0.23 ms at 512, 0.34 ms at 768)
+    P.ks_planes = (ctx->ks_mfma == 2 || (ctx->ks_mfma == 1 && nbits > 2L * ctx->num_cus)) ? key->d_ks_planes : nullptr;
     P.digits_t = nullptr;
     if (P.ks_planes) {
         rc = ensure(ctx, ctx->ks_digits, (size_t)P.input_size * ((nbits + 63) & ~63L) * sizeof(unsigned short));
