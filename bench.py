@@ -156,6 +156,33 @@ def cpu_baseline_and_parity(gate, sample_bits, cs_host, gpu_out):
     return base, parity
 
 
+def shard_parity(gate, transform, sample_bits, cs_host, out_host, dist, dev, world):
+    """N > 1: EVERY rank compares the first `sample_bits` ciphertexts of its own shard (its own inputs, its own
+    output of the last timed step) with the CPU oracle and the counts are all-reduced, so that a multi-GPU line
+    carries a parity verdict over all ranks (the N = 1 line compares a larger sample, cpu_baseline_and_parity)."""
+    from oracle import oracle as orc
+    lwe_key, tlwe_key, ck = orc.make_key_pair(orc.DeterministicRNG(123))
+    n = sample_bits
+    cs = [tuple(x[:n] for x in c) for c in cs_host]
+    ref = orc.gate_mux(ck, cs[0], cs[1], cs[2]) if gate == 'mux' else orc.gate('gate_nand', ck, cs[0], cs[1])
+    da = (out_host[0][:n].astype(numpy.int64) - ref[0].astype(numpy.int64) + 2**31) % 2**32 - 2**31
+    db = (out_host[1][:n].astype(numpy.int64) - ref[1].astype(numpy.int64) + 2**31) % 2**32 - 2**31
+    sums = torch.tensor([int((da != 0).sum() + (db != 0).sum()), int(da.size + db.size),
+                         int((out_host[2][:n] != ref[2]).sum()), 1], dtype=torch.int64, device=dev)
+    worst = torch.tensor([int(max(abs(da).max(), abs(db).max()))], dtype=torch.int64, device=dev)
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+    entry = {"bits_per_rank": n, "ranks_reporting": int(sums[3].item()), "words": int(sums[1].item()),
+             "differing": int(sums[0].item()), "variances_differing": int(sums[2].item()),
+             "note": "every rank: first %d ciphertexts of its shard (a[500] and b) vs the CPU oracle on the same inputs, "
+                     "counts all-reduced" % n}
+    if transform != "NTT":
+        entry["max_abs_diff_lsb"] = int(worst.item())
+        entry["tolerance_lsb"] = 16
+    assert entry["ranks_reporting"] == world
+    return entry
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -217,31 +244,56 @@ def main():
     ms = [data_rng.randint(0, 2, size=(B,)).astype(bool) for _ in range(3)]
     ctx.rng = nufhe_amd.DeterministicRNG(1000 + rank)
     cs = [ctx.encrypt(secret_key, m) for m in ms]
-    out = vm.empty_ciphertext((B,))
     from nufhe_amd import multi_gpu
+    # Result buffers.  With a process group: TWO packed buffers (a | b | variances of the slice in one int32
+    # allocation) that alternate, so the gather of step i (ONE RCCL collective, async) overlaps the gate of step i + 1;
+    # a buffer is reused only after the collective that read it has been waited for (examples/multi_gpu.py:104-107 is
+    # the reference's blocking collection of pickled slices).
+    if use_dist:
+        packs = [multi_gpu.PackedCiphertext(cs[0].params, B, thr.device) for _ in range(2)]
+        outs = [p.ciphertext for p in packs]
+        recv = [torch.empty(world * B * (cs[0].params.size + 2), dtype=torch.int32, device=thr.device)
+                if rank == 0 and dist.get_backend() == "nccl" else None for _ in range(2)]
+    else:
+        packs, recv = None, None
+        outs = [vm.empty_ciphertext((B,))]
+    pending = [None, None]
+    step_no = [0]
 
     def step():
+        k = step_no[0] % len(outs)
+        step_no[0] += 1
+        if pending[k] is not None:
+            pending[k].wait(unpack=False)        # orders this stream behind the collective that read buffer k
+            pending[k] = None
         if args.gate == "mux":
-            vm.gate_mux(cs[0], cs[1], cs[2], dest=out)
+            vm.gate_mux(cs[0], cs[1], cs[2], dest=outs[k])
         else:
-            vm.gate_nand(cs[0], cs[1], dest=out)
+            vm.gate_nand(cs[0], cs[1], dest=outs[k])
         if use_dist:
-            # the result gather of examples/multi_gpu.py:104-107: every rank's slice goes to rank 0
-            # (one RCCL gather per array; 2008 bytes per bit cross xGMI once)
-            multi_gpu.gather_ciphertext(out, world * B, dst=0)
+            pending[k] = multi_gpu.gather_packed_async(packs[k], world * B, dst=0, recv=recv[k])
+        return k
+
+    def drain():
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k].wait(unpack=False)
+                pending[k] = None
 
     import ctypes
     lib = _lib.lib()
     for _ in range(args.warmup):
         step()
+    drain()
     lib.nufhe_profile_enable(thr.handle, 1)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     br_ms, ks_ms, clock_ghz, wave_ms = [], [], [], []
     t0 = time.perf_counter()
+    last = 0
     for _ in range(args.steps):
-        step()
+        last = step()
         if rank == 0:
             # HIP-event timing of the kernels of this step (events recorded on the launch stream)
             a = ctypes.c_float(); b = ctypes.c_float()
@@ -250,6 +302,7 @@ def main():
             g = ctypes.c_double(); w = ctypes.c_double()
             if lib.nufhe_profile_clock(thr.handle, ctypes.byref(g), ctypes.byref(w)) == 0:
                 clock_ghz.append(g.value); wave_ms.append(w.value)
+    drain()                                         # every gather of the timed steps completes inside the timed region
     torch.cuda.synchronize()
     own_elapsed = time.perf_counter() - t0          # this rank alone (a straggler shows up here)
     if use_dist:
@@ -269,18 +322,19 @@ def main():
     # the result gather alone (reported separately; it is also part of every timed step)
     gather_ms = None
     gathered_ok = None
+    out = outs[last]                                # the result of the last timed step
     if use_dist:
-        full = multi_gpu.gather_ciphertext(out, world * B, dst=0)
+        full = multi_gpu.gather_packed_async(packs[last], world * B, dst=0).wait()
         torch.cuda.synchronize(); dist.barrier()
         t1 = time.perf_counter()
         for _ in range(5):
-            multi_gpu.gather_ciphertext(out, world * B, dst=0)
+            multi_gpu.gather_packed_async(packs[last], world * B, dst=0, recv=recv[last]).wait(unpack=False)
         torch.cuda.synchronize(); dist.barrier()
         gather_ms = 1e3 * (time.perf_counter() - t1) / 5
         if rank == 0:
             # rank 0's own slice must sit at the head of the gathered arrays
             gathered_ok = bool((full[0][:B] == out.a).all() and (full[1][:B] == out.b).all()
-                               and full[0].shape[0] == world * B)
+                               and (full[2][:B] == out.current_variances).all() and full[0].shape[0] == world * B)
 
     # secondary measurements, OUTSIDE the timed region: the other BASELINE configurations on the same
     # ciphertexts (3 steps each after 1 warm-up); reported under "other_configs", never in "value"
@@ -352,10 +406,22 @@ def main():
                 "scaled_ms_per_bit": 1e3 * (m1 - m2) / (B - B // 2),
                 "fixed_overhead_ms": 1e3 * (m1 - (m1 - m2) / (B - B // 2) * B)}
 
-    # correctness of what was timed: every decrypted bit equals the truth table
+    # correctness of what was timed: every decrypted bit equals the truth table -- on EVERY rank (each rank holds
+    # the secret key of the shared seed and its own plaintexts); the verdicts are combined below
     dec = ctx.decrypt(secret_key, out)
     expect = numpy.where(ms[0], ms[1], ms[2]) if args.gate == "mux" else ~(ms[0] & ms[1])
     correct = bool((dec == expect).all())
+    multi_parity = None
+    if use_dist:
+        dev = thr.device if dist.get_backend() == "nccl" else "cpu"
+        okt = torch.tensor([1 if correct else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        correct = bool(okt.item())
+        if world > 1 and not args.no_cpu_baseline:
+            def host_(ct):
+                return tuple(x.detach().cpu().numpy() for x in (ct.a, ct.b, ct.current_variances))
+            multi_parity = shard_parity(args.gate, args.transform, min(B, 32), [host_(c) for c in cs], host_(out),
+                                        dist, dev, world)
 
     if rank == 0:
         total_bits = world * B * args.steps
@@ -413,7 +479,20 @@ def main():
         if gather_ms is not None:
             result["gather_ms"] = gather_ms
             result["gather_bytes_per_rank"] = B * 2008
-            result["gather"] = {"backend": dist.get_backend(), "dst": 0, "verified": gathered_ok}
+            result["gather"] = {"backend": dist.get_backend(), "dst": 0, "verified": gathered_ok,
+                                "collectives_per_step": 1, "overlapped": True,
+                                "note": "a | b | variances of a slice share one buffer: ONE gather per step, started "
+                                        "async after the gate and overlapped with the next gate (two result buffers "
+                                        "alternate); every gather of the timed steps completes inside the timed region; "
+                                        "gather_ms = the same collective alone, blocking"}
+        if multi_parity is not None:
+            result["parity"] = multi_parity
+            bad_multi = (multi_parity["differing"] != 0 if args.transform == "NTT"
+                         else multi_parity["max_abs_diff_lsb"] > multi_parity["tolerance_lsb"])
+            result["correct"] = bool(result["correct"] and not bad_multi)
+        if world > 1:
+            result["config"]["note"] = ("weak scaling: %d bits per GPU; config 4 (32768 bits over 8 GPUs) is this line at "
+                                        "N = 8 -- the same run read as a strong-scaling split of 32768 bits" % B)
         if other:
             result["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:

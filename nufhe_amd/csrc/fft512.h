@@ -252,9 +252,12 @@ FF_FN void fft_inverse(cplx (&x)[8], cplx *xbuf, const cplx *tw1, const cplx *tw
 extern double g_emu_fft_max_frac, g_emu_fft_max_abs;
 #endif
 
-// round-to-nearest-even to the low 32 bits (two's complement), valid for |v| < 2^51
-// (fft.mako:272-277: round -> int64 -> truncate to int32).  The products of the blind rotation stay
-// below 2^52 in the worst case and below ~2^46 on real keys.
+// round-to-nearest-even, then the low 32 bits of the two's-complement integer: the reference's
+// round -> int64 -> truncate to int32 (fft.mako:272-277), for every |v| <= 2^52 -- the largest magnitude the
+// blind rotation can produce (4 digit polynomials x 1024 terms x 2^9 x 2^31).  The magnitude
+// takes the magic add (|v| + 2^52 lies in [2^52, 2^53], where the spacing of doubles is exactly 1 and the low
+// mantissa bits ARE the integer; a signed v + 1.5 * 2^52 would leave that binade from |v| = 2^51 on), the sign
+// is put back on the 32-bit result (round-half-even is symmetric).
 FF_FN u32 fft_round_to_u32(double v)
 {
 #if defined(NUFHE_EMU)
@@ -264,10 +267,13 @@ FF_FN u32 fft_round_to_u32(double v)
         if (fabs(v) > g_emu_fft_max_abs) g_emu_fft_max_abs = fabs(v);
     }
 #endif
-    const double magic = 6755399441055744.0;   // 1.5 * 2^52
-    union { double d; u64 u; } c;
-    c.d = v + magic;
-    return (u32)c.u;
+    const double magic = 4503599627370496.0;   // 2^52
+    union { double d; u64 u; } c, s;
+    c.d = fabs(v) + magic;
+    s.d = v;
+    const u32 r = (u32)c.u;
+    const u32 m = (u32)((i32)(u32)(s.u >> 32) >> 31);     // 0 or 0xFFFFFFFF
+    return (r ^ m) - m;
 }
 
 // host-side table construction (w = exp(-i pi / 1024))

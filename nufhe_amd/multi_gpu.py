@@ -5,8 +5,16 @@ which ships pickled slices between Python threads through host memory).
 One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on GPUs, "gloo" in the CPU
 tests).  The batch is cut into contiguous per-rank slices, the cloud key is replicated, every rank
 runs its gates locally with no data-path collective, and the only communication is the result
-gather to one rank (RCCL gather = grouped send/recv over xGMI).  The functions below contain no device-specific code: they work on whatever tensors
-(``a``, ``b``, ``current_variances``) they are given.
+gather to one rank (RCCL gather = grouped send/recv over xGMI).
+
+Two forms of that gather:
+  * ``gather_arrays`` / ``gather_ciphertext``: one blocking collective per array (a, b, variances);
+  * ``PackedCiphertext`` + ``gather_packed_async``: the three arrays of a result are views of ONE
+    int32 buffer (2008 bytes per bit), so a step is one collective, started with ``async_op=True``:
+    RCCL runs it on its own stream after the gate that produced the buffer and the next gate
+    overlaps it.  Two such buffers alternate (``bench.py``); ``AsyncGather.wait`` orders the
+    caller's stream behind the collective before a buffer is reused.
+The functions contain no device-specific code: they work on whatever tensors they are given.
 """
 
 import torch
@@ -29,19 +37,45 @@ def shard_ciphertext(ciphertext, world_size: int, rank: int):
     return ciphertext[lo:hi]
 
 
+def _group_info(group, dst):
+    """(world, group-local rank, group-local dst, global dst).  ``dst`` is GROUP-LOCAL everywhere in
+    this module (rank order inside the group = slice order); torch's collectives want the global
+    rank, so it is translated here once."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if dst is None:
+        return world, rank, None, None
+    if not (0 <= dst < world):
+        raise ValueError("dst %d out of range [0, %d)" % (dst, world))
+    global_dst = dist.get_global_rank(group, dst) if group is not None else dst
+    return world, rank, dst, global_dst
+
+
+def _unpad(full, nbits, world, cap):
+    """[world * cap, ...] gathered with ragged slices padded to ``cap`` -> [nbits, ...] in rank order"""
+    if nbits == world * cap:
+        return full
+    pieces = []
+    for r in range(world):
+        l, h = shard_bounds(nbits, world, r)
+        pieces.append(full[r * cap:r * cap + (h - l)])
+    return torch.cat(pieces, dim=0)
+
+
 def gather_arrays(local_tensors, nbits: int, group=None, dst=0):
     """
     Collects per-rank result slices (first axis = bits, possibly ragged by one) into full arrays, in
     rank order.  ``local_tensors`` is a tuple such as (a [b_r, n], b [b_r], cv [b_r]).
 
-    ``dst`` = rank that receives the result (default 0, the reference's main thread collecting the
-    slices, examples/multi_gpu.py:104-107): returns a tuple of full tensors [nbits, ...] there and None
-    on the other ranks -- every rank sends its 2008 bytes per bit exactly once.  ``dst=None`` gathers on
-    every rank (world_size times the traffic; for callers that continue a circuit on all ranks).
+    ``dst`` = group-local rank that receives the result (default 0, the reference's main thread
+    collecting the slices, examples/multi_gpu.py:104-107): returns a tuple of full tensors
+    [nbits, ...] there and None on the other ranks -- every rank sends its 2008 bytes per bit exactly
+    once.  ``dst=None`` gathers on every rank (world_size times the traffic; for callers that
+    continue a circuit on all ranks).
     """
     import torch.distributed as dist
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+    world, rank, dst, global_dst = _group_info(group, dst)
     base, extra = divmod(nbits, world)
     cap = base + (1 if extra else 0)
     lo, hi = shard_bounds(nbits, world, rank)
@@ -64,18 +98,13 @@ def gather_arrays(local_tensors, nbits: int, group=None, dst=0):
             dist.all_gather_into_tensor(full, send, group=group)
         elif rank == dst:
             full = torch.empty((world * cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=send.device)
-            dist.gather(send, list(full.split(cap, dim=0)), dst=dst, group=group)
+            dist.gather(send, list(full.split(cap, dim=0)), dst=global_dst, group=group)
         else:
-            dist.gather(send, None, dst=dst, group=group)
+            dist.gather(send, None, dst=global_dst, group=group)
         if full is not None:
             if stage:
                 full = full.to(t.device)
-            if extra:
-                pieces = []
-                for r in range(world):
-                    l, h = shard_bounds(nbits, world, r)
-                    pieces.append(full[r * cap:r * cap + (h - l)])
-                full = torch.cat(pieces, dim=0)
+            full = _unpad(full, nbits, world, cap)
         out.append(full)
     if dst is not None and rank != dst:
         return None
@@ -86,3 +115,120 @@ def gather_ciphertext(local_ct, nbits: int, group=None, dst=0):
     """Collects an LweSampleArray's slices; returns (a, b, current_variances) full tensors on ``dst``
     (every rank for ``dst=None``), None elsewhere."""
     return gather_arrays((local_ct.a, local_ct.b, local_ct.current_variances), nbits, group=group, dst=dst)
+
+
+# ----------------------------------------------------------------------------------------------
+# One buffer per result: a | b | variances as views of a single int32 allocation
+# ----------------------------------------------------------------------------------------------
+
+class PackedCiphertext:
+    """
+    Storage of one rank's result slice laid out for a single collective: an int32 buffer of
+    ``capacity * (n + 2)`` words = ``a [capacity, n] | b [capacity] | variances [capacity]`` (the
+    variances are float32 seen through an int32 view; same bytes).  ``ciphertext`` is an
+    LweSampleArray over the first ``nbits`` rows -- pass it as ``dest=`` to a gate.
+    ``capacity`` >= nbits is the common slice size of a ragged batch (the padding rows travel as
+    zeros).
+    """
+
+    def __init__(self, params, nbits: int, device, capacity=None, sample_array_class=None):
+        n = params.size
+        capacity = nbits if capacity is None else capacity
+        if capacity < nbits:
+            raise ValueError("capacity %d < nbits %d" % (capacity, nbits))
+        self.n = n
+        self.nbits = nbits
+        self.capacity = capacity
+        self.flat = torch.zeros(capacity * (n + 2), dtype=torch.int32, device=device)
+        a, b, cv = unpack_views(self.flat, capacity, n)
+        if sample_array_class is None:
+            from .lwe import LweSampleArray as sample_array_class
+        self.ciphertext = sample_array_class(params, a[:nbits], b[:nbits], cv[:nbits])
+
+
+def unpack_views(flat, capacity: int, n: int):
+    """(a [capacity, n], b [capacity], variances [capacity] float32) views of one packed block"""
+    a = flat[:capacity * n].view(capacity, n)
+    b = flat[capacity * n:capacity * (n + 1)]
+    cv = flat[capacity * (n + 1):capacity * (n + 2)].view(torch.float32)
+    return a, b, cv
+
+
+class AsyncGather:
+    """Handle of a gather started by ``gather_packed_async``.
+
+    ``wait()`` makes the caller's current stream wait for the collective (device-side for RCCL, so
+    the host does not block) and returns, on the destination rank, (a, b, variances) full tensors
+    [nbits_total, ...] in rank order -- views of the receive buffer when the batch divides evenly;
+    None on the other ranks."""
+
+    def __init__(self, work, recv, keep, world, cap, n, nbits_total, device, is_dst):
+        self._work, self._recv, self._keep = work, recv, keep
+        self._world, self._cap, self._n, self._nbits = world, cap, n, nbits_total
+        self._device, self._is_dst = device, is_dst
+        self._result = None
+        self._done = False
+
+    def wait(self, unpack=True):
+        """``unpack=False``: only order the stream behind the collective (the send buffer may be reused)"""
+        if not self._done:
+            if self._work is not None:
+                self._work.wait()
+            self._done = True
+            self._keep = None
+        if unpack and self._result is None and self._is_dst:
+            recv = self._recv if self._recv.device == self._device else self._recv.to(self._device)
+            blocks = recv.view(self._world, self._cap * (self._n + 2))
+            parts = [unpack_views(blocks[r], self._cap, self._n) for r in range(self._world)]
+            if self._nbits == self._world * self._cap and self._world == 1:
+                self._result = parts[0]
+            else:
+                res = []
+                for k in range(3):
+                    pieces = []
+                    for r in range(self._world):
+                        l, h = shard_bounds(self._nbits, self._world, r)
+                        pieces.append(parts[r][k][:h - l])
+                    res.append(torch.cat(pieces, dim=0))
+                self._result = tuple(res)
+        return self._result
+
+
+def gather_packed_async(packed: PackedCiphertext, nbits_total: int, group=None, dst=0, recv=None):
+    """
+    Starts the gather of every rank's PackedCiphertext to group-local rank ``dst`` as ONE collective
+    (``async_op=True``) and returns an :class:`AsyncGather`.  All ranks must use the same
+    ``capacity`` = ceil(nbits_total / world).  ``recv`` (destination rank only) lets the caller
+    reuse a receive buffer of ``world * capacity * (n + 2)`` int32 words.
+
+    RCCL orders the collective behind the work already queued on the current stream (the gate that
+    fills ``packed``) and runs it on its own stream; whatever the caller queues next overlaps it.
+    The caller must not overwrite ``packed`` before ``wait()``.
+    """
+    import torch.distributed as dist
+    world, rank, dst, global_dst = _group_info(group, dst)
+    if dst is None:
+        raise ValueError("the packed gather has one destination; use gather_arrays(dst=None) to gather everywhere")
+    cap = -(-nbits_total // world)
+    if packed.capacity != cap:
+        raise ValueError("packed capacity %d, expected ceil(%d / %d) = %d" % (packed.capacity, nbits_total, world, cap))
+    lo, hi = shard_bounds(nbits_total, world, rank)
+    if packed.nbits != hi - lo:
+        raise ValueError("local slice has %d bits, expected %d" % (packed.nbits, hi - lo))
+    send = packed.flat
+    device = send.device
+    stage = dist.get_backend(group) == 'gloo' and send.is_cuda      # test-only route: through the host
+    if stage:
+        send = send.cpu()
+    words = cap * (packed.n + 2)
+    is_dst = rank == dst
+    if is_dst:
+        if recv is None or stage:
+            recv = torch.empty(world * words, dtype=torch.int32, device=send.device)
+        elif recv.numel() != world * words or recv.dtype != torch.int32:
+            raise ValueError("receive buffer must hold %d int32 words" % (world * words))
+        work = dist.gather(send, list(recv.split(words)), dst=global_dst, group=group, async_op=True)
+    else:
+        recv = None
+        work = dist.gather(send, None, dst=global_dst, group=group, async_op=True)
+    return AsyncGather(work, recv, send, world, cap, packed.n, nbits_total, device, is_dst)

@@ -163,3 +163,10 @@ def fft_margin():
     a = ctypes.c_double(); b = ctypes.c_double()
     lib().emu_fft_margin(ctypes.byref(a), ctypes.byref(b))
     return a.value, b.value
+
+
+def fft_round(v):
+    v = numpy.ascontiguousarray(v, numpy.float64)
+    r = numpy.empty(v.shape, numpy.uint32)
+    lib().emu_fft_round(_p(r, c_u32p), v.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ctypes.c_long(v.size))
+    return r

@@ -239,6 +239,12 @@ void emu_fft_margin(double *max_frac, double *max_abs)
     g_emu_fft_max_frac = 0.0; g_emu_fft_max_abs = 0.0;
 }
 
+// the final rounding of the FFT path as compiled from fft512.h
+void emu_fft_round(uint32_t *out, const double *in, long n)
+{
+    for (long i = 0; i < n; i++) out[i] = fft_round_to_u32(in[i]);
+}
+
 static cplx g_ftw1[FFT_TW1_ELEMS], g_ftw2[FFT_TW2_ELEMS];
 static bool g_ftables = false;
 static void ftables() { if (!g_ftables) { fft_make_tables(g_ftw1, g_ftw2); g_ftables = true; } }

@@ -136,6 +136,30 @@ def test_fft_forward_inverse_vs_numpy():
 
 
 @pytest.mark.slow
+def test_fft_final_rounding_matches_reference_semantics_up_to_2_52():
+    """fft_round_to_u32 (fft512.h) == round-half-even -> int64 -> low 32 bits (transform/fft.mako:272-277) on the whole
+    range the blind rotation can reach, |v| <= 2^52: both signs, ties, the binade edges 2^51 and 2^52 where a signed
+    magic-number add stops working."""
+    rs = numpy.random.RandomState(7)
+    vals = [0.0, -0.0, 0.5, -0.5, 1.5, -1.5, 2.5, -2.5, 2.0**31, -2.0**31, 2.0**32 - 0.5, -(2.0**32) + 0.5,
+            2.0**51, -(2.0**51), 2.0**51 + 1, -(2.0**51) - 1, 2.0**52 - 1, -(2.0**52) + 1, 2.0**52, -(2.0**52),
+            2.0**51 - 0.5, -(2.0**51) + 0.5]
+    for e in range(1, 53):
+        m = rs.randint(0, 2**31, size=200).astype(numpy.float64) * 2.0**21 + rs.randint(0, 2**21, size=200)   # 52 bits
+        v = numpy.ldexp(m, e - 52)
+        vals.extend(v.tolist()); vals.extend((-v).tolist())
+        k = numpy.floor(numpy.ldexp(rs.rand(50), min(e, 50))) + 0.5                                           # ties
+        vals.extend(k.tolist()); vals.extend((-k).tolist())
+    top = 2.0**51 + numpy.floor(rs.rand(2000) * 2.0**51)              # the binade [2^51, 2^52): integers only
+    vals.extend(top.tolist()); vals.extend((-top).tolist())
+    v = numpy.array(vals, numpy.float64)
+    v = v[numpy.abs(v) <= 2.0**52]
+    assert (numpy.abs(v) >= 2.0**51).sum() > 500
+    expect = (numpy.rint(v).astype(numpy.int64) & 0xFFFFFFFF).astype(numpy.uint32)
+    got = emu.fft_round(v)
+    assert (got == expect).all(), v[got != expect][:5]
+
+
 def test_bootstrap_wave_body_fft_full_key(orc, oracle_keys):
     """FFT variant of the fused body on the full-size key, one bit: equals the EXACT (NTT) oracle --
     the fp64 rounding error stays below 0.5 LSB (FFT tolerance statement)."""

@@ -115,6 +115,78 @@ def test_fft_external_mul_vs_reference_golden(thr, H, golden, orc):
     assert numpy.abs(d2).max() <= 1 and (d2 != 0).mean() <= 1e-4
 
 
+def _exact_external_mul(accum, tgsw, row):
+    """exact negacyclic external product mod 2^32 in integer arithmetic (tgsw_cpu.py:26-106 semantics)"""
+    a = accum.astype(numpy.int64)
+    t = (a + 0x80200000) & 0xFFFFFFFF
+    out = numpy.zeros_like(a)
+    idx = numpy.arange(1024)
+    for b in range(a.shape[0]):
+        for m in range(2):
+            for d in range(2):
+                dg = ((t[b, m] >> (32 - 10 * (d + 1))) & 1023) - 512
+                for mo in range(2):
+                    key = tgsw[row, m, d, mo].astype(numpy.int64)
+                    full = numpy.convolve(dg, key)                   # |terms| <= 2^40, 1024 of them: fits int64
+                    neg = full[:1024].copy()
+                    neg[:1023] -= full[1024:]
+                    out[b, mo] += neg
+    return out
+
+
+def test_fft_external_mul_at_the_largest_reachable_magnitude(thr, H):
+    """The final rounding of the FFT path at the edge of its domain: a TGSW row whose
+    coefficients are all +-2^31-ish, sign-aligned with accumulators whose gadget digits are all -512 or +511, drives
+    the values handed to `round` up to 4 x 1024 x 2^9 x 2^31 = 2^52 -- beyond 2^51, where a signed magic-number
+    add leaves its binade.  fft_round_to_u32 rounds the MAGNITUDE, so it follows the reference's
+    round -> int64 -> truncate (transform/fft.mako:272-277) on the whole reachable range; what is left is the fp64
+    error of the transforms themselves, ~2^-50 relative: at |v| ~ 2^52 that is a few units, and the tolerance
+    stated for the path (2^4 LSB) is asserted here exactly where it is hardest to meet."""
+    from oracle import oracle_fft as of
+    rs = numpy.random.RandomState(77)
+    B = 4
+    # digits: t + OFFSET has all decomposition bits 0 (digits -512, -512) or all 1 (digits 511, 511)
+    lo_t = numpy.uint32(0x100000000 - 0x80200000)                 # t + 0x80200000 = 0 (mod 2^32)
+    hi_t = numpy.uint32((0xFFFFF000 - 0x80200000) & 0xFFFFFFFF)   # t + 0x80200000 = 0xFFFFF000
+    accum = numpy.empty((B, 2, 1024), numpy.uint32)
+    tgsw = numpy.empty((1, 2, 2, 2, 1024), numpy.int32)
+    # bit 0: everything at the extreme, constant sign: coefficient 1023 of every output reaches -/+ 2^52
+    accum[0] = lo_t
+    # bit 1: digits +511
+    accum[1] = hi_t
+    # bits 2, 3: random choice of the two extremes per coefficient
+    accum[2:] = numpy.where(rs.randint(0, 2, size=(2, 2, 1024)).astype(bool), lo_t, hi_t)
+    accum += rs.randint(0, 0x1000, size=accum.shape).astype(numpy.uint32)      # low 12 bits do not reach a digit
+    tgsw[:] = -2**31
+    tgsw[0, :, :, 1] = 2**31 - 1
+    tgsw[0, 1, 1, :, ::2] = rs.choice([-2**31, 2**31 - 1], size=(2, 512))
+    accum = accum.view(numpy.int32)
+    exact = _exact_external_mul(accum, tgsw, 0)
+    assert numpy.abs(exact).max() >= 1.5 * 2**51 and (numpy.abs(exact) >= 2**51).sum() > 1000
+    expect = (exact & 0xFFFFFFFF).astype(numpy.uint32)
+
+    from nufhe_amd.bootstrap import NativeCloudKey
+    native = NativeCloudKey(thr, 1, 'FFT')
+    d_tgsw = H.dev(thr, tgsw)
+    call("nufhe_bk_from_coeffs", native.handle, ptr(d_tgsw))
+    acc = H.dev(thr, accum.reshape(B, 1, 2, 1024).copy())
+    call("nufhe_external_mul", thr.handle, native.handle, ptr(acc), 0, B)      # the accumulator becomes the product
+    got = H.host(acc).reshape(B, 2, 1024).view(numpy.uint32)
+    delta = (got.astype(numpy.int64) - expect.astype(numpy.int64) + 2**31) % 2**32 - 2**31
+    big = numpy.abs(exact) >= 2**51
+    print("FFT external product at |v| up to 2^%.2f: max |delta| %d LSB overall, %d LSB where |v| >= 2^51 (%d values), "
+          "%d of %d words differ" % (numpy.log2(float(numpy.abs(exact).max())), numpy.abs(delta).max(),
+                                     numpy.abs(delta[big]).max(), int(big.sum()), int((delta != 0).sum()), delta.size))
+    assert numpy.abs(delta).max() <= FFT_TOLERANCE_LSB
+    # the reference's own FFT formulation (numpy fft, round -> int64 -> truncate) on the same inputs stays within
+    # the same tolerance of the exact product: the deviation is the transforms' rounding, not the final conversion
+    bkf = of.bk_from_coeffs(tgsw)
+    ref = numpy.array([of.external_mul(accum[b].copy(), bkf, 0) for b in range(B)]).astype(numpy.int32).view(numpy.uint32)
+    dref = (ref.astype(numpy.int64) - expect.astype(numpy.int64) + 2**31) % 2**32 - 2**31
+    print("oracle_fft (numpy) on the same inputs: max |delta| %d LSB" % numpy.abs(dref).max())
+    assert numpy.abs(dref).max() <= 4 * FFT_TOLERANCE_LSB
+
+
 @pytest.fixture(scope='module')
 def fft_env(thr, H, orc, oracle_keys):
     import nufhe_amd

@@ -62,6 +62,104 @@ def _worker(rank, world, port, nbits, results):
     dist.destroy_process_group()
 
 
+class _Params:
+    size = 500
+
+
+class _Ct:
+    def __init__(self, params, a, b, cv):
+        self.params, self.a, self.b, self.current_variances = params, a, b, cv
+
+
+def _packed_worker(rank, world, port, nbits, results):
+    """the one-collective, asynchronous gather of bench.py / examples/multi_gpu.py: two result buffers in
+    flight, each filled by a stand-in gate, gathered to rank 0 while the next one is being filled"""
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from nufhe_amd import multi_gpu
+    g = torch.Generator().manual_seed(99)
+    a = torch.randint(-2**31, 2**31 - 1, (nbits, 500), dtype=torch.int32, generator=g)
+    b = torch.randint(-2**31, 2**31 - 1, (nbits,), dtype=torch.int32, generator=g)
+    cv = torch.rand((nbits,), generator=g)
+    lo, hi = multi_gpu.shard_bounds(nbits, world, rank)
+    cap = -(-nbits // world)
+    bufs = [multi_gpu.PackedCiphertext(_Params, hi - lo, 'cpu', capacity=cap, sample_array_class=_Ct) for _ in range(2)]
+    ok = True
+    pending = [None, None]
+    outs = []
+    for step in range(4):
+        k = step % 2
+        if pending[k] is not None:
+            outs.append((step - 2, pending[k].wait()))         # buffer k is free again
+        ct = bufs[k].ciphertext
+        ct.a.copy_(_fake_gate(a[lo:hi], a[lo:hi] + step))       # the "gate" writes into the packed views
+        ct.b.copy_(_fake_gate(b[lo:hi], b[lo:hi] + step))
+        ct.current_variances.copy_(cv[lo:hi] + step)
+        pending[k] = multi_gpu.gather_packed_async(bufs[k], nbits, dst=0)
+    for k in ((4 % 2), (5 % 2)):
+        outs.append((4 - 2 + (0 if k == 0 else 1), pending[k].wait()))
+    for step, res in outs:
+        if rank == 0:
+            ok = ok and bool((res[0] == _fake_gate(a, a + step)).all()) and bool((res[1] == _fake_gate(b, b + step)).all())
+            ok = ok and bool((res[2] == cv + step).all()) and res[0].shape == (nbits, 500) and res[2].dtype == torch.float32
+        else:
+            ok = ok and res is None
+    # wrong capacity / wrong slice size are refused before any collective starts
+    try:
+        multi_gpu.gather_packed_async(multi_gpu.PackedCiphertext(_Params, hi - lo, 'cpu', capacity=cap + 1,
+                                                                 sample_array_class=_Ct), nbits)
+        ok = False
+    except ValueError:
+        pass
+    results[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('nbits', [64, 37])
+def test_packed_async_gather_world2(nbits):
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_packed_worker, args=(world, port, nbits, results), nprocs=world, join=True)
+    assert all(results.get(r) for r in range(world)), dict(results)
+
+
+def _subgroup_worker(rank, world, port, results):
+    """dst is GROUP-LOCAL: in a group made of global ranks (2, 1) the destination 0 is global rank 2"""
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from nufhe_amd import multi_gpu
+    grp = dist.new_group(ranks=[1, 2])
+    ok = True
+    if rank in (1, 2):
+        gr = dist.get_rank(grp)
+        lo, hi = multi_gpu.shard_bounds(10, 2, gr)
+        local = (torch.arange(lo, hi, dtype=torch.int32),)
+        res = multi_gpu.gather_arrays(local, 10, group=grp, dst=1)      # group-local 1 = global rank 2
+        if rank == 2:
+            ok = res is not None and bool((res[0] == torch.arange(10, dtype=torch.int32)).all())
+        else:
+            ok = res is None
+    results[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_destination_is_group_local():
+    world = 3
+    port = _free_port()
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_subgroup_worker, args=(world, port, results), nprocs=world, join=True)
+    assert all(results.get(r) for r in range(world)), dict(results)
+
+
 @pytest.mark.parametrize('nbits', [64, 37])
 def test_shard_and_gather_world2(nbits):
     world = 2
