@@ -64,7 +64,7 @@ int nufhe_h2d(nufhe_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);   /
 int nufhe_d2h(nufhe_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);   /* synchronous */
 
 /* ---- cloud key (BootstrapKey bootstrap.py:44-92, LweKeyswitchKey lwe.py:254-308) ---- */
-/* transform: NUFHE_TRANSFORM_NTT or NUFHE_TRANSFORM_FFT; mask_size: tlwe_mask_size k, 1 or (NTT only) 2
+/* transform: NUFHE_TRANSFORM_NTT or NUFHE_TRANSFORM_FFT; mask_size: tlwe_mask_size k, 1 or 2 (both transforms)
  * (NuFHEParameters(transform_type=..., tlwe_mask_size=...), api_low_level.py:44-47).  They fix the
  * domain and the shape [n][k+1][2][k+1][...] of the bootstrapping key and the keyswitch input size k*1024. */
 int nufhe_cloudkey_create(nufhe_ctx *ctx, int lwe_size, int transform, int mask_size, nufhe_cloudkey **key);
@@ -100,19 +100,25 @@ int nufhe_ks_download_reference(nufhe_cloudkey *key, int32_t *h_ks_a, int32_t *h
 int nufhe_tgsw_add_message(nufhe_ctx *ctx, int32_t *d_tgsw, const int32_t *d_messages, long count,
                            int mask_size);
 
-/* ---- LWE sample descriptor: a[bit * a_stride + i], b[bit * b_stride], cv[bit * cv_stride] ---- */
+/* ---- LWE sample descriptor: a[bit * a_stride + i], b[bit * b_stride], cv[bit * cv_stride] ----
+ * Carries what the reference's typed Reikna signatures carry (lwe_gpu.py:151-159, blind_rotate.py:226-234: the
+ * array shapes are part of the computation's signature and a mismatch is refused before anything is launched):
+ * `size` is the LWE dimension of THIS operand and every entry point checks it against what its key / its other
+ * operands require (n for gate operands and results, k * 1024 for extracted samples) and returns NUFHE_EINVAL
+ * on a mismatch, a NULL a / b, a negative stride or 0 < a_stride < size -- never an out-of-bounds access. */
 typedef struct {
     int32_t *a;
     int32_t *b;
     float *cv;          /* may be NULL where the variance is not needed */
     long a_stride;      /* elements between consecutive bits of a (>= size, or 0 to broadcast) */
-    long b_stride;      /* elements between consecutive bits of b and cv (1, or 0 to broadcast) */
+    long b_stride;      /* elements between consecutive bits of b and cv (>= 1, or 0 to broadcast) */
+    int32_t size;       /* number of mask coefficients per bit (the length of the last axis of a) */
 } nufhe_lwe;
 
 /* ---- hot path ---- */
 
 /* LweLinear (lwe_gpu.py:287-316, lwe_gpu.mako:123-169): res = [res +] p * src on (a, b),
- * cv = [cv +] p^2 * cv; size = LWE size of both. */
+ * cv = [cv +] p^2 * cv; size = LWE size of both (must equal res.size and src.size). */
 int nufhe_lwe_linear(nufhe_ctx *ctx, nufhe_lwe res, nufhe_lwe src, int32_t p, int add_result,
                      long nbits, int size);
 /* LweNoiselessTrivialConstant (lwe_gpu.py:340-344): res = (0, mu), cv = 0 */
@@ -156,6 +162,16 @@ int nufhe_shift_torus_polynomial(nufhe_ctx *ctx, int32_t *d_result, const int32_
 /* tlwe_extract_lwe_samples (tlwe_gpu.mako:54-84): tlwe [batch][k+1][1024] -> a [batch][k*1024], b */
 int nufhe_tlwe_extract(nufhe_ctx *ctx, int32_t *d_result_a, int32_t *d_result_b,
                        const int32_t *d_tlwe, long batch, int mask_size);
+/* TGswTorus32PolynomialDecompH (tgsw_gpu.py:60-107, tgsw_cpu.py:26-49; unit test test/test_tgsw.py:44-69):
+ * sample int32 [polys][1024] -> result int32 [polys][2][1024], the gadget digits (l = 2, Bg = 2^10) of every
+ * coefficient -- the function the fused blind rotation applies to (X^a - 1) ACC. */
+int nufhe_tgsw_decompose(nufhe_ctx *ctx, int32_t *d_result, const int32_t *d_sample, long polys);
+/* TLweTransformedAddMulTo (tgsw_cpu.py:52-79; unit test test/test_tgsw.py:72-115): the multiply-accumulate of the
+ * external product on REFERENCE-format transformed arrays (natural order, key Montgomery-prepared):
+ *   result uint64 [batch][k+1][1024] = sum_{m,d} sample [batch][k+1][2][1024] * bk [bk_len][k+1][2][k+1][1024] (row
+ *   bk_row), with the paired two-products-one-reduction arithmetic of the fused kernel. */
+int nufhe_tgsw_mac(nufhe_ctx *ctx, uint64_t *d_result, const uint64_t *d_sample, const uint64_t *d_bk, int bk_len,
+                   int bk_row, long batch, int mask_size);
 /* Transform (transform/computation.py:28-99): batched negacyclic NTT-1024, natural order,
  * identical values to ntt_transform_ref (transform/ntt.py:30-44). */
 int nufhe_ntt_forward_i32(nufhe_ctx *ctx, uint64_t *d_out, const int32_t *d_in, long batch);

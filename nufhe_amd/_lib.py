@@ -25,6 +25,7 @@ class NufheLwe(ctypes.Structure):
         ("cv", ctypes.c_void_p),
         ("a_stride", ctypes.c_long),
         ("b_stride", ctypes.c_long),
+        ("size", ctypes.c_int32),
     ]
 
 
@@ -70,6 +71,8 @@ PROTOTYPES = {
     "nufhe_t32_to_phase": [_vp, _vp, _vp, _long, ctypes.c_uint32],
     "nufhe_shift_torus_polynomial": [_vp, _vp, _vp, _vp, _long, _long, _long, _int, _int, _int],
     "nufhe_tlwe_extract": [_vp, _vp, _vp, _vp, _long, _int],
+    "nufhe_tgsw_decompose": [_vp, _vp, _vp, _long],
+    "nufhe_tgsw_mac": [_vp, _vp, _vp, _vp, _int, _int, _long, _int],
     "nufhe_ntt_forward_i32": [_vp, _vp, _vp, _long],
     "nufhe_ntt_forward_u64": [_vp, _vp, _vp, _long],
     "nufhe_ntt_inverse_i32": [_vp, _vp, _vp, _long],
@@ -121,5 +124,24 @@ def check(rc):
     raise NufheError("nufhe_hip error %d: %s" % (rc, msg))
 
 
+# context / cloud-key handle value -> callable that raises when the caller's torch stream is not the stream the
+# library enqueues on (DeviceThread.check_stream).  Centralised here so that EVERY entry point that hands device
+# memory to the library is guarded, not only the ones that remember to ask.
+_stream_guards = {}
+
+
+def register_stream_guard(handle, guard):
+    _stream_guards[int(handle.value)] = guard
+
+
+def unregister_stream_guard(handle):
+    if handle is not None and handle.value is not None:
+        _stream_guards.pop(int(handle.value), None)
+
+
 def call(name, *args):
+    if args and isinstance(args[0], ctypes.c_void_p) and args[0].value is not None:
+        guard = _stream_guards.get(int(args[0].value))
+        if guard is not None:
+            guard()
     check(getattr(lib(), name)(*args))

@@ -34,9 +34,14 @@ class NativeCloudKey:
         _lib.call("nufhe_cloudkey_create", thr.handle, int(lwe_size), self.TRANSFORMS[transform_type],
                   int(mask_size), ctypes.byref(handle))
         self.handle = handle
+        import weakref
+        ref = weakref.ref(thr)
+        _lib.register_stream_guard(handle, lambda: (ref() is not None) and ref().check_stream())
         thr._cloud_keys.add(self)
 
     def destroy(self):
+        if self.handle:
+            _lib.unregister_stream_guard(self.handle)
         if self.handle and not self.thr._released:
             _lib.lib().nufhe_cloudkey_destroy(self.handle)
         self.handle = None

@@ -99,6 +99,21 @@ inline LweView view(const nufhe_lwe &x) { return LweView{x.a, x.b, x.cv, x.a_str
 
 inline BrSource source(const nufhe_lwe &x, i32 p) { return BrSource{x.a, x.b, x.a_stride, x.b_stride, p}; }
 
+// The checks the reference gets from its typed computation signatures (lwe_gpu.py:151-159, blind_rotate.py:226-234):
+// an operand whose LWE dimension is not the one the key / the operation needs is refused, not read out of bounds.
+static int check_lwe(const nufhe_lwe &x, int expect_size, const char *what, bool need_cv, long nbits)
+{
+    // (an empty batch has no storage: its pointers may be NULL)
+    if (nbits > 0 && (x.a == nullptr || x.b == nullptr)) return fail(NUFHE_EINVAL, "%s: NULL a / b pointer", what);
+    if (nbits > 0 && need_cv && x.cv == nullptr) return fail(NUFHE_EINVAL, "%s: NULL variance pointer", what);
+    if (x.size != expect_size)
+        return fail(NUFHE_EINVAL, "%s: LWE size %d, expected %d", what, (int)x.size, expect_size);
+    if (x.a_stride < 0 || x.b_stride < 0) return fail(NUFHE_EINVAL, "%s: negative stride", what);
+    if (x.a_stride != 0 && x.a_stride < x.size)
+        return fail(NUFHE_EINVAL, "%s: a_stride %ld shorter than the sample (%d)", what, x.a_stride, (int)x.size);
+    return NUFHE_OK;
+}
+
 int check_ctx(nufhe_ctx *ctx)
 {
     if (!ctx) return fail(NUFHE_EINVAL, "null context");
@@ -546,6 +561,8 @@ int nufhe_lwe_linear(nufhe_ctx *ctx, nufhe_lwe res, nufhe_lwe src, int32_t p, in
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (nbits < 0 || size < 1) return fail(NUFHE_EINVAL, "bad sizes");
+    if ((rc = check_lwe(res, size, "lwe_linear result", true, nbits)) || (rc = check_lwe(src, size, "lwe_linear source", true, nbits)))
+        return rc;
     HIP_TRY(launch_lwe_linear(view(res), view(src), p, add_result, nbits, size, ctx->stream));
     return NUFHE_OK;
 }
@@ -555,6 +572,7 @@ int nufhe_lwe_trivial_const(nufhe_ctx *ctx, nufhe_lwe res, int32_t mu, long nbit
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (nbits < 0 || size < 1) return fail(NUFHE_EINVAL, "bad sizes");
+    if ((rc = check_lwe(res, size, "lwe_trivial_const result", true, nbits))) return rc;
     HIP_TRY(launch_lwe_trivial_const(view(res), mu, nbits, size, ctx->stream));
     return NUFHE_OK;
 }
@@ -616,6 +634,9 @@ int nufhe_bootstrap(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe
 {
     int rc = check_key(ctx, key, true, !no_keyswitch);
     if (rc) return rc;
+    if ((rc = check_lwe(x, key->n, "bootstrap input", false, nbits)) ||
+        (rc = check_lwe(result, no_keyswitch ? key->ext_size() : key->n, "bootstrap result", !no_keyswitch, nbits)))
+        return rc;
     BrJob job;
     memset(&job, 0, sizeof(job));
     job.s0 = source(x, 1);
@@ -628,6 +649,9 @@ int nufhe_keyswitch(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe
     int rc = check_key(ctx, key, false, true);
     if (rc) return rc;
     if (nbits < 0) return fail(NUFHE_EINVAL, "negative batch size");
+    if ((rc = check_lwe(src, key->ext_size(), "keyswitch source", false, nbits)) ||
+        (rc = check_lwe(result, key->n, "keyswitch result", true, nbits)))
+        return rc;
     if (nbits == 0) return NUFHE_OK;
     if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
     if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
@@ -645,6 +669,9 @@ int nufhe_gate_binary(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nuf
 {
     int rc = check_key(ctx, key, true, true);
     if (rc) return rc;
+    if ((rc = check_lwe(result, key->n, "gate result", true, nbits)) || (rc = check_lwe(a, key->n, "gate operand a", false, nbits)) ||
+        (rc = check_lwe(b, key->n, "gate operand b", false, nbits)))
+        return rc;
     BrJob job;
     memset(&job, 0, sizeof(job));
     job.s0 = source(a, pa);
@@ -658,6 +685,9 @@ int nufhe_gate_mux(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe_
 {
     int rc = check_key(ctx, key, true, true);
     if (rc) return rc;
+    if ((rc = check_lwe(result, key->n, "mux result", true, nbits)) || (rc = check_lwe(a, key->n, "mux operand a", false, nbits)) ||
+        (rc = check_lwe(b, key->n, "mux operand b", false, nbits)) || (rc = check_lwe(c, key->n, "mux operand c", false, nbits)))
+        return rc;
     const i32 MU = (i32)(1u << 29);
     BrJob jobs[2];
     memset(jobs, 0, sizeof(jobs));
@@ -706,6 +736,29 @@ int nufhe_tlwe_extract(nufhe_ctx *ctx, int32_t *d_result_a, int32_t *d_result_b,
     if (rc) return rc;
     if (mask_size < 1) return fail(NUFHE_EINVAL, "mask_size must be positive");
     HIP_TRY(launch_tlwe_extract(d_result_a, d_result_b, d_tlwe, batch, mask_size, ctx->stream));
+    return NUFHE_OK;
+}
+
+int nufhe_tgsw_decompose(nufhe_ctx *ctx, int32_t *d_result, const int32_t *d_sample, long polys)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (polys < 0) return fail(NUFHE_EINVAL, "negative polynomial count");
+    if (polys && (!d_result || !d_sample)) return fail(NUFHE_EINVAL, "null argument");
+    HIP_TRY(launch_tgsw_decompose(d_result, d_sample, polys, ctx->stream));
+    return NUFHE_OK;
+}
+
+int nufhe_tgsw_mac(nufhe_ctx *ctx, uint64_t *d_result, const uint64_t *d_sample, const uint64_t *d_bk, int bk_len,
+                   int bk_row, long batch, int mask_size)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (mask_size != 1 && mask_size != 2) return fail(NUFHE_EINVAL, "mask_size must be 1 or 2");
+    if (batch < 0) return fail(NUFHE_EINVAL, "negative batch size");
+    if (bk_row < 0 || bk_row >= bk_len) return fail(NUFHE_EINVAL, "bk_row %d out of range [0, %d)", bk_row, bk_len);
+    if (batch && (!d_result || !d_sample || !d_bk)) return fail(NUFHE_EINVAL, "null argument");
+    HIP_TRY(launch_tgsw_mac(d_result, d_sample, d_bk, bk_row, batch, mask_size, ctx->stream));
     return NUFHE_OK;
 }
 

@@ -125,4 +125,7 @@ hipError_t launch_lwe_phase(i32 *out, long out_stride, const i32 *a, long a_stri
 hipError_t launch_t32_to_phase(i32 *result, const i32 *phase, long count, u32 mspace, hipStream_t stream);
 hipError_t launch_shift_tp(i32 *result, const i32 *source, const i32 *powers, long powers_stride, long powers_idx,
                            long batch, int polys, int minus_one, int invert_powers, hipStream_t stream);
+hipError_t launch_tgsw_decompose(i32 *result, const i32 *sample, long polys, hipStream_t stream);
+hipError_t launch_tgsw_mac(u64 *result, const u64 *sample, const u64 *bk, int bk_row, long batch, int mask_size,
+                           hipStream_t stream);
 hipError_t launch_tlwe_extract(i32 *ra, i32 *rb, const i32 *tlwe, long batch, int mask_size, hipStream_t stream);

@@ -806,6 +806,52 @@ __global__ void k_bk_to_reference(u64 *__restrict__ out, const u64 *__restrict__
     out[p * 1024 + ntt_freq_index(lane, reg)] = ff_mul_pow2<64>(in[p * 1024 + bk_elem_offset(lane, reg)]);
 }
 
+// ------------------------------------------------------------------------------------------
+// Unit-granularity hooks for the two steps that are otherwise only reachable fused inside the blind rotation
+// (reference test surface: test/test_tgsw.py:44-69 and :72-115).
+// ------------------------------------------------------------------------------------------
+
+// TGswTorus32PolynomialDecompH (tgsw_gpu.py / tgsw_cpu.py:26-49): sample int32 [polys][1024] ->
+// result int32 [polys][2][1024], the two gadget digits of every coefficient (br_digit, the hot path's function)
+__global__ void k_tgsw_decompose(i32 *__restrict__ result, const i32 *__restrict__ sample, long polys)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= polys * 1024) return;
+    const long p = t >> 10;
+    const int j = (int)(t & 1023);
+    const u32 v = (u32)sample[t];
+    result[(p * 2 + 0) * 1024 + j] = br_digit<0>(v);
+    result[(p * 2 + 1) * 1024 + j] = br_digit<1>(v);
+}
+
+// TLweTransformedAddMulTo (tgsw_cpu.py:52-79; tgsw_gpu.mako MAC of the fused kernel): transformed-domain
+//   result[b][mo][f] = sum_{m, d} sample[b][m][d][f] * bk[row][m][d][mo][f] / 2^64   (mod P)
+// on arrays in the REFERENCE's format (natural order, key Montgomery-prepared: the factor 2^-64 is the shift the key
+// upload applies, k_bk_from_reference).  The products run through ff_dot2 -- two products, one reduction, the
+// multiply-accumulate of br_mac2 -- in the order of the hot path (d = 0, 1 paired, then over m); field addition is
+// exact, so the value equals the reference's sequential sum.
+template <int K>
+__global__ void k_tgsw_mac(u64 *__restrict__ result, const u64 *__restrict__ sample, const u64 *__restrict__ bk,
+                           int bk_row, long batch)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch * (K + 1) * 1024) return;
+    const int f = (int)(t & 1023);
+    const int mo = (int)((t >> 10) % (K + 1));
+    const long b = (t >> 10) / (K + 1);
+    const u64 *row = bk + (long)bk_row * BK_ROW_ELEMS_K(K);
+    u64 acc = 0;
+#pragma unroll
+    for (int m = 0; m <= K; m++) {
+        const u64 x0 = ff_canon(sample[((b * (K + 1) + m) * 2 + 0) * 1024 + f]);
+        const u64 x1 = ff_canon(sample[((b * (K + 1) + m) * 2 + 1) * 1024 + f]);
+        const u64 k0 = ff_mul_pow2<128>(ff_canon(row[((m * 2 + 0) * (K + 1) + mo) * 1024 + f]));   // * 2^-64 (2^192 = 1)
+        const u64 k1 = ff_mul_pow2<128>(ff_canon(row[((m * 2 + 1) * (K + 1) + mo) * 1024 + f]));
+        acc = (m == 0) ? ff_dot2<false>(x0, k0, x1, k1, 0) : ff_dot2<true>(x0, k0, x1, k1, acc);
+    }
+    result[t] = ff_canon(acc);
+}
+
 // coefficient-domain TGSW polynomials (int32) -> wave layout (forward NTT only; no Montgomery)
 __global__ __launch_bounds__(NTT_BLOCK_THREADS) void k_bk_from_coeffs(u64 *__restrict__ out, const i32 *__restrict__ in,
                                                                       long polys, const u64 *__restrict__ tw1f,
@@ -1473,6 +1519,23 @@ hipError_t launch_poly_mul(i32 *out, const i32 *x, const i32 *y, const i32 *base
 hipError_t launch_bk_from_reference(u64 *out, const u64 *in, long polys, hipStream_t stream)
 {
     hipLaunchKernelGGL(k_bk_from_reference, dim3(blocks_for(polys * 1024, 256)), dim3(256), 0, stream, out, in, polys);
+    return hipGetLastError();
+}
+
+hipError_t launch_tgsw_decompose(i32 *result, const i32 *sample, long polys, hipStream_t stream)
+{
+    if (polys == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tgsw_decompose, dim3(blocks_for(polys * 1024, 256)), dim3(256), 0, stream, result, sample, polys);
+    return hipGetLastError();
+}
+
+hipError_t launch_tgsw_mac(u64 *result, const u64 *sample, const u64 *bk, int bk_row, long batch, int mask_size,
+                           hipStream_t stream)
+{
+    if (batch == 0) return hipSuccess;
+    const dim3 grid(blocks_for(batch * (mask_size + 1) * 1024, 256));
+    if (mask_size == 1) hipLaunchKernelGGL(k_tgsw_mac<1>, grid, dim3(256), 0, stream, result, sample, bk, bk_row, batch);
+    else hipLaunchKernelGGL(k_tgsw_mac<2>, grid, dim3(256), 0, stream, result, sample, bk, bk_row, batch);
     return hipGetLastError();
 }
 

@@ -55,6 +55,8 @@ class DeviceThread:
         _lib.check(lib.nufhe_ctx_create(
             self.device_index, ctypes.c_void_p(self._torch_stream.cuda_stream), 0, ctypes.byref(handle)))
         self.handle = handle
+        ref = weakref.ref(self)
+        _lib.register_stream_guard(handle, lambda: (ref() is not None) and ref().check_stream())
         props = torch.cuda.get_device_properties(self.device)
         self.device_params = DeviceParams(props.name, props.multi_processor_count)
         self._released = False
@@ -96,6 +98,7 @@ class DeviceThread:
         if not self._released and self.handle:
             for key in list(self._cloud_keys):    # ~100 MB of device memory each: free them with the context
                 key.destroy()
+            _lib.unregister_stream_guard(self.handle)
             _lib.lib().nufhe_ctx_destroy(self.handle)
             self._released = True
 
@@ -110,6 +113,24 @@ def ptr(tensor):
     return ctypes.c_void_p(tensor.data_ptr() if tensor is not None else 0)
 
 
+def int32_operand(name, tensor, device, shape=None):
+    """A key / message tensor about to be handed to a kernel that reads int32.  Other integer / bool tensors are
+    CONVERTED (the reference's ``astype(Torus32)``, lwe.py:265-270, tgsw.py:155-161) -- handing their bytes over
+    as they are would be reinterpreted silently --, floating-point ones are refused; returns the tensor contiguous
+    on this device.  ``shape``: expected shape."""
+    if not isinstance(tensor, torch.Tensor):
+        raise TypeError("%s: expected a torch tensor, got %s" % (name, type(tensor).__name__))
+    if tensor.dtype != torch.int32:
+        if tensor.dtype.is_floating_point or tensor.dtype.is_complex:
+            raise TypeError("%s: expected an integer tensor, got %s" % (name, tensor.dtype))
+        tensor = tensor.to(torch.int32)
+    if tensor.device != device:
+        raise ValueError("%s lives on %s, the context on %s" % (name, tensor.device, device))
+    if shape is not None and tuple(tensor.shape) != tuple(shape):
+        raise ValueError("%s has shape %s, expected %s" % (name, tuple(tensor.shape), tuple(shape)))
+    return tensor.contiguous()
+
+
 def lwe_desc(a, b, cv, size):
     """Builds the C descriptor of an LWE sample batch from (a [B, size], b [B], cv [B]) device
     tensors that are 2D/1D views with a contiguous last axis (stride-0 batch axes broadcast)."""
@@ -121,4 +142,5 @@ def lwe_desc(a, b, cv, size):
     return NufheLwe(
         a=a.data_ptr(), b=b.data_ptr(), cv=(cv.data_ptr() if cv is not None else None),
         a_stride=a.stride(0) if a.shape[0] > 1 else (a.stride(0) if a.shape[0] == 1 else 0),
-        b_stride=b.stride(0) if b.shape[0] > 1 else (b.stride(0) if b.shape[0] == 1 else 0))
+        b_stride=b.stride(0) if b.shape[0] > 1 else (b.stride(0) if b.shape[0] == 1 else 0),
+        size=size)

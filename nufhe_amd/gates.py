@@ -18,44 +18,43 @@ from .numeric_functions import phase_to_t32
 
 
 def get_shape(obj):
-    """nufhe/gates.py:42-48"""
-    if hasattr(obj, 'shape'):
-        return tuple(obj.shape)
-    elif isinstance(obj, list):
+    """Shape of a plaintext / ciphertext argument: anything with a ``shape``, or a (nested) list
+    (reference behaviour: nufhe/gates.py:42-48)."""
+    shape = getattr(obj, 'shape', None)
+    if shape is not None:
+        return tuple(shape)
+    if isinstance(obj, list):
         return numpy.asarray(obj).shape
-    else:
-        raise ValueError("An object of type " + str(type(obj)) + " is not array-like")
-
-
-def _result_shape_pair(shape1, shape2):
-    if len(shape1) > len(shape2):
-        shape2 = (1,) * (len(shape1) - len(shape2)) + shape2
-    else:
-        shape1 = (1,) * (len(shape2) - len(shape1)) + shape1
-    if any((l1 != l2 and l1 > 1 and l2 > 1) for l1, l2 in zip(shape1, shape2)):
-        raise ValueError("Incompatible shapes: {s1}, {s2}".format(s1=shape1, s2=shape2))
-    return tuple((l1 if l1 > 1 else l2) for l1, l2 in zip(shape1, shape2))
+    raise ValueError("%s objects have no shape: expected an array-like argument" % type(obj).__name__)
 
 
 def result_shape(*shapes):
-    """nufhe/gates.py:63-69"""
-    shapes = [tuple(s) for s in shapes]
-    if len(shapes) == 1:
-        return shapes[0]
-    elif len(shapes) == 2:
-        return _result_shape_pair(*shapes)
-    else:
-        return _result_shape_pair(shapes[0], result_shape(*shapes[1:]))
+    """Broadcast of the operand shapes, aligned at the LAST axis (reference: nufhe/gates.py:51-69).  An axis
+    of length <= 1 stretches to the other operand's length; two different lengths above 1 do not combine."""
+    out = ()
+    for shape in shapes:
+        shape = tuple(shape)
+        rank = max(len(out), len(shape))
+        a = (1,) * (rank - len(out)) + out
+        b = (1,) * (rank - len(shape)) + shape
+        merged = []
+        for axis, (x, y) in enumerate(zip(a, b)):
+            if x > 1 and y > 1 and x != y:
+                raise ValueError("operand shapes %s do not broadcast: lengths %d and %d meet on axis %d (from the left of "
+                                 "the aligned shapes)" % (", ".join(str(tuple(s)) for s in shapes), x, y, axis))
+            merged.append(x if x > 1 else y)
+        out = tuple(merged)
+    return out
 
 
 def check_shape(result, *args):
-    """nufhe/gates.py:72-78"""
-    rshape = result_shape(*[arg.shape for arg in args])
-    if len(rshape) > len(result.shape) or rshape != result.shape[len(result.shape)-len(rshape):]:
-        raise ValueError(
-            ("The shape of the result derived from the arguments {derived_shape} "
-            "cannot be broadcasted to the shape of the destination {dest_shape}").format(
-            derived_shape=rshape, dest_shape=result.shape))
+    """The broadcast shape of the arguments must be the trailing part of the destination's shape
+    (leading destination axes repeat the gate; reference: nufhe/gates.py:72-78)."""
+    need = result_shape(*[get_shape(arg) for arg in args])
+    have = tuple(result.shape)
+    if len(need) > len(have) or have[len(have) - len(need):] != need:
+        raise ValueError("gate arguments broadcast to %s, which is not a trailing part of the destination shape %s"
+                         % (need, have))
 
 
 MU = phase_to_t32(1, 8)

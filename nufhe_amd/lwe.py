@@ -16,7 +16,7 @@ import numpy
 import torch
 
 from . import _lib
-from .device import DeviceThread, lwe_desc, ptr
+from .device import DeviceThread, lwe_desc, ptr, int32_operand
 from .numeric_functions import Torus32, ErrorFloat
 from .random_numbers import rand_uniform_bool, rand_gaussian_torus32_host
 from .utils import arrays_equal, to_numpy
@@ -304,8 +304,11 @@ class LweKeyswitchKey:
             raise ValueError("the gfx950 keyswitch kernels support ks_decomp_length=8, ks_log2_base=2")
         accum_params = tgsw_key.params.tlwe_params
         extract_params = accum_params.extracted_lweparams
-        in_key = LweKey.from_tlwe_key(extract_params, tgsw_key.tlwe_key).key.contiguous()
-        out_key = lwe_key.key.contiguous()
+        # nufhe_ks_make reads int32 [mask_size * 1024] and int32 [lwe_size] and indexes the masks by the native key's
+        # own sizes: anything else (another dtype, a key of another dimension) is refused here
+        in_key = int32_operand("extracted TLWE key", LweKey.from_tlwe_key(extract_params, tgsw_key.tlwe_key).key,
+                               thr.device, (native.mask_size * 1024,))
+        out_key = int32_operand("LWE key", lwe_key.key, thr.device, (native.lwe_size,))
         input_size = in_key.shape[0]
         output_size = out_key.shape[0]
         noise = lwe_key.params.min_noise

@@ -6,7 +6,7 @@ bootstrap-key generation (tgsw_add_message, tgsw.py:142-161 / tgsw_cpu.py:109-12
 import numpy
 
 from . import _lib
-from .device import ptr
+from .device import ptr, int32_operand
 from .numeric_functions import Torus32
 from .tlwe import TLweParams, TLweKey, tlwe_encrypt_zero
 
@@ -65,5 +65,6 @@ def tgsw_encrypt_int(thr, rng, messages, noise: float, key: TGswKey):
         raise ValueError("the gfx950 kernels support bs_decomp_length=2, bs_log2_base=10")
     result = tlwe_encrypt_zero(thr, rng, shape + (k1, l), noise, key.tlwe_key)
     count = int(numpy.prod(shape)) if len(shape) else 1
-    _lib.call("nufhe_tgsw_add_message", thr.handle, ptr(result), ptr(messages.contiguous()), count, k1 - 1)
+    messages = int32_operand("TGSW messages", messages, thr.device)        # the kernel reads int32
+    _lib.call("nufhe_tgsw_add_message", thr.handle, ptr(result), ptr(messages), count, k1 - 1)
     return result

@@ -158,6 +158,68 @@ def test_views_through_the_kernels_and_copy_log(thr, params, caplog):
         assert (exp == got).all()
 
 
+def test_c_boundary_refuses_wrong_operand_sizes(thr):
+    """BELOW the Python wrapper: raw ctypes calls into libnufhe_hip.so with hand-made nufhe_lwe descriptors over raw
+    device pointers (nufhe_alloc), the way INTEGRATION.md's stub would call it.  A descriptor whose `size` is not what
+    the key / operation needs, a NULL pointer, or a stride shorter than the sample must come back as NUFHE_EINVAL
+    with a message -- the reference's typed Reikna signatures refuse such calls before launching
+    (lwe_gpu.py:151-159, blind_rotate.py:226-234) -- and must not touch memory."""
+    import ctypes
+    import nufhe_amd
+    from nufhe_amd import _lib
+    L = _lib.lib()
+    ctx = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(11), thread=thr)
+    sk, ck = ctx.make_key_pair()
+    key = ck._native.handle
+    h = thr.handle
+    nbits, n, ext = 4, 500, 1024
+
+    def alloc(nbytes):
+        p = ctypes.c_void_p()
+        assert L.nufhe_alloc(h, nbytes, ctypes.byref(p)) == 0
+        return p
+    bufs = [alloc(nbits * ext * 4) for _ in range(8)]
+
+    def desc(i, size, a_stride=None, null=None):
+        d = _lib.NufheLwe(a=bufs[2 * i].value, b=bufs[2 * i + 1].value, cv=bufs[2 * i + 1].value,
+                          a_stride=size if a_stride is None else a_stride, b_stride=1, size=size)
+        if null:
+            setattr(d, null, None)
+        return d
+    EINVAL = -1
+
+    def refused(rc, text):
+        assert rc == EINVAL, rc
+        msg = L.nufhe_last_error().decode()
+        assert text in msg, msg
+    MU = 2**29
+    ok = desc(0, n)
+    refused(L.nufhe_gate_binary(h, key, desc(0, ext), desc(1, n), desc(2, n), MU, -1, -1, MU, nbits), "gate result: LWE size 1024, expected 500")
+    refused(L.nufhe_gate_binary(h, key, ok, desc(1, ext), desc(2, n), MU, -1, -1, MU, nbits), "gate operand a: LWE size 1024")
+    refused(L.nufhe_gate_binary(h, key, ok, desc(1, n), desc(2, 0), MU, -1, -1, MU, nbits), "gate operand b: LWE size 0")
+    refused(L.nufhe_gate_binary(h, key, ok, desc(1, n, a_stride=499), desc(2, n), MU, -1, -1, MU, nbits), "a_stride 499 shorter")
+    refused(L.nufhe_gate_binary(h, key, ok, desc(1, n, null='a'), desc(2, n), MU, -1, -1, MU, nbits), "NULL a / b")
+    refused(L.nufhe_gate_binary(h, key, desc(0, n, null='cv'), desc(1, n), desc(2, n), MU, -1, -1, MU, nbits), "NULL variance")
+    refused(L.nufhe_gate_mux(h, key, ok, desc(1, n), desc(2, n), desc(3, ext), nbits), "mux operand c: LWE size 1024")
+    refused(L.nufhe_bootstrap(h, key, desc(0, n), desc(1, n), MU, nbits, 1), "bootstrap result: LWE size 500, expected 1024")
+    refused(L.nufhe_bootstrap(h, key, desc(0, ext), desc(1, n), MU, nbits, 0), "bootstrap result: LWE size 1024, expected 500")
+    refused(L.nufhe_bootstrap(h, key, desc(0, n), desc(1, ext), MU, nbits, 0), "bootstrap input: LWE size 1024")
+    refused(L.nufhe_keyswitch(h, key, desc(0, n), desc(1, n), nbits), "keyswitch source: LWE size 500, expected 1024")
+    refused(L.nufhe_keyswitch(h, key, desc(0, ext), desc(1, ext), nbits), "keyswitch result: LWE size 1024, expected 500")
+    refused(L.nufhe_lwe_linear(h, desc(0, n), desc(1, ext), 1, 0, nbits, n), "lwe_linear source: LWE size 1024")
+    refused(L.nufhe_lwe_trivial_const(h, desc(0, ext), MU, nbits, n), "lwe_trivial_const result: LWE size 1024")
+    # a negative batch is refused as before, and the well-formed calls run
+    refused(L.nufhe_gate_binary(h, key, ok, desc(1, n), desc(2, n), MU, -1, -1, MU, -1), "negative batch")
+    assert L.nufhe_lwe_trivial_const(h, desc(1, n), MU, nbits, n) == 0
+    assert L.nufhe_lwe_trivial_const(h, desc(2, n), 0, nbits, n) == 0
+    assert L.nufhe_gate_binary(h, key, ok, desc(1, n), desc(2, n), MU, -1, -1, MU, nbits) == 0
+    assert L.nufhe_bootstrap(h, key, desc(3, ext), desc(1, n), MU, nbits, 1) == 0
+    assert L.nufhe_keyswitch(h, key, desc(0, n), desc(3, ext), nbits) == 0
+    thr.synchronize()
+    for b in bufs:
+        assert L.nufhe_free(h, b) == 0
+
+
 def test_lwe_size_validation(thr, params):
     """Operands whose LWE size does not match the key are rejected in Python (the kernels would read or
     write out of bounds): gates, bootstrap with / without keyswitch, keyswitch, decrypt."""

@@ -104,6 +104,35 @@ def test_extract(thr, H, golden):
     assert (H.host(ra) == golden['tlwe_extract_a']).all() and (H.host(rb) == golden['tlwe_extract_b']).all()
 
 
+def test_tgsw_decompose_vs_reference_golden(thr, H, golden):
+    """the gadget decomposition as a standalone device call (test/test_tgsw.py:44-69): full-range accumulators with
+    the boundary values in front, against the output of the reference's tgsw_polynomial_decomp_trf_reference"""
+    x = gi.decomp_inputs()                                   # int32 (2, 3, 2, 1024)
+    d_x = H.dev(thr, x)
+    out = thr.array(x.shape[:-1] + (2, 1024), numpy.int32)
+    call("nufhe_tgsw_decompose", thr.handle, ptr(out), ptr(d_x), x.size // 1024)
+    got = H.host(out)
+    assert got.shape == golden['tgsw_decomp'].shape and (got == golden['tgsw_decomp']).all()
+    assert got.min() >= -512 and got.max() <= 511
+    with pytest.raises(ValueError):
+        call("nufhe_tgsw_decompose", thr.handle, ptr(out), ptr(d_x), -1)
+
+
+def test_tgsw_mac_vs_reference_golden(thr, H, golden):
+    """the transformed-domain multiply-accumulate as a standalone device call (test/test_tgsw.py:72-115) on
+    reference-format arrays, against tlwe_transformed_add_mul_to_trf_reference's output"""
+    tr_sample, bk, row = gi.mac_inputs()                     # uint64 (2, 3, 2, 2, 1024), (4, 2, 2, 2, 1024)
+    d_s = H.dev(thr, tr_sample); d_bk = H.dev(thr, bk)
+    out = thr.array(tr_sample.shape[:-3] + (2, 1024), numpy.uint64)
+    call("nufhe_tgsw_mac", thr.handle, ptr(out), ptr(d_s), ptr(d_bk), bk.shape[0], row, 6, 1)
+    got = H.host_u64(out)
+    assert (got == golden['tgsw_mac']).all()
+    with pytest.raises(ValueError):
+        call("nufhe_tgsw_mac", thr.handle, ptr(out), ptr(d_s), ptr(d_bk), bk.shape[0], bk.shape[0], 6, 1)   # row out of range
+    with pytest.raises(ValueError):
+        call("nufhe_tgsw_mac", thr.handle, ptr(out), ptr(d_s), ptr(d_bk), bk.shape[0], row, 6, 3)
+
+
 def test_lwe_linear_and_trivial(thr, H, golden):
     from nufhe_amd import lwe as L
     from nufhe_amd.api_low_level import NuFHEParameters
