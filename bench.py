@@ -55,66 +55,125 @@ def pmc_traffic(transform, gate, bits):
 
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X vector fp64: 256 CUs x 128 flop/clk x 2.4 GHz (v_fma_f64 measured
-                                    # at 4.2 cycles per wave64 instruction: profiles/r01_microbench_valu_rates.txt)
+                                    # at 4.1-4.4 cycles per wave64 instruction: profiles/r03_microbench_issue.txt)
+MFMA_I8_PEAK_TOPS = 5000.0          # dense int8 / fp8 matrix peak (MI355X_MICROARCH.md: ~5 PF dense)
+SIMDS = 1024                        # 256 CUs x 4
+
+# arithmetic one blind-rotate iteration of ONE bit needs, whatever the representation (k = 1, l = 2, N = 1024):
+# 6 negacyclic NTT-1024 = 6 x 10 stages x 512 butterflies, a butterfly = 1 add + 1 sub in GF(P); general
+# multiplications: 6 x 1024 (the one table layer per transform) + 8 x 1024 (the key products)
+ALG_ADDSUB_PER_BIT_ITER = 6 * 10 * 512 * 2         # 61,440
+ALG_MODMUL_PER_BIT_ITER = 6 * 1024 + 8 * 1024      # 14,336
 
 
 def issue_roofline(transform, bits, rotations, n_iter, kernel_ms, live_clock_ghz=None):
-    """What actually bounds the bootstrap kernel, from TRACKED files only:
-    profiles/isa_mix.json (tools/isa_mix.py: instructions per blind-rotate iteration by issue class),
-    profiles/valu_class_costs.json (tools/microbench_l4: measured cycles per class at this occupancy),
-    profiles/pmc_<transform>.json (tools/profile.sh: SQ_INSTS_VALU, SQ_WAVE_CYCLES -> sustained clock).
-    NTT: VALU issue -- sum(count_class x cycles_class) against the SIMD cycles the launch had.
-    FFT: fp64 -- flops issued against the vector fp64 peak."""
+    """What bounds the bootstrap kernel: VALU issue.  Everything comes from TRACKED files:
+    profiles/isa_mix.json (tools/isa_mix.py: instructions per blind-rotate iteration by issue class, counted in the
+    ISA of the loop), profiles/valu_issue_costs.json (tools/microbench_issue -> tools/valu_issue_costs.py: cycles per
+    class as a function of occupancy), profiles/pmc_<transform>.json (tools/profile.sh), and the live HIP-event
+    duration / in-kernel clock of the timed launches.  Every fraction names its denominator."""
     mix = _profile_json("isa_mix.json")
-    costs = _profile_json("valu_class_costs.json")
+    costs = _profile_json("valu_issue_costs.json")
     pmc = _profile_json("pmc_%s.json" % transform)
     if mix is None:
         return None
     k = mix["k_bootstrap<1>" if transform == "NTT" else "k_bootstrap_fft"]
     iters = bits * rotations * n_iter
     out = {"isa_mix_per_iteration": {c: k.get(c, 0) for c in (
-        "valu", "valu_full_rate", "valu_half_rate", "valu_f64", "s_nop", "lds", "vmem", "scratch")},
+        "valu", "valu_plain", "valu_other", "valu_f64", "s_nop", "lds", "vmem", "scratch")},
         "vgprs": k.get("vgprs"), "scratch_bytes": k.get("scratch_bytes")}
     clock = None
     if pmc is not None:
         d = pmc.get("derived", {})
-        # sustained shader clock of the profiled launches: GRBM_GUI_ACTIVE per XCD / kernel time (agrees
-        # with SQ_BUSY_CYCLES per shader engine); fall back to the wave-cycle estimate
         clock = d.get("grbm_gui_active_per_xcd_ghz") or d.get("shader_clock_ghz_from_wave_cycles")
         out["pmc"] = {"valu_instructions_per_wave_iteration": (d.get("valu_instructions_per_wave") or 0) / n_iter,
                       "sustained_clock_ghz": clock,
-                      "cycles_per_valu_instruction_per_simd": d.get("cycles_per_valu_instruction_per_simd"),
                       "frac_wave_cycles_issuing": d.get("frac_SQ_ACTIVE_INST_ANY"),
                       "frac_wave_cycles_waiting_for_issue": d.get("frac_SQ_WAIT_INST_ANY"),
-                      "frac_wave_cycles_at_waitcnt": d.get("frac_SQ_WAIT_ANY")}
+                      "frac_wave_cycles_at_waitcnt": d.get("frac_SQ_WAIT_ANY"),
+                      "note": "counter passes of an earlier build (profiles/README.md); the instruction count is re-derived "
+                              "from the current ISA above"}
     if live_clock_ghz:
-        # measured inside the timed launches (nufhe_profile_clock: s_memtime / s_memrealtime of one wave): the
-        # ceiling of THIS run, whatever clock this box sustains
-        out["clock_ghz_in_kernel"] = live_clock_ghz
+        out["clock_ghz_in_kernel"] = live_clock_ghz     # s_memtime / s_memrealtime of one wave inside the timed launches
         clock = live_clock_ghz
-    simds = 1024
-    if transform == "NTT" and costs is not None and clock:
-        cyc = k.get("valu_full_rate", 0) * costs["full_rate_cycles"] + k.get("valu_half_rate", 0) * costs["half_rate_cycles"]
-        issued = iters * cyc                                  # SIMD cycles of VALU issue the launch needs
-        avail = simds * clock * 1e9 * kernel_ms * 1e-3        # SIMD cycles the launch had
-        out.update({"bound": "valu-issue", "achieved": issued / (kernel_ms * 1e-3) / 1e9, "peak": simds * clock,
-                    "unit": "G SIMD issue cycles/s", "frac": issued / avail,
-                    "model": "sum over issue classes of (instructions x measured cycles): %d x %.2f + %d x %.2f = %.0f "
-                             "cycles per bit-iteration" % (k.get("valu_full_rate", 0), costs["full_rate_cycles"],
-                                                           k.get("valu_half_rate", 0), costs["half_rate_cycles"], cyc)})
-    elif transform == "FFT":
+    if costs is None or not clock:
+        return out
+    avail = SIMDS * clock * 1e9 * kernel_ms * 1e-3            # SIMD cycles the launch had
+    per_iter = avail / iters                                  # SIMD cycles spent per bit-iteration
+    n_plain, n_other, n_valu = k.get("valu_plain", 0), k.get("valu_other", 0), k.get("valu", 0)
+    cyc_machine = n_plain * costs["machine_plain_cycles"] + n_other * costs["machine_other_cycles"]
+    cyc_nominal = n_valu * costs["nominal_cycles_microarch_guide"]
+    cyc_slots = n_valu * costs["two_wave_other_cycles"]
+    out["simd_cycles_per_bit_iteration"] = per_iter
+    out["cycles_per_valu_instruction_per_simd"] = per_iter / n_valu
+    fracs = {
+        "vs_measured_class_rates": {
+            "frac": cyc_machine / per_iter, "cycles_per_bit_iteration": cyc_machine,
+            "denominator": "SIMD cycles of the launch (1024 SIMDs x in-kernel clock x kernel time)",
+            "numerator": "issued instructions x the best rate each class reaches on this chip at ANY occupancy "
+                         "(plain VOP1/VOP2 %.2f cycles -- two waves sharing a slot --, everything else %.2f; "
+                         "profiles/valu_issue_costs.json): %d x %.2f + %d x %.2f" % (
+                             costs["machine_plain_cycles"], costs["machine_other_cycles"], n_plain,
+                             costs["machine_plain_cycles"], n_other, costs["machine_other_cycles"])},
+        "vs_nominal_2_cycle_issue": {
+            "frac": cyc_nominal / per_iter, "cycles_per_bit_iteration": cyc_nominal,
+            "denominator": "SIMD cycles of the launch",
+            "numerator": "issued instructions x the 2 cycles per wave64 instruction MI355X_MICROARCH.md quotes for SIMD-32 "
+                         "(measured: only the plain class reaches it, and only paired across two waves)"},
+        "vs_one_slot_per_instruction": {
+            "frac": cyc_slots / per_iter, "cycles_per_bit_iteration": cyc_slots,
+            "denominator": "SIMD cycles of the launch",
+            "numerator": "issued instructions x %.2f cycles = one issue slot each, what a MIXED stream pays at 2 waves per SIMD "
+                         "(blend lines of the microbenchmark); above 1 means plain instructions of the two waves shared "
+                         "slots" % costs["two_wave_other_cycles"]},
+    }
+    if transform == "NTT":
+        # minimal-instruction arithmetic: a GF(P) add / sub = 4 plain limb instructions at the paired rate; a modular
+        # multiplication = 4 v_mad_u64_u32 + 4 instructions of reduction / split at the "other" rate
+        alg = (ALG_ADDSUB_PER_BIT_ITER * 4 * costs["machine_plain_cycles"]
+               + ALG_MODMUL_PER_BIT_ITER * 8 * costs["machine_other_cycles"]) / 64.0
+        fracs["algorithmic"] = {
+            "frac": alg / per_iter, "cycles_per_bit_iteration": alg,
+            "denominator": "SIMD cycles of the launch",
+            "numerator": "per bit-iteration %d field add/sub x 4 plain instructions + %d field multiplications x 8 instructions "
+                         "(4 v_mad_u64_u32 + 4 to reduce / split), per lane (/ 64), at the machine rates: the arithmetic "
+                         "the transforms cannot avoid; the rest of the issued cycles is representation overhead (packing to "
+                         "64-bit words, limb splits, per-lane shifts, zero-extension moves) and unshared issue slots" % (
+                             ALG_ADDSUB_PER_BIT_ITER, ALG_MODMUL_PER_BIT_ITER)}
+        out.update({"bound": "valu-issue", "achieved": cyc_machine * iters / (kernel_ms * 1e-3) / 1e9,
+                    "peak": SIMDS * clock, "unit": "G SIMD issue cycles/s",
+                    "frac": fracs["vs_measured_class_rates"]["frac"],
+                    "frac_is": "vs_measured_class_rates"})
+    else:
         flops = iters * 64.0 * k.get("f64_flops_per_lane", 0)
-        if costs is not None and clock:
-            # secondary reading: the transform is add/sub-dominated (fma = 2 flops is a quarter of its fp64
-            # instructions), so the fma peak is out of reach by construction; issue slots used / available
-            cyc = (k.get("valu_f64", 0) * costs.get("f64_fma_cycles", 4.0) + k.get("valu_full_rate", 0) * costs["full_rate_cycles"]
-                   + k.get("valu_half_rate", 0) * costs["half_rate_cycles"])
-            out["valu_issue"] = {"cycles_per_bit_iteration": cyc,
-                                 "frac": iters * cyc / (simds * clock * 1e9 * kernel_ms * 1e-3)}
-        out.update({"bound": "fp64-fma", "achieved": flops / (kernel_ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": flops / (kernel_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                    "model": "fp64 flops issued per bit-iteration (fma = 2): 64 lanes x %d" % k.get("f64_flops_per_lane", 0)})
+        fracs["fp64_fma_peak"] = {
+            "frac": flops / (kernel_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+            "denominator": "vector fp64 peak %.1f TFLOP/s (fma = 2 flops per lane)" % FP64_VECTOR_PEAK_TFLOPS,
+            "numerator": "fp64 flops issued: 64 lanes x %d per bit-iteration; three quarters of the fp64 instructions are "
+                         "add / sub / mul (1 flop), so 0.5 is the most this instruction mix can show" % k.get("f64_flops_per_lane", 0)}
+        out.update({"bound": "valu-issue (fp64)", "achieved": cyc_machine * iters / (kernel_ms * 1e-3) / 1e9,
+                    "peak": SIMDS * clock, "unit": "G SIMD issue cycles/s",
+                    "frac": fracs["vs_measured_class_rates"]["frac"], "frac_is": "vs_measured_class_rates",
+                    "fp64_tflops": flops / (kernel_ms * 1e-3) / 1e12})
+    out["fractions"] = fracs
     return out
+
+
+def keyswitch_roofline(bits, ks_ms, mfma):
+    """K2 (keyswitch stage = digit transpose + matrix-core product + finalize, HIP events around the three kernels)."""
+    if not ks_ms:
+        return None
+    if not mfma:
+        return {"kernel": "k_keyswitch_a (LDS row window; batches <= 2 x CUs bits) + finalize", "stage_ms": ks_ms,
+                "bound": "lds", "note": "small-batch kernel: no matrix-core line"}
+    ops = 2.0 * bits * 1024 * 8 * 4 * 500 * 4        # one-hot K = 1024 x 8 x 4 slots, 500 columns, 4 byte planes; MAC = 2
+    return {"kernel": "k_ks_digits_t + k_keyswitch_mfma (v_mfma_i32_16x16x64_i8, one-hot A) + k_keyswitch_finalize",
+            "stage_ms": ks_ms, "bound": "mfma", "achieved": ops / (ks_ms * 1e-3) / 1e12, "peak": MFMA_I8_PEAK_TOPS,
+            "unit": "TOP/s (int8)", "frac": ops / (ks_ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
+            "ops_per_launch": ops,
+            "note": "issued int8 multiply-adds of the one-hot product (3 of 4 K-slots multiply zeros by construction) over "
+                    "the WHOLE keyswitch stage incl. the pre-pass and finalize; the MFMA kernel alone is ~70 % of the stage "
+                    "(profiles/*_kernel_stats.csv)"}
 
 
 def cpu_baseline_and_parity(gate, sample_bits, cs_host, gpu_out):
@@ -473,7 +532,20 @@ def main():
         roof.update({"kernel": "k_bootstrap%s (fused mod-switch + blind rotate + extract)" % (
                          "_fft" if args.transform == "FFT" else ""),
                      "traffic": pmc_traffic(args.transform, args.gate, B),
-                     "kernel_ms": br_avg, "keyswitch_ms": ks_avg, "streaming_model": streaming})
+                     "kernel_ms": br_avg, "keyswitch_ms": ks_avg, "streaming_model": streaming,
+                     "keyswitch": keyswitch_roofline(B, ks_avg, B > 2 * 256)})
+        # self-check of the SIMD-partner pacing: the two waves of a SIMD must finish together (rounds x one
+        # wave's life time ~ kernel time) and the clock must not have sagged; a line that fails this was measured on a
+        # box / in a state where the kernel does not run as designed
+        rounds = -(-(B * n_rot) // (256 * 8))
+        checks = {}
+        if wave_ms:
+            checks["rounds"] = rounds
+            checks["wave_ms_x_rounds_over_kernel_ms"] = roof["wave_ms_in_kernel"] * rounds / br_avg
+            checks["pacing_ok"] = bool(checks["wave_ms_x_rounds_over_kernel_ms"] >= 0.9)
+        if live_clock:
+            checks["clock_ok"] = bool(live_clock >= 2.2 or args.transform == "FFT" and live_clock >= 2.0)
+        roof["self_check"] = checks
         result["roofline"] = roof
         result["per_rank_ms_per_step"] = per_rank_ms
         if gather_ms is not None:

@@ -247,6 +247,11 @@ int nufhe_profile_last(nufhe_ctx *ctx, float *blind_rotate_ms, float *keyswitch_
  * *shader_ghz = their ratio, *wave_ms = how long that wavefront ran (the kernel runs ceil(bits / (8 x CUs)) such
  * rounds).  Fails for batches that ran the small- or medium-batch kernels. */
 int nufhe_profile_clock(nufhe_ctx *ctx, double *shader_ghz, double *wave_ms);
+/* Start / end (ms after the first wave's start, from the constant 100 MHz counter) and SIMD number of every wave of
+ * work-group 0 of the last profiled wave-per-bit bootstrap launch (up to 8): two waves that share a SIMD are paced
+ * against each other (csrc/blind_rotate.h, BrPace) and must END together -- the self-check of bench.py and of
+ * tests/test_gpu_kernels.py::test_simd_partners_finish_together. */
+int nufhe_profile_waves(nufhe_ctx *ctx, double *start_ms, double *end_ms, int *simd, int capacity, int *count);
 
 #ifdef __cplusplus
 }

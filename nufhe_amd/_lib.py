@@ -86,6 +86,8 @@ PROTOTYPES = {
     "nufhe_profile_enable": [_vp, _int],
     "nufhe_profile_last": [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)],
     "nufhe_profile_clock": [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],
+    "nufhe_profile_waves": [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                            ctypes.POINTER(_int), _int, ctypes.POINTER(_int)],
 }
 
 _lib = None

@@ -50,7 +50,7 @@ struct nufhe_ctx {
     bool own_stream = false;
     u64 *d_tw1f = nullptr;
     u64 *d_tw1x = nullptr;    // forward table permuted for the limb-form transform (ntt_make_tw1x)
-    unsigned long long *d_clock = nullptr;   // BrLaunch::clock_probe target (2 words)
+    unsigned long long *d_clock = nullptr;   // BrLaunch::clock_probe target (CLOCK_PROBE_WORDS words)
     u64 *d_tw1i = nullptr;
     cplx *d_ftw1 = nullptr;
     cplx *d_ftw2 = nullptr;
@@ -235,8 +235,8 @@ int nufhe_ctx_create(int device, void *stream, int own_stream, nufhe_ctx **out)
     std::vector<u64> fx(1024);
     ntt_make_tw1x(fx.data(), f.data());
     hipError_t e = hipMalloc((void **)&ctx->d_tw1f, 1024 * sizeof(u64));
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_clock, 2 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(ctx->d_clock, 0, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_clock, CLOCK_PROBE_WORDS * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(ctx->d_clock, 0, CLOCK_PROBE_WORDS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_tw1x, 1024 * sizeof(u64));
     if (e == hipSuccess) e = hipMemcpy(ctx->d_tw1x, fx.data(), 1024 * sizeof(u64), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_tw1i, 1024 * sizeof(u64));
@@ -609,7 +609,7 @@ static int run_gate(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result
         P.out_b = result.b; P.out_b_stride = result.b_stride;
     }
     if (ctx->profile) {
-        HIP_TRY(hipMemsetAsync(ctx->d_clock, 0, 2 * sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->d_clock, 0, CLOCK_PROBE_WORDS * sizeof(unsigned long long), ctx->stream));
         HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
     }
     HIP_TRY(launch_bootstrap(P, key->transform, key->mask_size, ctx->team_max_bits, ctx->pair_max_bits, ctx->num_cus,
@@ -944,6 +944,31 @@ int nufhe_profile_clock(nufhe_ctx *ctx, double *shader_ghz, double *wave_ms)
     if (h[1] == 0) return fail(NUFHE_EINVAL, "the last profiled launch did not run a wave-per-bit kernel");
     if (shader_ghz) *shader_ghz = (double)h[0] / ((double)h[1] * 10.0);     // 100 MHz ticks = 10 ns
     if (wave_ms) *wave_ms = (double)h[1] * 1e-5;
+    return NUFHE_OK;
+}
+
+int nufhe_profile_waves(nufhe_ctx *ctx, double *start_ms, double *end_ms, int *simd, int capacity, int *count)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!ctx->ev_valid) return fail(NUFHE_EINVAL, "no profiled launch recorded");
+    if (!start_ms || !end_ms || !simd || !count || capacity < 1) return fail(NUFHE_EINVAL, "null argument");
+    HIP_TRY(hipEventSynchronize(ctx->ev[2]));
+    unsigned long long h[CLOCK_PROBE_WORDS];
+    HIP_TRY(hipMemcpy(h, ctx->d_clock, sizeof(h), hipMemcpyDeviceToHost));
+    unsigned long long first = ~0ull;
+    for (int w = 0; w < 8; w++)
+        if (h[4 + 3 * w] && h[2 + 3 * w] < first) first = h[2 + 3 * w];
+    int n = 0;
+    for (int w = 0; w < 8 && n < capacity; w++) {
+        if (!h[4 + 3 * w]) continue;
+        start_ms[n] = (double)(h[2 + 3 * w] - first) * 1e-5;      // 100 MHz ticks
+        end_ms[n] = (double)(h[3 + 3 * w] - first) * 1e-5;
+        simd[n] = (int)h[4 + 3 * w] - 1;
+        n++;
+    }
+    *count = n;
+    if (n == 0) return fail(NUFHE_EINVAL, "the last profiled launch did not run a wave-per-bit kernel");
     return NUFHE_OK;
 }
 

@@ -17,6 +17,8 @@ struct BrJob {
 
 // Fused bootstrap launch: global bit g in [0, nbits_total); job = g / bits_per_job (at most 2 jobs:
 // MUX runs its two blind rotations in one launch), bit = g % bits_per_job.
+#define CLOCK_PROBE_WORDS (2 + 3 * 8)
+
 struct BrLaunch {
     BrJob job[2];
     long bits_per_job;
@@ -32,7 +34,7 @@ struct BrLaunch {
     const void *tw_b;     // NTT: tw1i u64[1024]; FFT: tw2 complex[64]
     // profiling only (nufhe_profile_enable), else nullptr: wave 0 of work-group 0 of the wave-per-bit kernels stores
     // how long it lived, {shader-clock ticks (s_memtime), constant 100 MHz ticks (s_memrealtime)}
-    unsigned long long *clock_probe;
+    unsigned long long *clock_probe;     // nullptr or CLOCK_PROBE_WORDS words (ClockProbe, kernels.hip)
 };
 
 struct KsLaunch {

@@ -82,18 +82,32 @@ __device__ __forceinline__ BrLds carve_br_lds(int wave)
     return lds;
 }
 
-// life time of one wave in both clocks (BrLaunch::clock_probe): the sustained shader clock of the launch is their ratio
+// life time of the waves of work-group 0 in both clocks (BrLaunch::clock_probe): words [0], [1] = shader-clock and
+// 100 MHz ticks of wave 0 (their ratio is the sustained shader clock of the launch); then, for each of its up to 8
+// waves w, words [2 + 3 w ..] = start, end (100 MHz ticks) and 1 + the SIMD the wave ran on -- what the pacing
+// self-check reads (two waves that share a SIMD must end together)
 struct ClockProbe {
     long long t0, r0;
     __device__ __forceinline__ void begin(const BrLaunch &P)
     {
-        if (P.clock_probe && blockIdx.x == 0 && threadIdx.x == 0) { t0 = clock64(); r0 = wall_clock64(); }
+        if (P.clock_probe && blockIdx.x == 0 && (threadIdx.x & 63) == 0) { t0 = clock64(); r0 = wall_clock64(); }
     }
     __device__ __forceinline__ void end(const BrLaunch &P) const
     {
-        if (P.clock_probe && blockIdx.x == 0 && threadIdx.x == 0) {
-            P.clock_probe[0] = (unsigned long long)(clock64() - t0);
-            P.clock_probe[1] = (unsigned long long)(wall_clock64() - r0);
+        if (P.clock_probe && blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
+            const long long t1 = clock64(), r1 = wall_clock64();
+            const unsigned wave = threadIdx.x >> 6;
+            if (wave == 0) {
+                P.clock_probe[0] = (unsigned long long)(t1 - t0);
+                P.clock_probe[1] = (unsigned long long)(r1 - r0);
+            }
+            if (wave < 8) {
+                unsigned hw;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+                P.clock_probe[2 + 3 * wave] = (unsigned long long)r0;
+                P.clock_probe[3 + 3 * wave] = (unsigned long long)r1;
+                P.clock_probe[4 + 3 * wave] = 1ull + ((hw >> 4) & 3u);
+            }
         }
     }
 };

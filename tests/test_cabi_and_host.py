@@ -149,7 +149,7 @@ def test_ciphertext_view_indexing_with_ellipsis():
 
 def test_tracked_profile_inputs_of_the_bench_roofline_are_current():
     """bench.py's issue roofline multiplies the ISA counts of profiles/isa_mix.json by the measured
-    class costs of profiles/valu_class_costs.json: the counts must belong to the CURRENT device sources
+    class costs of profiles/valu_issue_costs.json: the counts must belong to the CURRENT device sources
     (tools/isa_mix.py --write records a hash of nufhe_amd/csrc)."""
     import importlib.util
     import json
@@ -164,8 +164,12 @@ def test_tracked_profile_inputs_of_the_bench_roofline_are_current():
     # the loop of the NTT kernel is allowed a handful of spilled dwords (5 stores + 5 loads per iteration measured
     # faster than the spill-free code generation), not the hundreds of bytes of a lost allocation
     assert mix['k_bootstrap<1>']['scratch_bytes'] <= 64 and mix['k_bootstrap<1>'].get('scratch', 0) <= 16
-    costs = json.load(open(os.path.join(ROOT, 'profiles', 'valu_class_costs.json')))
-    assert 2.0 <= costs['full_rate_cycles'] < costs['half_rate_cycles'] <= 6.0
+    for kernel in ('k_bootstrap<1>', 'k_bootstrap_fft'):
+        assert mix[kernel]['valu_plain'] + mix[kernel]['valu_other'] == mix[kernel]['valu']
+    costs = json.load(open(os.path.join(ROOT, 'profiles', 'valu_issue_costs.json')))
+    assert 2.0 <= costs['machine_plain_cycles'] < costs['machine_other_cycles'] <= 5.0
+    assert costs['two_wave_plain_cycles'] < 2.5 and costs['plain_cycles']['1'] > 4.0      # pairing needs two waves
+    assert os.path.isfile(os.path.join(ROOT, 'profiles', costs['source']))
     for name in ('pmc_NTT.json', 'pmc_FFT.json', 'pmc_traffic.json'):
         assert os.path.isfile(os.path.join(ROOT, 'profiles', name))
 

@@ -104,6 +104,49 @@ def test_extract(thr, H, golden):
     assert (H.host(ra) == golden['tlwe_extract_a']).all() and (H.host(rb) == golden['tlwe_extract_b']).all()
 
 
+def test_simd_partners_finish_together(thr):
+    """The throughput kernels put two one-bit waves on every SIMD and pace them against each other (BrPace,
+    csrc/blind_rotate.h): the arbiter alone would let the older wave run ahead and leave the younger one a third of
+    the kernel ALONE at ~60 % issue utilisation (46 ms instead of 39 for the 4096-bit NAND).  On a batch of 8 x CUs
+    bits the waves of work-group 0 that share a SIMD must end within 2 % of the kernel time of each other, and every
+    wave must live to (almost) the end of the kernel -- for both transforms."""
+    import ctypes
+    import nufhe_amd
+    from nufhe_amd import _lib
+    L = _lib.lib()
+    cus = thr.device_params.compute_units
+    B = 8 * cus
+    for transform in ('NTT', 'FFT'):
+        ctx = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(5), thread=thr)
+        sk, ck = ctx.make_key_pair(transform_type=transform)
+        vm = ctx.make_virtual_machine(ck)
+        rs = numpy.random.RandomState(3)
+        c1 = ctx.encrypt(sk, rs.randint(0, 2, size=B).astype(bool)); c2 = ctx.encrypt(sk, rs.randint(0, 2, size=B).astype(bool))
+        out = vm.empty_ciphertext((B,))
+        vm.gate_nand(c1, c2, dest=out)                      # warm-up
+        L.nufhe_profile_enable(thr.handle, 1)
+        try:
+            vm.gate_nand(c1, c2, dest=out)
+            br = ctypes.c_float(); ks = ctypes.c_float()
+            _lib.check(L.nufhe_profile_last(thr.handle, ctypes.byref(br), ctypes.byref(ks)))
+            start = (ctypes.c_double * 8)(); end = (ctypes.c_double * 8)(); simd = (ctypes.c_int * 8)(); n = ctypes.c_int()
+            _lib.check(L.nufhe_profile_waves(thr.handle, start, end, simd, 8, ctypes.byref(n)))
+        finally:
+            L.nufhe_profile_enable(thr.handle, 0)
+        assert n.value == 8
+        kernel_ms = br.value
+        by_simd = {}
+        for w in range(8):
+            by_simd.setdefault(simd[w], []).append(end[w])
+        assert sorted(len(v) for v in by_simd.values()) == [2, 2, 2, 2], by_simd     # two waves on each of the 4 SIMDs
+        spread = max(abs(v[0] - v[1]) for v in by_simd.values())
+        print("%s: kernel %.2f ms, wave ends %s ms, largest partner gap %.3f ms" % (
+            transform, kernel_ms, [round(end[w], 2) for w in range(8)], spread))
+        assert spread <= 0.02 * kernel_ms, (transform, spread, kernel_ms)
+        assert min(end[w] for w in range(8)) >= 0.93 * kernel_ms
+        del vm, ck
+
+
 def test_tgsw_decompose_vs_reference_golden(thr, H, golden):
     """the gadget decomposition as a standalone device call (test/test_tgsw.py:44-69): full-range accumulators with
     the boundary values in front, against the output of the reference's tgsw_polynomial_decomp_trf_reference"""

@@ -16,6 +16,7 @@ tests/test_cabi_and_host.py can tell when it is stale.
 """
 import collections
 import hashlib
+import importlib.util
 import json
 import os
 import re
@@ -37,6 +38,13 @@ def source_hash():
             h.update(name.encode())
             h.update(open(os.path.join(CSRC, name), 'rb').read())
     return h.hexdigest()[:16]
+
+
+def _asm_sched():
+    spec = importlib.util.spec_from_file_location('asm_sched', os.path.join(ROOT, 'tools', 'asm_sched.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def strip(op):
@@ -62,6 +70,13 @@ def loop_body(lines):
 
 def count(body):
     c = collections.Counter()
+    sched = _asm_sched()
+    for l in body:
+        t = l.split(';')[0].strip()
+        if t.startswith('v_'):
+            # issue classes of profiles/valu_issue_costs.json: "plain" = the VOP1/VOP2 instructions that can share an
+            # issue slot with another wave's plain instruction (no SGPR / VCC operand, no SDWA / DPP / VOP3 form)
+            c['valu_plain' if sched.Inst(t, 0).plain else 'valu_other'] += 1
     for l in body:
         mm = re.match(r'^\s+([a-z_0-9]+)', l)
         if not mm:
