@@ -70,7 +70,15 @@ FF_FN u32 brf_prologue(const BrSource &s0, const BrSource &s1, i32 c0, long bit,
 // software-pipelined in groups of BRF_KEY_GROUP: the next group is in flight while the current one is
 // multiplied -- left to itself the compiler hoists all 32 loads (128 VGPRs) above the arithmetic and
 // spills part of the accumulator to scratch.
+#ifndef BRF_KEY_GROUP
 #define BRF_KEY_GROUP 2
+#endif
+#ifndef BRF_KEY_DEPTH
+#define BRF_KEY_DEPTH 2      /* wave kernel: groups in flight ahead of the one being multiplied: 2 = 8 more VGPRs, 255 in all, no
+                                scratch, K1 12.59 -> 12.30 ms; 3 spills (72 bytes), group 4 x depth 2 is 12.20 ms with 52 bytes
+                                of scratch (profiles/r03_fft_key_prefetch_variants.txt) */
+#endif
+template <int D = 1>
 FF_FN void brf_mac_pair(cplx (&sum)[2][8], const cplx (&x)[2][8], const cplx *row, int m, int lane)
 {
     // group g: polynomial (m, d, mo) = g / GROUPS_PER_POLY, registers GROUP * (g % GROUPS_PER_POLY) ...
@@ -80,25 +88,29 @@ FF_FN void brf_mac_pair(cplx (&sum)[2][8], const cplx (&x)[2][8], const cplx *ro
         const int poly = g / GPP, r = BRF_KEY_GROUP * (g % GPP) + i;    // poly = d * 2 + mo
         return base + poly * BKF_POLY_ELEMS + r * 64;
     };
-    cplx k[BRF_KEY_GROUP], n[BRF_KEY_GROUP];
+    cplx q[D + 1][BRF_KEY_GROUP];          // ring of pending groups: q[j] belongs to group g + j
 #pragma unroll
-    for (int i = 0; i < BRF_KEY_GROUP; i++) k[i] = *addr(0, i);
+    for (int j = 0; j < D; j++)
+#pragma unroll
+        for (int i = 0; i < BRF_KEY_GROUP; i++) q[j][i] = *addr(j, i);
 #pragma unroll
     for (int g = 0; g < NG; g++) {
-        if (g + 1 < NG) {
+        if (g + D < NG) {
 #pragma unroll
-            for (int i = 0; i < BRF_KEY_GROUP; i++) n[i] = *addr(g + 1, i);
+            for (int i = 0; i < BRF_KEY_GROUP; i++) q[D][i] = *addr(g + D, i);
             BR_ISSUE_FENCE();
         }
         const int d = (g / GPP) >> 1, mo = (g / GPP) & 1;
 #pragma unroll
         for (int i = 0; i < BRF_KEY_GROUP; i++) {
             const int r = BRF_KEY_GROUP * (g % GPP) + i;
-            sum[mo][r].re += x[d][r].re * k[i].re - x[d][r].im * k[i].im;
-            sum[mo][r].im += x[d][r].re * k[i].im + x[d][r].im * k[i].re;
+            sum[mo][r].re += x[d][r].re * q[0][i].re - x[d][r].im * q[0][i].im;
+            sum[mo][r].im += x[d][r].re * q[0][i].im + x[d][r].im * q[0][i].re;
         }
 #pragma unroll
-        for (int i = 0; i < BRF_KEY_GROUP; i++) k[i] = n[i];
+        for (int j = 0; j < D; j++)
+#pragma unroll
+            for (int i = 0; i < BRF_KEY_GROUP; i++) q[j][i] = q[j + 1][i];
     }
 }
 
@@ -123,7 +135,7 @@ FF_FN void brf_external_product(u32 (&res)[2][16], const u32 (&T)[2][16], const 
         }
         fft_forward_n<2>(x, bufs, lds.tw1, tw2, L);
         BR_PROBE_MARK(2 * m);
-        brf_mac_pair(sum, x, row, m, L.lane);
+        brf_mac_pair<BRF_KEY_DEPTH>(sum, x, row, m, L.lane);       // (the 2-waves-per-bit kernel keeps depth 1: no registers to spare)
 #if defined(__HIP_DEVICE_COMPILE__)
         // keep the key loads of the next polynomial below this point (register pressure)
         asm volatile("" ::: "memory");

@@ -83,26 +83,28 @@ FF_FN void dft8(cplx (&x)[8])
     cplx u1 = c_add(x[1], x[5]), v1 = c_sub(x[1], x[5]);
     cplx u2 = c_add(x[2], x[6]), v2 = c_sub(x[2], x[6]);
     cplx u3 = c_add(x[3], x[7]), v3 = c_sub(x[3], x[7]);
-    // twiddles E^j on v_j, E = exp(-+ 2 pi i/8)
+    // twiddles E^j on v_j, E = exp(-+ 2 pi i/8).  E^1 and E^3 carry the factor s = 1/sqrt 2: it is NOT applied to
+    // v1, v3 (2 multiplications each) but folded into the last stage, whose additions become fused multiply-adds
+    // x = q +- s q' (same instruction count there, one rounding less per output)
     if (!INV) {
-        v1 = cplx{(v1.re + v1.im) * s, (v1.im - v1.re) * s};     // * (1 - i)/sqrt2
+        v1 = cplx{v1.re + v1.im, v1.im - v1.re};                 // * (1 - i)        [* s pending]
         v2 = c_mul_mi(v2);
-        v3 = cplx{(v3.im - v3.re) * s, -(v3.re + v3.im) * s};    // * (-1 - i)/sqrt2
+        v3 = cplx{v3.im - v3.re, -(v3.re + v3.im)};              // * (-1 - i)       [* s pending]
     } else {
-        v1 = cplx{(v1.re - v1.im) * s, (v1.re + v1.im) * s};     // * (1 + i)/sqrt2
+        v1 = cplx{v1.re - v1.im, v1.re + v1.im};                 // * (1 + i)        [* s pending]
         v2 = c_mul_pi(v2);
-        v3 = cplx{-(v3.re + v3.im) * s, (v3.re - v3.im) * s};    // * (-1 + i)/sqrt2
+        v3 = cplx{-(v3.re + v3.im), v3.re - v3.im};              // * (-1 + i)       [* s pending]
     }
     // stage 1
     cplx p0 = c_add(u0, u2), p2 = c_sub(u0, u2);
     cplx p1 = c_add(u1, u3), p3 = INV ? c_mul_pi(c_sub(u1, u3)) : c_mul_mi(c_sub(u1, u3));
     cplx q0 = c_add(v0, v2), q2 = c_sub(v0, v2);
-    cplx q1 = c_add(v1, v3), q3 = INV ? c_mul_pi(c_sub(v1, v3)) : c_mul_mi(c_sub(v1, v3));
+    cplx q1 = c_add(v1, v3), q3 = INV ? c_mul_pi(c_sub(v1, v3)) : c_mul_mi(c_sub(v1, v3));     // [* s pending]
     // stage 2
     x[0] = c_add(p0, p1); x[1] = c_sub(p0, p1);
     x[2] = c_add(p2, p3); x[3] = c_sub(p2, p3);
-    x[4] = c_add(q0, q1); x[5] = c_sub(q0, q1);
-    x[6] = c_add(q2, q3); x[7] = c_sub(q2, q3);
+    x[4] = cplx{fma(s, q1.re, q0.re), fma(s, q1.im, q0.im)};  x[5] = cplx{fma(-s, q1.re, q0.re), fma(-s, q1.im, q0.im)};
+    x[6] = cplx{fma(s, q3.re, q2.re), fma(s, q3.im, q2.im)};  x[7] = cplx{fma(-s, q3.re, q2.re), fma(-s, q3.im, q2.im)};
 }
 
 // compile-time constants g^j2 = exp(-i pi j2/16), j2 = 0..7
