@@ -60,6 +60,26 @@ __device__ __forceinline__ void body(uint32_t (&a)[16], uint64_t (&w)[8], uint32
         else if (OP == 32) A1("v_alignbit_b32 %0, %0, %1, 24");
         else if (OP == 33) A1("v_and_or_b32 %0, %0, %1, %2");
         else if (OP == 34) A1("v_lshl_or_b32 %0, %0, 8, %1");
+        else if (OP == 60) asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(w[i % 8]) : "v"(a[i % 16]));
+        else if (OP == 61) asm volatile("v_add_f64 %0, %0, %0" : "+v"(w[i % 8]));
+        else if (OP == 62) asm volatile("v_mul_f64 %0, %0, %0" : "+v"(w[i % 8]));
+        else if (OP == 63) asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(a[i % 16]) : "v"(w[i % 8]));
+        else if (OP == 64) asm volatile("v_rndne_f64 %0, %0" : "+v"(w[i % 8]));
+        else if (OP == 65) asm volatile("v_ldexp_f64 %0, %0, %1" : "+v"(w[i % 8]) : "v"(c));
+        else if (OP == 66) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i % 16]) : "v"(b));
+        else if (OP == 67) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(a[i % 16]) : "v"(b), "s"(((uint64_t)sc << 32) | sc));
+        else if (OP == 68) asm volatile("v_cmp_lt_u32 vcc, %0, %1" :: "v"(a[i % 16]), "v"(b) : "vcc");
+        else if (OP == 69) asm volatile("v_lshlrev_b64 %0, 3, %0" : "+v"(w[i % 8]));
+        else if (OP == 70) asm volatile("v_bfe_u32 %0, %0, 3, 10" : "+v"(a[i % 16]));
+        else if (OP == 71) asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(w[i % 8]) : "v"(a[i % 16]));
+        else if (OP == 72) { if (i % 2 == 0) asm volatile("v_cmp_lt_u32 vcc, %0, %1" :: "v"(a[i % 16]), "v"(b) : "vcc"); else asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i % 16]) : "v"(b)); }
+        else if (OP == 73) { if (i % 5 == 0) asm volatile("v_cmp_lt_u32 vcc, %0, %1" :: "v"(a[i % 16]), "v"(b) : "vcc"); else asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i % 16]) : "v"(b)); }
+        else if (OP == 74) { if (i % 5 == 0) asm volatile("v_cmp_lt_u32 s[40:41], %0, %1" :: "v"(a[i % 16]), "v"(b) : "s40", "s41"); else asm volatile("v_cndmask_b32 %0, %0, %1, s[40:41]" : "+v"(a[i % 16]) : "v"(b)); }
+        else if (OP == 75) { if (i % 64 == 0) asm volatile("s_mov_b64 vcc, s[40:41]" ::: "vcc"); else asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i % 16]) : "v"(b)); }
+        else if (OP == 76) { if (i % 64 == 0) asm volatile("v_cmp_lt_u32 vcc, %0, %1" :: "v"(a[i % 16]), "v"(b) : "vcc"); else asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i % 16]) : "v"(b)); }
+        else if (OP == 77) { if (i % 64 == 0) asm volatile("v_cmp_lt_u32 s[40:41], %0, %1" :: "v"(a[i % 16]), "v"(b) : "s40", "s41"); else asm volatile("v_cndmask_b32 %0, %0, %1, s[40:41]" : "+v"(a[i % 16]) : "v"(b)); }
+        else if (OP == 78) asm volatile("v_addc_co_u32 %0, s[40:41], %0, %1, s[40:41]" : "+v"(a[i % 16]) : "v"(b) : "s40", "s41");
+        else if (OP == 79) { if (i % 2 == 0) asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(a[i % 16]) : "v"(b) : "vcc"); else asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(a[i % 16]) : "v"(b) : "vcc"); }
         else if (OP == 40) { if (i % 16 < 8) A1("v_add_u32 %0, %0, %1"); else A1("v_lshl_add_u32 %0, %0, 3, %1"); }
         else if (OP == 41) { if (i % 64 < 32) A1("v_add_u32 %0, %0, %1"); else A1("v_lshl_add_u32 %0, %0, 3, %1"); }
         else if (OP == 42) { if (i % 256 < 128) A1("v_add_u32 %0, %0, %1"); else A1("v_lshl_add_u32 %0, %0, 3, %1"); }
@@ -295,6 +315,26 @@ int main()
     run_op<16>("v_pk_fma_f32", d_out, d_cyc);
     run_op<15>("v_fma_f64", d_out, d_cyc);
     run_op<29>("blend 3 add : 2 lshl_add", d_out, d_cyc);
+    run_op<60>("v_cvt_f64_i32", d_out, d_cyc);
+    run_op<71>("v_cvt_f64_u32", d_out, d_cyc);
+    run_op<63>("v_cvt_i32_f64", d_out, d_cyc);
+    run_op<61>("v_add_f64", d_out, d_cyc);
+    run_op<62>("v_mul_f64", d_out, d_cyc);
+    run_op<64>("v_rndne_f64", d_out, d_cyc);
+    run_op<65>("v_ldexp_f64", d_out, d_cyc);
+    run_op<66>("v_cndmask_b32 vcc", d_out, d_cyc);
+    run_op<67>("v_cndmask_b32 sgpr pair", d_out, d_cyc);
+    run_op<68>("v_cmp_lt_u32 -> vcc", d_out, d_cyc);
+    run_op<69>("v_lshlrev_b64", d_out, d_cyc);
+    run_op<70>("v_bfe_u32", d_out, d_cyc);
+    run_op<72>("1 v_cmp vcc : 1 cndmask vcc", d_out, d_cyc);
+    run_op<73>("1 v_cmp vcc : 4 cndmask vcc", d_out, d_cyc);
+    run_op<74>("1 v_cmp sgpr : 4 cndmask sgpr", d_out, d_cyc);
+    run_op<75>("s_mov vcc : 63 cndmask vcc", d_out, d_cyc);
+    run_op<76>("1 v_cmp vcc : 63 cndmask vcc", d_out, d_cyc);
+    run_op<77>("1 v_cmp sgpr : 63 cndmask sgp", d_out, d_cyc);
+    run_op<78>("v_addc_co_u32 sgpr pair", d_out, d_cyc);
+    run_op<79>("add_co vcc : addc vcc", d_out, d_cyc);
     printf("\nstreams that alternate classes (same stream on every wave):\n");
     run_op<43>("1 add : 1 lshl_add", d_out, d_cyc);
     run_op<44>("2 add : 2 lshl_add", d_out, d_cyc);
