@@ -569,7 +569,8 @@ def main():
             result["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:
             nthreads = os.cpu_count() or 1
-            sample = min(B, args.cpu_sample_bits or max(16, min(256, 4 * nthreads)))
+            # ~10-20 s of oracle time for the headline gate on the box's 128 host threads (about 17 ms per bit)
+            sample = min(B, args.cpu_sample_bits or max(16, min(768, 6 * nthreads)))
 
             def host(ct):
                 return tuple(x.detach().cpu().numpy() for x in (ct.a, ct.b, ct.current_variances))
