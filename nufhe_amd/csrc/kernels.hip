@@ -374,6 +374,9 @@ __device__ __forceinline__ BrFftLds carve_brf_lds(int wave)
 
 __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_bootstrap_fft(BrLaunch P)
 {
+#if defined(BR_PROBE)
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_br_probe[8] = wall_clock64();
+#endif
     load_ftables((const cplx *)P.tw_a, (const cplx *)P.tw_b);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long gbit = (long)blockIdx.x * (blockDim.x >> 6) + wave;   // waves per group chosen at launch
@@ -390,9 +393,19 @@ __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_bootstrap_fft(BrLaunch 
     u32 acc[2][16];
     ClockProbe probe;
     probe.begin(P);
+#if defined(BR_PROBE)
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_br_probe[9] = wall_clock64();
+#endif
     brf_blind_rotate(acc, (const cplx *)P.bk, P.n, barb, P.mu, lds, L);
     probe.end(P);
+#if defined(BR_PROBE)
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_br_probe[10] = wall_clock64();
+#endif
     br_extract<1>(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, acc, lane);
+#if defined(BR_PROBE)
+    __threadfence();
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_br_probe[11] = wall_clock64();
+#endif
 }
 
 // Medium batches, FFT (CUs < bits <= 3 x CUs): two waves per bit, up to 3 pairs per work-group (blind_rotate_fft.h,
