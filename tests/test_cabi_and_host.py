@@ -8,6 +8,7 @@ reference's.
 import ctypes
 import os
 import re
+import sys
 
 import numpy
 import pytest
@@ -208,3 +209,24 @@ def test_keyswitch_byte_plane_formulation_is_exact():
         assert abs(cp).max() < 2**21 * (J * 8) // 8192 + 2**12                             # far inside int32
         total += cp << (8 * p)
     assert ((-total) % 2**32 == direct).all()
+
+
+def test_bench_roofline_helpers_on_tracked_profiles():
+    """bench.py's roofline section is computed from tracked files after the timed region: a KeyError there would lose a
+    whole GPU run.  Exercise it with the kernel times of round 3 and check that every fraction names its denominator."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module('bench')
+    for transform, ms, clock in (('NTT', 39.4, 2.39), ('FFT', 12.4, 2.26)):
+        r = bench.issue_roofline(transform, 4096, 1, 500, ms, clock)
+        assert r['frac_is'] == 'vs_measured_class_rates' and 0.3 < r['frac'] < 1.0
+        assert abs(r['frac'] - r['fractions']['vs_measured_class_rates']['frac']) < 1e-12
+        for name, f in r['fractions'].items():
+            assert 0.0 < f['frac'] < 1.5 and f['denominator'] and f['numerator'], name
+        assert r['fractions']['vs_nominal_2_cycle_issue']['frac'] < r['frac']
+        assert r['isa_mix_per_iteration']['valu_plain'] + r['isa_mix_per_iteration']['valu_other'] == r['isa_mix_per_iteration']['valu']
+    assert 'algorithmic' in bench.issue_roofline('NTT', 4096, 1, 500, 39.4, 2.39)['fractions']
+    k2 = bench.keyswitch_roofline(4096, 0.30, True)
+    assert k2['bound'] == 'mfma' and 0.2 < k2['frac'] < 0.6
+    assert bench.keyswitch_roofline(256, 0.2, False)['bound'] == 'lds'
+    assert bench.pmc_traffic('NTT', 'nand', 4096) > 1e8
