@@ -481,18 +481,27 @@ FF_FN void brt_step(u32 a, const u64 *row, const BrTeamLds &lds, const NttLane &
         const u32 T = ((t & 1024u) ? 0u - v : v) - (u32)lds.acc[m * 1024 + j];
         dg[r] = (((i32)(T + TGSW_OFFSET) >> sh) & 1023) - 512;
     }
+    // The wave is alone on its SIMD, so nothing hides the latency of its key loads: all 32 (its two key polynomials,
+    // 64 VGPRs -- the team kernel has them to spare) are issued HERE, before the forward transform, and have long
+    // arrived when the products need them.
+    u64 kq[2][16];
+    {
+        const u64 *kp = row + (long)w * 2 * BK_POLY_ELEMS + lane * 2;
+#pragma unroll
+        for (int mo = 0; mo < 2; mo++)
+#pragma unroll
+            for (int h = 0; h < 8; h++) {
+                kq[mo][2 * h] = kp[mo * BK_POLY_ELEMS + h * 128];
+                kq[mo][2 * h + 1] = kp[mo * BK_POLY_ELEMS + h * 128 + 1];
+            }
+        BR_ISSUE_FENCE();
+    }
     u64 x[16];
     ntt_forward_small_l4(x, dg, lds.xbuf, lds.tw1x, L);
-    u64 ps[2][16];
 #pragma unroll
     for (int mo = 0; mo < 2; mo++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) ps[mo][r] = 0;
-    br_mac<1>(ps, x, row + (long)w * 2 * BK_POLY_ELEMS, lane);
-#pragma unroll
-    for (int mo = 0; mo < 2; mo++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) lds.part[((w * 2 + mo) * 16 + r) * 64 + lane] = ps[mo][r];
+        for (int r = 0; r < 16; r++) lds.part[((w * 2 + mo) * 16 + r) * 64 + lane] = ff_mul(x[r], kq[mo][r]);
     team_sync();
     if (w < 2) {
         u64 sum[16];
