@@ -231,6 +231,11 @@ int nufhe_ctx_set_team_max_bits(nufhe_ctx *ctx, long bits);
  * k = 2, either transform: any non-zero value enables the 3-wavefront kernel without a partial-sum buffer for every
  * batch above the small-batch limit (rounds of 2 x CUs bits; with 0 the one-wavefront-per-bit kernels run instead). */
 int nufhe_ctx_set_pair_max_bits(nufhe_ctx *ctx, long bits);
+/* NTT, k = 1: batches up to the team limit run EIGHT wavefronts per bit (two per digit transform, the two half rings of
+ * X^1024 + 1 = (X^512 - i)(X^512 + i); csrc/ntt512_half.h) instead of four -- 5.0 ms instead of 5.8 ms per gate (measured); the key
+ * is kept a second time in the half-ring layout (made on first use).  0 switches back to the 4-wave team kernel (default
+ * 1).  Identical results either way. */
+int nufhe_ctx_set_team8(nufhe_ctx *ctx, int enable);
 /* Keyswitch kernel.  The matrix-core kernel writes the digit selection as a one-hot int8 matrix product against the
  * key split into four signed byte planes (v_mfma_i32_16x16x64_i8); the LDS-window kernel gathers key rows by digit.
  * mode 1 (default): matrix cores for batches of more than 2 x CUs bits (0.30 vs 1.15 ms at 4096 bits), the LDS-window

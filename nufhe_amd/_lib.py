@@ -50,6 +50,7 @@ PROTOTYPES = {
     "nufhe_cloudkey_create": [_vp, _int, _int, _int, _pp],
     "nufhe_ctx_set_team_max_bits": [_vp, _long],
     "nufhe_ctx_set_pair_max_bits": [_vp, _long],
+    "nufhe_ctx_set_team8": [_vp, _int],
     "nufhe_ctx_set_keyswitch_mfma": [_vp, _int],
     "nufhe_ff_op": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _long],
     "nufhe_ks_make": [_vp, _vp, _vp, _vp, _vp, ctypes.c_float],

@@ -50,6 +50,8 @@ struct nufhe_ctx {
     bool own_stream = false;
     u64 *d_tw1f = nullptr;
     u64 *d_tw1x = nullptr;    // forward table permuted for the limb-form transform (ntt_make_tw1x)
+    u64 *d_nth = nullptr;     // table block of the half-ring transforms (ntt512_half.h, NTH_TABLE_ELEMS)
+    int team8 = 1;            // smallest NTT batches on the 8-waves-per-bit half-ring kernel (nufhe_ctx_set_team8)
     unsigned long long *d_clock = nullptr;   // BrLaunch::clock_probe target (CLOCK_PROBE_WORDS words)
     u64 *d_tw1i = nullptr;
     cplx *d_ftw1 = nullptr;
@@ -71,6 +73,8 @@ struct nufhe_cloudkey {
     long bk_polys() const { return (long)n * (mask_size + 1) * 2 * (mask_size + 1); }
     int ext_size() const { return mask_size * 1024; }
     void *d_bk = nullptr;     // wave layout: u64 [n][8][1024] or complex128 [n][8][512] (same bytes)
+    u64 *d_bk_half = nullptr; // NTT, k = 1: the same key in the half-ring layout of k_bootstrap_team8, made on first use
+    bool bk_half_valid = false;
     i32 *d_ks_a3 = nullptr;   // [k*1024][8][3][n]
     signed char *d_ks_planes = nullptr;   // the same key as signed byte planes in MFMA operand order (k_ks_planes)
     i32 *d_ks_b = nullptr;    // [k*1024][8][4]
@@ -237,6 +241,12 @@ int nufhe_ctx_create(int device, void *stream, int own_stream, nufhe_ctx **out)
     hipError_t e = hipMalloc((void **)&ctx->d_tw1f, 1024 * sizeof(u64));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_clock, CLOCK_PROBE_WORDS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(ctx->d_clock, 0, CLOCK_PROBE_WORDS * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_nth, NTH_TABLE_ELEMS * sizeof(u64));
+    if (e == hipSuccess) {
+        std::vector<u64> nth(NTH_TABLE_ELEMS);
+        nth_make_tables(nth.data());
+        e = hipMemcpy(ctx->d_nth, nth.data(), NTH_TABLE_ELEMS * sizeof(u64), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_tw1x, 1024 * sizeof(u64));
     if (e == hipSuccess) e = hipMemcpy(ctx->d_tw1x, fx.data(), 1024 * sizeof(u64), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_tw1i, 1024 * sizeof(u64));
@@ -265,6 +275,7 @@ int nufhe_ctx_destroy(nufhe_ctx *ctx)
     hipStreamSynchronize(ctx->stream);
     if (ctx->d_tw1f) hipFree(ctx->d_tw1f);
     if (ctx->d_tw1x) hipFree(ctx->d_tw1x);
+    if (ctx->d_nth) hipFree(ctx->d_nth);
     if (ctx->d_clock) hipFree(ctx->d_clock);
     if (ctx->d_tw1i) hipFree(ctx->d_tw1i);
     if (ctx->d_ftw1) hipFree(ctx->d_ftw1);
@@ -361,6 +372,7 @@ int nufhe_cloudkey_destroy(nufhe_cloudkey *key)
     hipSetDevice(key->ctx->device);
     hipStreamSynchronize(key->ctx->stream);
     if (key->d_bk) hipFree(key->d_bk);
+    if (key->d_bk_half) hipFree(key->d_bk_half);
     if (key->d_ks_a3) hipFree(key->d_ks_a3);
     if (key->d_ks_planes) hipFree(key->d_ks_planes);
     if (key->d_ks_b) hipFree(key->d_ks_b);
@@ -390,7 +402,7 @@ int nufhe_bk_upload_reference(nufhe_cloudkey *key, const void *h_bk)
     hipError_t e = hipMemcpyAsync(tmp, h_bk, bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess)
         e = key->transform == NUFHE_TRANSFORM_NTT
-                ? launch_bk_from_reference((u64 *)key->d_bk, tmp, key->bk_polys(), ctx->stream)
+                ? (key->bk_half_valid = false, launch_bk_from_reference((u64 *)key->d_bk, tmp, key->bk_polys(), ctx->stream))
                 : launch_bkf_permute((cplx *)key->d_bk, (const cplx *)tmp, key->bk_polys(), 0, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     hipFree(tmp);
@@ -425,6 +437,7 @@ int nufhe_bk_from_coeffs(nufhe_cloudkey *key, const int32_t *d_tgsw)
     if (rc) return rc;
     rc = alloc_bk(key);
     if (rc) return rc;
+    key->bk_half_valid = false;
     if (key->transform == NUFHE_TRANSFORM_NTT)
         HIP_TRY(launch_bk_from_coeffs((u64 *)key->d_bk, d_tgsw, key->bk_polys(), ctx->d_tw1f, ctx->d_tw1i, ctx->stream));
     else
@@ -590,6 +603,22 @@ static int run_gate(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result
     P.bits_per_job = nbits;
     P.nbits_total = total;
     P.bk = key->d_bk;
+    P.bk_half = nullptr;
+    P.tw_half = ctx->d_nth;
+    {
+        // smallest batches of the NTT / k = 1 path run the half-ring team kernel: it reads the key in its own layout (a
+        // permutation of the same field elements), converted once per key on first use
+        const long team_limit = ctx->team_max_bits < 0 ? (long)ctx->num_cus : ctx->team_max_bits;
+        if (ctx->team8 && key->transform == NUFHE_TRANSFORM_NTT && key->mask_size == 1 && total <= team_limit) {
+            if (!key->d_bk_half)
+                HIP_TRY(hipMalloc((void **)&key->d_bk_half, (size_t)key->bk_polys() * BK_POLY_ELEMS * sizeof(u64)));
+            if (!key->bk_half_valid) {
+                HIP_TRY(launch_bk_to_half(key->d_bk_half, (const u64 *)key->d_bk, key->bk_polys(), ctx->stream));
+                key->bk_half_valid = true;
+            }
+            P.bk_half = key->d_bk_half;
+        }
+    }
     P.n = key->n;
     P.mu = mu;
     const bool fft = key->transform == NUFHE_TRANSFORM_FFT;
@@ -908,6 +937,14 @@ int nufhe_ctx_set_pair_max_bits(nufhe_ctx *ctx, long bits)
     int rc = check_ctx(ctx);
     if (rc) return rc;
     ctx->pair_max_bits = bits;
+    return NUFHE_OK;
+}
+
+int nufhe_ctx_set_team8(nufhe_ctx *ctx, int enable)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    ctx->team8 = enable != 0;
     return NUFHE_OK;
 }
 

@@ -24,6 +24,7 @@
 #include "ff.h"
 #include "ntt1024.h"
 #include "ntt1024_l4.h"
+#include "ntt512_half.h"
 
 #define BR_N 1024
 #define BR_MAX_LWE 512                    /* capacity of the per-wave bara buffer (u16 each) */
@@ -553,6 +554,159 @@ FF_FN void brt_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSou
     }
     // sample extraction (tlwe_cpu.py:55-58)
     for (int j = tid; j < 1024; j += 64 * BRT_WAVES) {
+        const u32 v = (u32)lds.acc[j];
+        out_a[(1024 - j) & 1023] = (i32)(j == 0 ? v : 0u - v);
+    }
+    if (tid == 0) *out_b = lds.acc[1024];
+}
+
+// ------------------------------------------------------------------------------------------
+// Half-ring team (k = 1, the smallest batches): EIGHT wavefronts share one bit -- two per digit transform.
+// X^1024 + 1 = (X^512 - i)(X^512 + i), so the external product runs independently in two rings of length 512
+// (ntt512_half.h) and only the gadget decomposition (before) and the accumulator update (after) see whole polynomials:
+//   wave w = 4 m + 2 d + h   decomposes digit d of polynomial m of (X^a - 1) ACC (as in brt_step), folds it into half
+//                            ring h, transforms it (8 values per lane) and multiplies it with its half of BK_i[m][d][0..1]
+//   barrier; wave 2 mo + h (w < 4) adds the four partial sums of output polynomial mo in half ring h and transforms back
+//   barrier; the two halves of an output meet: wave (mo, 0) forms a_lo = Y^0 + Y^1 and updates ACC[mo][0..511],
+//            wave (mo, 1) forms a_hi = i (Y^1 - Y^0) and updates ACC[mo][512..1023]; barrier.
+// Critical path: one HALF forward + one HALF inverse transform (~0.6 of the 4-wave team's).  Every step is exact in
+// GF(P), so the result equals the other kernels bit for bit.  The key is read in the half-ring layout
+// [row][m][d][mo][h][reg 8][lane 64] (the same field elements in another order: nth_freq_index, k_bk_to_half).
+// ------------------------------------------------------------------------------------------
+#define BRH_WAVES 8
+#define BRH_PART_ELEMS (BRH_WAVES * 2 * 512)     /* u64: partial sums [wave][mo][reg][lane] */
+#define BRH_JOIN_ELEMS (4 * 512)                 /* u64: inverse outputs [mo][h][reg][lane] */
+#define BKH_POLY_ELEMS 512                       /* one half of a key polynomial */
+
+struct BrHalfLds {
+    u64 *xbuf;         // this wave's exchange buffer (NTH_XBUF_ELEMS)
+    i32 *acc;          // [2][1024], shared by the team
+    uint16_t *bara;    // [BR_MAX_LWE], shared
+    u64 *part;         // [BRH_PART_ELEMS], shared
+    u64 *join;         // [BRH_JOIN_ELEMS], shared
+    const u64 *tables; // NTH_TABLE_ELEMS (ntt512_half.h)
+};
+
+#if defined(BR_PROBE) && defined(__HIPCC__)
+__device__ unsigned long long g_brh_probe[8];
+#endif
+#if defined(BR_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+#define BRH_MARK(i)                                                                                   \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        const long long now_ = clock64();                                                             \
+        if (w == 0 && lane == 0 && blockIdx.x == 0) g_brh_probe[i] += (unsigned long long)(now_ - brh_last_);   \
+        brh_last_ = now_;                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    } while (0)
+#define BRH_BEGIN() long long brh_last_ = clock64()
+#else
+#define BRH_MARK(i) do { } while (0)
+#define BRH_BEGIN() do { } while (0)
+#endif
+
+template <class TeamSync>
+FF_FN void brh_step(u32 a, const u64 *row, const BrHalfLds &lds, int lane, int w, TeamSync &&team_sync)
+{
+    BRH_BEGIN();
+    const int m = w >> 2, h = w & 1;
+    const int sh = (w & 2) ? 12 : 22;      // digit d = (w >> 1) & 1: shift 32 - 10 (d + 1)
+    // this wave's half of BK_i[m][d][mo], mo = 0, 1: 16 loads issued before anything else (the wave is alone on its SIMD)
+    u64 kq[2][8];
+    {
+        const u64 *kp = row + ((long)(w >> 1) * 2 * 2 + h) * BKH_POLY_ELEMS + lane;     // [m][d][mo = 0][h]
+#pragma unroll
+        for (int mo = 0; mo < 2; mo++)
+#pragma unroll
+            for (int r = 0; r < 8; r++) kq[mo][r] = kp[mo * 2 * BKH_POLY_ELEMS + r * 64];
+        BR_ISSUE_FENCE();
+    }
+    i32 dg[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const u32 j = (u32)(lane + 64 * r);
+        const u32 t = (j - a) & 2047u;
+        const u32 v = (u32)lds.acc[m * 1024 + (t & 1023u)];
+        const u32 T = ((t & 1024u) ? 0u - v : v) - (u32)lds.acc[m * 1024 + j];
+        dg[r] = (((i32)(T + TGSW_OFFSET) >> sh) & 1023) - 512;
+    }
+    BRH_MARK(0);
+    u64 x[8];
+    const NthTables tb = nth_tables(lds.tables, h);
+    if (h == 0) nth_forward_small<0>(x, dg, lds.xbuf, tb, lane);
+    else nth_forward_small<1>(x, dg, lds.xbuf, tb, lane);
+    BRH_MARK(1);
+#pragma unroll
+    for (int mo = 0; mo < 2; mo++)
+#pragma unroll
+        for (int r = 0; r < 8; r++) lds.part[((w * 2 + mo) * 8 + r) * 64 + lane] = ff_mul(ff_canon(x[r]), kq[mo][r]);
+    BRH_MARK(2);
+    team_sync();
+    BRH_MARK(3);
+    if (w < 4) {
+        const int mo = w >> 1;                                 // reducer (mo, h)
+        u64 sum[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            u64 acc = lds.part[(((0 * 2 + h) * 2 + mo) * 8 + r) * 64 + lane];
+#pragma unroll
+            for (int src = 1; src < 4; src++) acc = ff_add(acc, lds.part[(((src * 2 + h) * 2 + mo) * 8 + r) * 64 + lane]);
+            sum[r] = acc;
+        }
+        BRH_MARK(4);
+        u64 y[8];
+        if (h == 0) nth_inverse<0>(y, sum, lds.xbuf, tb, lane);
+        else nth_inverse<1>(y, sum, lds.xbuf, tb, lane);
+#pragma unroll
+        for (int r = 0; r < 8; r++) lds.join[((mo * 2 + h) * 8 + r) * 64 + lane] = ff_canon(y[r]);
+        BRH_MARK(5);
+    }
+    team_sync();
+    BRH_MARK(6);
+    if (w < 4) {
+        const int mo = w >> 1;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const u64 y0 = lds.join[((mo * 2 + 0) * 8 + r) * 64 + lane], y1 = lds.join[((mo * 2 + 1) * 8 + r) * 64 + lane];
+            // a_j' = Y^0 + Y^1 (half 0 writes it), a_(j'+512) = i (Y^1 - Y^0) (half 1); ntt.mako:402-408 for the conversion
+            const u64 v = h == 0 ? ff_add(y0, y1) : ff_mul_pow2<48>(ff_sub(y1, y0));
+            lds.acc[mo * 1024 + h * 512 + lane + 64 * r] += ff_to_i32(v);
+        }
+    }
+    team_sync();
+    BRH_MARK(7);
+}
+
+// Whole bootstrap body of the half-ring team for one bit: tid = 64 w + lane in [0, 512); out_a has 1024 entries.
+template <class TeamSync>
+FF_FN void brh_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSource &s1, i32 c0, long bit,
+                         const u64 *bkh, int n, i32 mu, const BrHalfLds &lds, int lane, int w, TeamSync &&team_sync)
+{
+    const int tid = 64 * w + lane;
+    for (int i = tid; i < n; i += 64 * BRH_WAVES) {
+        u32 v = 0;
+        if (s0.p) v += (u32)s0.p * (u32)s0.a[bit * s0.a_stride + i];
+        if (s1.p) v += (u32)s1.p * (u32)s1.a[bit * s1.a_stride + i];
+        lds.bara[i] = (uint16_t)br_modswitch(v);
+    }
+    u32 vb = (u32)c0;
+    if (s0.p) vb += (u32)s0.p * (u32)s0.b[bit * s0.b_stride];
+    if (s1.p) vb += (u32)s1.p * (u32)s1.b[bit * s1.b_stride];
+    const u32 barb = br_modswitch(vb);
+    // ACC = (0, X^(2N - barb) * mu)  (bootstrap.py:176-182)
+    for (int j = tid; j < 1024; j += 64 * BRH_WAVES) {
+        const u32 t = ((u32)j + barb) & 2047u;
+        lds.acc[j] = 0;
+        lds.acc[1024 + j] = (t < 1024u) ? mu : (i32)(0u - (u32)mu);
+    }
+    team_sync();
+    for (int i = 0; i < n; i++) {
+        const u32 a = WAVE_UNIFORM((u32)lds.bara[i]);
+        if (a == 0) continue;
+        brh_step(a, bkh + (long)i * BK_ROW_ELEMS, lds, lane, w, team_sync);
+    }
+    // sample extraction (tlwe_cpu.py:55-58)
+    for (int j = tid; j < 1024; j += 64 * BRH_WAVES) {
         const u32 v = (u32)lds.acc[j];
         out_a[(1024 - j) & 1023] = (i32)(j == 0 ? v : 0u - v);
     }

@@ -32,6 +32,10 @@ struct BrLaunch {
     long out_b_stride;
     const void *tw_a;     // NTT: tw1f u64[1024]; FFT: tw1 complex[512]
     const void *tw_b;     // NTT: tw1i u64[1024]; FFT: tw2 complex[64]
+    // half-ring team kernel (k_bootstrap_team8): the key in the half-ring layout and the table block of ntt512_half.h;
+    // bk_half == nullptr keeps the smallest batches on the 4-wave team kernel
+    const void *bk_half;
+    const void *tw_half;
     // profiling only (nufhe_profile_enable), else nullptr: wave 0 of work-group 0 of the wave-per-bit kernels stores
     // how long it lived, {shader-clock ticks (s_memtime), constant 100 MHz ticks (s_memrealtime)}
     unsigned long long *clock_probe;     // nullptr or CLOCK_PROBE_WORDS words (ClockProbe, kernels.hip)
@@ -112,6 +116,7 @@ hipError_t launch_poly_mul_strided(i32 *out, long out_stride, const i32 *x, long
                                    hipStream_t stream);
 hipError_t launch_bk_from_reference(u64 *out, const u64 *in, long polys, hipStream_t stream);
 hipError_t launch_bk_to_reference(u64 *out, const u64 *in, long polys, hipStream_t stream);
+hipError_t launch_bk_to_half(u64 *out, const u64 *in, long polys, hipStream_t stream);
 hipError_t launch_bk_from_coeffs(u64 *out, const i32 *in, long polys, const u64 *tw1f, const u64 *tw1i,
                                  hipStream_t stream);
 // byte planes of the keyswitch key for k_keyswitch_mfma: planes[4][input_size][2][KSM_COLS][16]

@@ -179,6 +179,36 @@ __global__ __launch_bounds__(64 * BRT_WAVES, 1) void k_bootstrap_team(BrLaunch P
                   [] { __syncthreads(); });
 }
 
+// Smallest batches (k = 1): the half-ring team, EIGHT waves per bit (blind_rotate.h, brh_*; ntt512_half.h).
+// LDS: half-ring tables | ACC 8 KiB | bara 1 KiB | partial sums 64 KiB | join 16 KiB | 8 exchange buffers
+#define NTH_TABLE_BYTES (NTH_TABLE_ELEMS * 8)
+#define TEAM8_LDS_BYTES (NTH_TABLE_BYTES + 2 * 1024 * 4 + WAVE_BARA_BYTES + BRH_PART_ELEMS * 8 + BRH_JOIN_ELEMS * 8 + BRH_WAVES * NTH_XBUF_ELEMS * 8)
+static_assert(TEAM8_LDS_BYTES <= 160 * 1024, "LDS budget of the half-ring team kernel");
+__global__ __launch_bounds__(64 * BRH_WAVES, 1) void k_bootstrap_team8(BrLaunch P)
+{
+    {
+        u64 *t = (u64 *)g_smem;
+        const u64 *g = (const u64 *)P.tw_half;
+        for (int i = threadIdx.x; i < NTH_TABLE_ELEMS; i += blockDim.x) t[i] = g[i];
+        __syncthreads();
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long gbit = blockIdx.x;
+    const int job = gbit >= P.bits_per_job ? 1 : 0;
+    const long bit = gbit - (job ? P.bits_per_job : 0);
+    unsigned char *base = g_smem + NTH_TABLE_BYTES;
+    BrHalfLds lds;
+    lds.tables = (const u64 *)g_smem;
+    lds.acc = (i32 *)base;
+    lds.bara = (uint16_t *)(base + 2 * 1024 * 4);
+    lds.part = (u64 *)(base + 2 * 1024 * 4 + WAVE_BARA_BYTES);
+    lds.join = lds.part + BRH_PART_ELEMS;
+    lds.xbuf = lds.join + BRH_JOIN_ELEMS + wave * NTH_XBUF_ELEMS;
+    brh_bootstrap(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, P.job[job].s0, P.job[job].s1,
+                  P.job[job].c0, bit, (const u64 *)P.bk_half, P.n, P.mu, lds, lane, WAVE_UNIFORM(wave),
+                  [] { __syncthreads(); });
+}
+
 // Small-batch variant for tlwe_mask_size = 2: a team of 3 waves per bit (blind_rotate.h, brtk_*).
 // LDS: tables | ACC 12 KiB | bara 1 KiB | partial sums 72 KiB | 3 exchange buffers
 #define TEAM2_LDS_BYTES (TABLE_LDS_BYTES + 3 * 1024 * 4 + WAVE_BARA_BYTES + BRTK_PART_ELEMS(2) * 8 + 3 * WAVE_XBUF_BYTES)
@@ -879,6 +909,18 @@ __global__ void k_tgsw_mac(u64 *__restrict__ result, const u64 *__restrict__ sam
     result[t] = ff_canon(acc);
 }
 
+// wave layout -> half-ring layout [poly][h][reg 8][lane 64] of the same field elements (k_bootstrap_team8)
+__global__ void k_bk_to_half(u64 *__restrict__ out, const u64 *__restrict__ in, long polys)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= polys * 1024) return;
+    const long p = t >> 10;
+    const int e = (int)(t & 1023), h = e >> 9, reg = (e >> 6) & 7, lane = e & 63;
+    const int k = nth_freq_index(h, lane, reg);
+    const int k2 = k & 15, k1a = (k >> 4) & 15, k1b = k >> 8;                  // inverse of ntt_freq_index
+    out[t] = in[p * 1024 + bk_elem_offset(4 * k2 + (k1a & 3), 4 * (k1a >> 2) + k1b)];
+}
+
 // coefficient-domain TGSW polynomials (int32) -> wave layout (forward NTT only; no Montgomery)
 __global__ __launch_bounds__(NTT_BLOCK_THREADS) void k_bk_from_coeffs(u64 *__restrict__ out, const i32 *__restrict__ in,
                                                                       long polys, const u64 *__restrict__ tw1f,
@@ -1283,6 +1325,8 @@ hipError_t kernels_init_device(int *num_cus)
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap_fft_team, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAMF_LDS_BYTES);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_bootstrap_team8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAM8_LDS_BYTES);
+    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap_team, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAM_LDS_BYTES);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap_team_k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAM2_LDS_BYTES);
@@ -1363,7 +1407,10 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, lon
     if (pair_max_bits < 0) pair_max_bits = (long)BRP_MAX_PAIRS * num_cus;
     if (team_max_bits < 0)
         team_max_bits = (transform == 0) ? (long)num_cus : 2L * num_cus;
-    if (transform == 0 && mask_size == 1 && P.nbits_total <= team_max_bits) {
+    if (transform == 0 && mask_size == 1 && P.nbits_total <= team_max_bits && P.bk_half != nullptr) {
+        // smallest batches: 8 waves per bit (two per digit transform, half rings), one bit per CU at a time
+        hipLaunchKernelGGL(k_bootstrap_team8, dim3((unsigned)P.nbits_total), dim3(64 * BRH_WAVES), TEAM8_LDS_BYTES, stream, P);
+    } else if (transform == 0 && mask_size == 1 && P.nbits_total <= team_max_bits) {
         // small batch: 4 waves per bit, one bit per CU at a time
         hipLaunchKernelGGL(k_bootstrap_team, dim3((unsigned)P.nbits_total), dim3(64 * BRT_WAVES), TEAM_LDS_BYTES, stream, P);
     } else if (transform == 0 && mask_size == 1 && P.nbits_total <= pair_max_bits) {
@@ -1563,6 +1610,12 @@ hipError_t launch_tgsw_mac(u64 *result, const u64 *sample, const u64 *bk, int bk
     const dim3 grid(blocks_for(batch * (mask_size + 1) * 1024, 256));
     if (mask_size == 1) hipLaunchKernelGGL(k_tgsw_mac<1>, grid, dim3(256), 0, stream, result, sample, bk, bk_row, batch);
     else hipLaunchKernelGGL(k_tgsw_mac<2>, grid, dim3(256), 0, stream, result, sample, bk, bk_row, batch);
+    return hipGetLastError();
+}
+
+hipError_t launch_bk_to_half(u64 *out, const u64 *in, long polys, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_bk_to_half, dim3(blocks_for(polys * 1024, 256)), dim3(256), 0, stream, out, in, polys);
     return hipGetLastError();
 }
 
@@ -1862,6 +1915,13 @@ hipError_t launch_tlwe_extract(i32 *ra, i32 *rb, const i32 *tlwe, long batch, in
 
 #if defined(BR_PROBE)
 // variant builds only (blind_rotate.h, BR_PROBE): read and clear the segment tick counters
+extern "C" int nufhe_probe_read_team8(unsigned long long *out8)
+{
+    unsigned long long zero[8] = {0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_brh_probe), sizeof(zero)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_brh_probe), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+
 extern "C" int nufhe_probe_read(unsigned long long *out16)
 {
     unsigned long long zero[16] = {0};

@@ -94,7 +94,14 @@ def bk_from_reference(bk):
     return out
 
 
-def bootstrap_bit(bk_internal, n, src0, p0, src1, p1, c0, mu, mask_size=1, team=False, pair=False, ring=False):
+def bk_to_half(bk_internal):
+    bk_internal = numpy.ascontiguousarray(bk_internal, numpy.uint64)
+    out = numpy.empty_like(bk_internal)
+    lib().emu_bk_to_half(_p(out, c_u64p), _p(bk_internal, c_u64p), ctypes.c_long(bk_internal.size // 1024))
+    return out
+
+
+def bootstrap_bit(bk_internal, n, src0, p0, src1, p1, c0, mu, mask_size=1, team=False, pair=False, ring=False, team8=False):
     """src = (a [n], b scalar array [1]); returns (ext_a [1024 * mask_size], ext_b).
     team=True runs the 4-wave (k = 2: 3-wave) team variant of the body, pair=True the 2-wave variant (k = 1)."""
     a0 = numpy.ascontiguousarray(src0[0], numpy.int32); b0 = numpy.ascontiguousarray(src0[1], numpy.int32).reshape(1)
@@ -107,6 +114,8 @@ def bootstrap_bit(bk_internal, n, src0, p0, src1, p1, c0, mu, mask_size=1, team=
         fn = lib().emu_bootstrap_bit_pair
     if ring:
         fn = lib().emu_bootstrap_bit_ring_k2          # mask_size 2 only
+    if team8:
+        fn = lib().emu_bootstrap_bit_team8            # bk_internal must be in the half-ring layout (bk_to_half)
     fn(_p(out_a, c_i32p), _p(out_b, c_i32p), _p(bk_internal, c_u64p), ctypes.c_int(n),
                             _p(a0, c_i32p), _p(b0, c_i32p), ctypes.c_int32(p0),
                             _p(a1, c_i32p), _p(b1, c_i32p), ctypes.c_int32(p1),
@@ -169,4 +178,18 @@ def fft_round(v):
     v = numpy.ascontiguousarray(v, numpy.float64)
     r = numpy.empty(v.shape, numpy.uint32)
     lib().emu_fft_round(_p(r, c_u32p), v.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ctypes.c_long(v.size))
+    return r
+
+
+def nth_forward_small(d):
+    d = numpy.ascontiguousarray(d, numpy.int32)
+    r = numpy.empty(1024, numpy.uint64)
+    lib().emu_nth_forward_small(_p(r, c_u64p), _p(d, c_i32p))
+    return r
+
+
+def nth_inverse_i32(x):
+    x = numpy.ascontiguousarray(x, numpy.uint64)
+    r = numpy.empty(1024, numpy.uint32)
+    lib().emu_nth_inverse_i32(_p(r, c_u32p), _p(x, c_u64p))
     return r

@@ -11,6 +11,7 @@
 #include "../../nufhe_amd/csrc/blind_rotate.h"
 #include "../../nufhe_amd/csrc/ff24.h"
 #include "../../nufhe_amd/csrc/ntt1024_l4.h"
+#include "../../nufhe_amd/csrc/ntt512_half.h"
 #include "../../nufhe_amd/csrc/l4_hook.h"
 #include "../../nufhe_amd/csrc/fft512.h"
 #include "../../nufhe_amd/csrc/blind_rotate_fft.h"
@@ -112,6 +113,52 @@ void emu_ntt_inverse_l4_i32(u32 *out, const u64 *in)
     });
 }
 
+// half-ring transforms (ntt512_half.h): the forward transform of a digit polynomial by two waves (h = 0: even, h = 1: odd
+// output frequencies); out: canonical values in natural frequency order of the 1024-point transform
+static u64 g_nth[NTH_TABLE_ELEMS];
+static bool g_nth_ready = false;
+static void nth_ready() { if (!g_nth_ready) { nth_make_tables(g_nth); g_nth_ready = true; } }
+
+void emu_nth_forward_small(u64 *out, const i32 *in)
+{
+    nth_ready();
+    for (int h = 0; h < 2; h++) {
+        std::vector<u64> xbuf(NTH_XBUF_ELEMS);
+        const NthTables T = nth_tables(g_nth, h);
+        emu_run_wave([&](int lane) {
+            i32 d[16];
+            u64 x[8];
+            for (int r = 0; r < 16; r++) d[r] = in[lane + 64 * r];
+            if (h == 0) nth_forward_small<0>(x, d, xbuf.data(), T, lane); else nth_forward_small<1>(x, d, xbuf.data(), T, lane);
+            for (int b = 0; b < 8; b++) out[nth_freq_index(h, lane, b)] = ff_canon(x[b]);
+        });
+    }
+}
+
+// inverse of the whole 1024-point transform through the two half rings + the join; in: canonical values in natural
+// frequency order; out: coefficients mod 2^32 (the caller guarantees small integer coefficients, as ntt_inverse_l4_i32)
+void emu_nth_inverse_i32(u32 *out, const u64 *in)
+{
+    nth_ready();
+    std::vector<u64> Y(2 * 512);
+    for (int h = 0; h < 2; h++) {
+        std::vector<u64> xbuf(NTH_XBUF_ELEMS);
+        const NthTables T = nth_tables(g_nth, h);
+        emu_run_wave([&](int lane) {
+            u64 x[8], y[8];
+            for (int b = 0; b < 8; b++) x[b] = in[nth_freq_index(h, lane, b)];
+            if (h == 0) nth_inverse<0>(y, x, xbuf.data(), T, lane); else nth_inverse<1>(y, x, xbuf.data(), T, lane);
+            for (int j = 0; j < 8; j++) Y[h * 512 + lane + 64 * j] = ff_canon(y[j]);
+        });
+    }
+    for (int j = 0; j < 512; j++) {
+        const u64 lo = ff_add(Y[j], Y[512 + j]);
+        const u64 hi = ff_mul_pow2<48>(ff_sub(Y[512 + j], Y[j]));
+        out[j] = (u32)ff_to_i32(lo);
+        out[j + 512] = (u32)ff_to_i32(hi);
+    }
+}
+
 // reference-format key polynomials (natural-order NTT, Montgomery) -> wave layout, plain
 void emu_bk_from_reference(u64 *out, const u64 *in, long polys)
 {
@@ -159,6 +206,36 @@ extern "C" void emu_bootstrap_bit_team(i32 *out_a, i32 *out_b, const u64 *bk_int
         BrTeamLds lds{xbuf.data() + w * NTT_XBUF_ELEMS, accbuf.data(), bara.data(), part.data(), g_tw1x, g_tw1i};
         NttLane L = ntt_lane_init(lane);
         brt_bootstrap(out_a, out_b, s0, s1, c0, 0, bk_internal, n, mu, lds, L, w, [] { emu_team_sync(); });
+    });
+}
+
+// wave-layout key (bk_internal) -> half-ring layout [poly][h][reg 8][lane 64] (the permutation of k_bk_to_half)
+extern "C" void emu_bk_to_half(u64 *out, const u64 *in, long polys)
+{
+    for (long p = 0; p < polys; p++)
+        for (int h = 0; h < 2; h++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int r = 0; r < 8; r++) {
+                    const int k = nth_freq_index(h, lane, r);
+                    const int k2 = k & 15, k1a = (k >> 4) & 15, k1b = k >> 8;
+                    const int sl = 4 * k2 + (k1a & 3), sr = 4 * (k1a >> 2) + k1b;      // inverse of ntt_freq_index
+                    out[p * 1024 + h * 512 + r * 64 + lane] = in[p * 1024 + bk_elem_offset(sl, sr)];
+                }
+}
+
+// the 8-wave half-ring team (blind_rotate.h, brh_*): 512 fibres; the key in the half-ring layout
+extern "C" void emu_bootstrap_bit_team8(i32 *out_a, i32 *out_b, const u64 *bk_half, int n,
+                                        const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,
+                                        i32 c0, i32 mu)
+{
+    nth_ready();
+    std::vector<u64> xbuf(BRH_WAVES * NTH_XBUF_ELEMS), part(BRH_PART_ELEMS), join(BRH_JOIN_ELEMS);
+    std::vector<i32> accbuf(2 * 1024);
+    std::vector<uint16_t> bara(BR_MAX_LWE);
+    BrSource s0{a0, b0, 0, 0, p0}, s1{a1, b1, 0, 0, p1};
+    emu_run_team(BRH_WAVES, [&](int w, int lane) {
+        BrHalfLds lds{xbuf.data() + w * NTH_XBUF_ELEMS, accbuf.data(), bara.data(), part.data(), join.data(), g_nth};
+        brh_bootstrap(out_a, out_b, s0, s1, c0, 0, bk_half, n, mu, lds, lane, w, [] { emu_team_sync(); });
     });
 }
 

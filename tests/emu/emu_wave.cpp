@@ -3,7 +3,7 @@
 
 namespace {
 constexpr int kLanes = 64;
-constexpr int kMaxFibres = 256;
+constexpr int kMaxFibres = 512;
 int g_nfibres = kLanes;
 int g_arrived = 0;
 long g_generation = 0;

@@ -93,6 +93,10 @@ def test_bootstrap_wave_body_reduced(orc):
         ga, gb = emu.bootstrap_bit(bki, n, (a0, b0), -1, (a1, b1), -1, MU, MU, pair=True)
         assert (ga == ea[0]).all()
         assert gb == eb[0]
+        # the 8-wave half-ring team (smallest batches; key in the half-ring layout): identical bits
+        ga, gb = emu.bootstrap_bit(emu.bk_to_half(bki), n, (a0, b0), -1, (a1, b1), -1, MU, MU, team8=True)
+        assert (ga == ea[0]).all()
+        assert gb == eb[0]
 
 
 @pytest.mark.slow
@@ -136,6 +140,25 @@ def test_fft_forward_inverse_vs_numpy():
 
 
 @pytest.mark.slow
+def test_half_ring_transforms_vs_oracle(orc):
+    """ntt512_half.h (the small-batch kernel's transforms: X^1024 + 1 = (X^512 - i)(X^512 + i), two wavefronts per
+    transform): the forward half transforms of a digit polynomial give the even / odd frequencies of the oracle's
+    1024-point NTT, and the two inverse halves + the join give back the coefficients of a product-sized polynomial."""
+    rs = numpy.random.RandomState(31)
+    for trial in range(3):
+        d = rs.randint(-512, 512, size=1024).astype(numpy.int32)
+        if trial == 0:
+            d[:] = -512                                    # extreme digits: the limb bounds of pass 1
+        ref = orc.ntt_forward(d)                           # i32 -> field -> natural-order NTT
+        got = emu.nth_forward_small(d)
+        assert (got == ref).all(), (trial, int((got != ref).sum()))
+    for trial in range(3):
+        c = rs.randint(-2**51, 2**51, size=1024).astype(numpy.int64)       # |coefficients| < 2^52 like the products
+        x = orc.ntt_forward(numpy.array([int(v) % orc.P for v in c], dtype=numpy.uint64), i32_conversion=False)
+        got = emu.nth_inverse_i32(x)
+        assert (got == (c & 0xFFFFFFFF).astype(numpy.uint32)).all(), trial
+
+
 def test_fft_final_rounding_matches_reference_semantics_up_to_2_52():
     """fft_round_to_u32 (fft512.h) == round-half-even -> int64 -> low 32 bits (transform/fft.mako:272-277) on the whole
     range the blind rotation can reach, |v| <= 2^52: both signs, ties, the binade edges 2^51 and 2^52 where a signed

@@ -217,9 +217,10 @@ def test_error_behaviour(env):
 
 
 def test_small_batch_team_kernel_equals_wave_kernel(env, orc):
-    """The 4-waves-per-bit kernel (batches <= CUs by default), the 2-waves-per-bit kernel (<= 4 x CUs) and the
-    wave-per-bit kernel give bit-identical ciphertexts, all equal to the oracle; the switches are exercised on both
-    sides of their boundaries (nufhe_ctx_set_team_max_bits / nufhe_ctx_set_pair_max_bits)."""
+    """The 8-waves-per-bit half-ring kernel (batches <= CUs by default), the 4-waves-per-bit kernel (the same batches
+    with nufhe_ctx_set_team8(0)), the 2-waves-per-bit kernel (<= 4 x CUs) and the wave-per-bit kernel give bit-identical
+    ciphertexts, all equal to the oracle; the switches are exercised on both sides of their boundaries
+    (nufhe_ctx_set_team_max_bits / nufhe_ctx_set_pair_max_bits / nufhe_ctx_set_team8)."""
     from nufhe_amd import _lib
     H = env['H']; thr = env['thr']; vm = env['vm']; ck = env['ck']; lwe_key = env['lwe_key']
     rng = orc.DeterministicRNG(2024)
@@ -232,15 +233,18 @@ def test_small_batch_team_kernel_equals_wave_kernel(env, orc):
     try:
         # MUX launches 2 B = 140 bits in one bootstrap.  (team limit, pair limit): (0, 0) = wave kernel only,
         # (0, -1) = pair kernel, (69, 139): NAND pair / MUX wave, (70, 140): NAND team / MUX pair, ...
-        for team, pair in ((0, 0), (0, -1), (69, 139), (69, 140), (70, 140), (139, 0), (140, -1), (-1, -1)):
-            _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, team)
-            _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, pair)
-            for got, exp in ((vm.gate_nand(ds[0], ds[1]), exp_nand), (vm.gate_mux(ds[0], ds[1], ds[2]), exp_mux)):
-                ra, rb, rcv = H.ct_arrays(got)
-                assert (ra == exp[0]).all() and (rb == exp[1]).all() and (rcv == exp[2]).all(), (team, pair)
+        for team8 in (1, 0):
+            _lib.call("nufhe_ctx_set_team8", thr.handle, team8)
+            for team, pair in ((0, 0), (0, -1), (69, 139), (69, 140), (70, 140), (139, 0), (140, -1), (-1, -1)):
+                _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, team)
+                _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, pair)
+                for got, exp in ((vm.gate_nand(ds[0], ds[1]), exp_nand), (vm.gate_mux(ds[0], ds[1], ds[2]), exp_mux)):
+                    ra, rb, rcv = H.ct_arrays(got)
+                    assert (ra == exp[0]).all() and (rb == exp[1]).all() and (rcv == exp[2]).all(), (team8, team, pair)
     finally:
         _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, -1)
         _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, -1)
+        _lib.call("nufhe_ctx_set_team8", thr.handle, 1)
 
 
 def test_medium_batch_pair_kernel_every_group_size(env, orc):
