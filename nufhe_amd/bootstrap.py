@@ -5,6 +5,13 @@ nufhe/blind_rotate.py:262-281).
 The reference's driver issues ~10 kernel launches per gate (mod-switch x2, fill, shift, trivial,
 fused blind-rotate, keyswitch, ...); here `bootstrap()` is ONE C-ABI call that enqueues the fused
 gfx950 bootstrap kernel (+ the keyswitch kernels).
+
+The reference's second mode, ``PerformanceParameters(single_kernel_bootstrap=False)`` (bootstrap.py:96-196: one
+shift, one external product and one addition per key row, 1,500 launches per blind rotation), is kept as the
+step-by-step driver below -- `mux_rotate`, `blind_rotate`, `blind_rotate_and_extract` with the reference's names and
+argument order, every step one launch of a gfx950 kernel.  It is the structure the CPU oracle mirrors
+(SURVEY 3.2), serves callers of the low-level API, and gives the fused kernels a second, independently composed
+device path to be compared with (tests/test_gpu_stepwise.py): same bits, ~100x the time.
 """
 
 import ctypes
@@ -15,8 +22,13 @@ import numpy
 from . import _lib
 from . import serialization
 from .device import ptr
-from .lwe import LweParams, LweKey, LweSampleArray, LweKeyswitchKey, _Flat, check_lwe_size
-from .tgsw import TGswKey, TGswParams, tgsw_encrypt_int
+from .lwe import LweParams, LweKey, LweSampleArray, LweKeyswitchKey, _Flat, check_lwe_size, lwe_keyswitch
+from .numeric_functions import Torus32, t32_to_phase
+from .polynomials import TorusPolynomialArray, shift_tp_inverted_power
+from .tgsw import (TGswKey, TGswParams, TransformedTGswSampleArray, tgsw_encrypt_int,
+                   tgsw_transformed_external_mul)
+from .tlwe import (TLweSampleArray, tlwe_noiseless_trivial, tlwe_extract_lwe_samples, tlwe_shift_polynomials,
+                   tlwe_add_to, tlwe_copy)
 from .utils import arrays_equal
 
 
@@ -67,6 +79,8 @@ class BootstrapKey:
         self.accum_params = accum_params
         self.extract_params = accum_params.extracted_lweparams
         self._native = native
+        # the transformed TGSW samples as the step-by-step driver addresses them (bootstrap.py:57, `bk.tgsw`)
+        self.tgsw = TransformedTGswSampleArray(bk_params, native, in_out_params.size)
 
     @classmethod
     def from_rng(cls, thr, rng, lwe_key: LweKey, tgsw_key: TGswKey, native: NativeCloudKey,
@@ -123,15 +137,81 @@ class BootstrapKey:
             and arrays_equal(self.transformed_reference_format(), other.transformed_reference_format()))
 
 
+def single_kernel(perf_params):
+    """False only for a performance-parameter object that asks for the step-by-step driver."""
+    return perf_params is None or getattr(perf_params, 'single_kernel_bootstrap', True) is not False
+
+
+def mux_rotate(thr, result: TLweSampleArray, accum: TLweSampleArray, bki: TransformedTGswSampleArray, bk_idx: int,
+               barai, bk_params: TGswParams = None, perf_params=None):
+    """result = accum + BK[bk_idx] (x) ((X^barai[..., bk_idx] - 1) accum): one step of the blind rotation as three
+    launches (nufhe/bootstrap.py:95-108)."""
+    tlwe_shift_polynomials(thr, result, accum, barai, bk_idx)
+    tgsw_transformed_external_mul(thr, result, bki, bk_idx, perf_params)
+    tlwe_add_to(thr, result, accum)
+
+
+def blind_rotate(thr, accum: TLweSampleArray, bk: BootstrapKey, bara, n: int, bk_params: TGswParams = None,
+                 perf_params=None):
+    """accum *= X^(sum_i bara[..., i] s_i) over the first ``n`` key rows, ping-ponging between the accumulator and
+    one temporary (nufhe/bootstrap.py:119-142)."""
+    if not (0 <= n <= bk.tgsw.shape[0]):
+        raise ValueError("%d rows requested from a key of %d" % (n, bk.tgsw.shape[0]))
+    spare = TLweSampleArray.empty(thr, accum.params, accum.shape)
+    src, dst = accum, spare
+    for i in range(n):
+        mux_rotate(thr, dst, src, bk.tgsw, i, bara, bk.bk_params, perf_params)
+        src, dst = dst, src
+    if src is not accum:
+        tlwe_copy(thr, accum, src)
+
+
+def blind_rotate_and_extract(thr, result: LweSampleArray, v: TorusPolynomialArray, bk: BootstrapKey,
+                             ks: LweKeyswitchKey, barb, bara, perf_params=None, no_keyswitch=False):
+    """result = LWE(v_p), p = barb - sum_i bara_i s_i mod 2N: test vector rotated by -barb, trivial accumulator,
+    blind rotation, extraction of the constant coefficient and (unless ``no_keyswitch``) the keyswitch back to the
+    input key (nufhe/bootstrap.py:154-196), one launch per step."""
+    accum_params = bk.accum_params
+    shape = tuple(result.shape)
+    extracted = result if no_keyswitch else LweSampleArray.empty(thr, bk.extract_params, shape)
+    check_lwe_size("extracted sample", extracted, bk.extract_params.size)
+    rotated = TorusPolynomialArray.empty(thr, accum_params.polynomial_degree, shape)
+    shift_tp_inverted_power(thr, rotated, barb, v)
+    acc = TLweSampleArray.empty(thr, accum_params, shape)
+    tlwe_noiseless_trivial(thr, acc, rotated)
+    blind_rotate(thr, acc, bk, bara, bk.in_out_params.size, bk.bk_params, perf_params)
+    tlwe_extract_lwe_samples(thr, extracted, acc)
+    if not no_keyswitch:
+        lwe_keyswitch(thr, result, ks, extracted)
+
+
+def _bootstrap_stepwise(thr, result, bk, ks, mu, x, perf_params, no_keyswitch):
+    """nufhe/bootstrap.py:206-229 with ``single_kernel_bootstrap=False``"""
+    N = bk.accum_params.polynomial_degree
+    shape = tuple(result.shape)
+    if tuple(x.shape) != shape:
+        raise ValueError("argument of shape %s, result of shape %s" % (tuple(x.shape), shape))
+    barb = thr.array(shape, Torus32)
+    bara = thr.array(shape + (bk.in_out_params.size,), Torus32)
+    t32_to_phase(thr, barb, x.b, 2 * N)
+    t32_to_phase(thr, bara, x.a, 2 * N)
+    testvect = TorusPolynomialArray.empty(thr, N, shape)
+    testvect.coeffs.fill_(int(numpy.int32(mu)))
+    blind_rotate_and_extract(thr, result, testvect, bk, ks, barb, bara, perf_params, no_keyswitch=no_keyswitch)
+
+
 def bootstrap(thr, result: LweSampleArray, bk: BootstrapKey, ks: LweKeyswitchKey, mu, x: LweSampleArray,
               perf_params=None, no_keyswitch=False):
     """
     result = LWE(mu) iff phase(x) > 0, LWE(-mu) iff phase(x) < 0  (nufhe/bootstrap.py:206-229).
     With ``no_keyswitch`` the result is an LWE sample under the extracted key (size N*k).
+    ``perf_params.single_kernel_bootstrap == False`` takes the step-by-step driver above instead of the fused call.
     """
     thr.check_stream()
     check_lwe_size("bootstrap result", result, bk.extract_params.size if no_keyswitch else bk.in_out_params.size)
     check_lwe_size("bootstrap argument", x, bk.in_out_params.size)
+    if not single_kernel(perf_params):
+        return _bootstrap_stepwise(thr, result, bk, ks, mu, x, perf_params, no_keyswitch)
     res = _Flat(result, result.shape, output=True)
     src = _Flat(x, result.shape)
     _lib.call("nufhe_bootstrap", thr.handle, bk._native.handle, res.desc, src.desc,

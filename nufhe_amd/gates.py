@@ -5,14 +5,19 @@ Same names, argument order, broadcasting rules and error behaviour as the refere
 gate is `result = KS(BS((0, c) + pa * a + pb * b))`; the linear pre-combination,
 mod-switch, blind rotation, sample extraction and keyswitch of a gate are a single C-ABI call
 (`nufhe_gate_binary` / `nufhe_gate_mux`), not the reference's chain of ~10 kernel launches.
+With ``perf_params.single_kernel_bootstrap == False`` a gate instead runs the reference's own sequence -- trivial
+constant, linear combinations, `bootstrap` through the step-by-step driver of nufhe_amd/bootstrap.py -- one launch
+per step (the reference's multi-kernel mode, gates.py:104-121 / bootstrap.py:96-196).
 """
 
 import numpy
 
 from . import _lib
+from .bootstrap import bootstrap, single_kernel
 from .lwe import (
     LweSampleArray, _Flat, check_lwe_size,
-    lwe_negate, lwe_copy, lwe_noiseless_trivial,
+    lwe_negate, lwe_copy, lwe_noiseless_trivial, lwe_noiseless_trivial_constant,
+    lwe_add_to, lwe_sub_to, lwe_add_mul_to, lwe_sub_mul_to, lwe_keyswitch,
     )
 from .numeric_functions import phase_to_t32
 
@@ -67,10 +72,33 @@ def _check_sizes(cloud_key, result, *args):
         check_lwe_size("gate argument", x, n)
 
 
-def _binary_gate(thr, cloud_key, result, a, b, c, pa, pb):
+def _accumulate(thr, result, p, source):
+    """result += p * source with the reference's choice of primitive (add / sub for +-1, the multiplying forms else)"""
+    if p == 1:
+        lwe_add_to(thr, result, source)
+    elif p == -1:
+        lwe_sub_to(thr, result, source)
+    elif p > 0:
+        lwe_add_mul_to(thr, result, p, source)
+    else:
+        lwe_sub_mul_to(thr, result, -p, source)
+
+
+def _binary_gate_stepwise(thr, cloud_key, result, a, b, c, pa, pb, perf_params):
+    """(0, c) + pa a + pb b in a temporary, then `bootstrap` (nufhe/gates.py:104-121 and siblings)"""
+    temp = LweSampleArray.empty(thr, cloud_key.params.in_out_params, result.shape)
+    lwe_noiseless_trivial_constant(thr, temp, c)
+    _accumulate(thr, temp, pa, a)
+    _accumulate(thr, temp, pb, b)
+    bootstrap(thr, result, cloud_key.bootstrap_key, cloud_key.keyswitch_key, MU, temp, perf_params)
+
+
+def _binary_gate(thr, cloud_key, result, a, b, c, pa, pb, perf_params=None):
     check_shape(result, a, b)
     _check_sizes(cloud_key, result, a, b)
     thr.check_stream()
+    if not single_kernel(perf_params):
+        return _binary_gate_stepwise(thr, cloud_key, result, a, b, int(c), int(pa), int(pb), perf_params)
     res = _Flat(result, result.shape, output=True)
     fa = _Flat(a, result.shape)
     fb = _Flat(b, result.shape)
@@ -81,27 +109,27 @@ def _binary_gate(thr, cloud_key, result, a, b, c, pa, pb):
 
 def gate_nand(thr, cloud_key, result, a, b, perf_params=None):
     """Homomorphic bootstrapped NAND: (0, 1/8) - a - b  (nufhe/gates.py:81-121)."""
-    _binary_gate(thr, cloud_key, result, a, b, phase_to_t32(1, 8), -1, -1)
+    _binary_gate(thr, cloud_key, result, a, b, phase_to_t32(1, 8), -1, -1, perf_params)
 
 
 def gate_or(thr, cloud_key, result, a, b, perf_params=None):
     """Homomorphic bootstrapped OR: (0, 1/8) + a + b  (nufhe/gates.py:124-163)."""
-    _binary_gate(thr, cloud_key, result, a, b, phase_to_t32(1, 8), 1, 1)
+    _binary_gate(thr, cloud_key, result, a, b, phase_to_t32(1, 8), 1, 1, perf_params)
 
 
 def gate_and(thr, cloud_key, result, a, b, perf_params=None):
     """Homomorphic bootstrapped AND: (0, -1/8) + a + b  (nufhe/gates.py:166-205)."""
-    _binary_gate(thr, cloud_key, result, a, b, phase_to_t32(-1, 8), 1, 1)
+    _binary_gate(thr, cloud_key, result, a, b, phase_to_t32(-1, 8), 1, 1, perf_params)
 
 
 def gate_xor(thr, cloud_key, result, a, b, perf_params=None):
     """Homomorphic bootstrapped XOR: (0, 1/4) + 2 (a + b)  (nufhe/gates.py:208-247)."""
-    _binary_gate(thr, cloud_key, result, a, b, phase_to_t32(1, 4), 2, 2)
+    _binary_gate(thr, cloud_key, result, a, b, phase_to_t32(1, 4), 2, 2, perf_params)
 
 
 def gate_xnor(thr, cloud_key, result, a, b, perf_params=None):
     """Homomorphic bootstrapped XNOR: (0, -1/4) - 2 (a + b)  (nufhe/gates.py:250-289)."""
-    _binary_gate(thr, cloud_key, result, a, b, phase_to_t32(-1, 4), -2, -2)
+    _binary_gate(thr, cloud_key, result, a, b, phase_to_t32(-1, 4), -2, -2, perf_params)
 
 
 def gate_not(thr, cloud_key, result, a, perf_params=None):
@@ -129,27 +157,50 @@ def gate_constant(thr, cloud_key, result, vals, perf_params=None):
 
 def gate_nor(thr, cloud_key, result, a, b, perf_params=None):
     """Homomorphic bootstrapped NOR: (0, -1/8) - a - b  (nufhe/gates.py:390-429)."""
-    _binary_gate(thr, cloud_key, result, a, b, phase_to_t32(-1, 8), -1, -1)
+    _binary_gate(thr, cloud_key, result, a, b, phase_to_t32(-1, 8), -1, -1, perf_params)
 
 
 def gate_andny(thr, cloud_key, result, a, b, perf_params=None):
     """Homomorphic bootstrapped AND(NOT a, b): (0, -1/8) - a + b  (nufhe/gates.py:432-471)."""
-    _binary_gate(thr, cloud_key, result, a, b, phase_to_t32(-1, 8), -1, 1)
+    _binary_gate(thr, cloud_key, result, a, b, phase_to_t32(-1, 8), -1, 1, perf_params)
 
 
 def gate_andyn(thr, cloud_key, result, a, b, perf_params=None):
     """Homomorphic bootstrapped AND(a, NOT b): (0, -1/8) + a - b  (nufhe/gates.py:474-513)."""
-    _binary_gate(thr, cloud_key, result, a, b, phase_to_t32(-1, 8), 1, -1)
+    _binary_gate(thr, cloud_key, result, a, b, phase_to_t32(-1, 8), 1, -1, perf_params)
 
 
 def gate_orny(thr, cloud_key, result, a, b, perf_params=None):
     """Homomorphic bootstrapped OR(NOT a, b): (0, 1/8) - a + b  (nufhe/gates.py:516-555)."""
-    _binary_gate(thr, cloud_key, result, a, b, phase_to_t32(1, 8), -1, 1)
+    _binary_gate(thr, cloud_key, result, a, b, phase_to_t32(1, 8), -1, 1, perf_params)
 
 
 def gate_oryn(thr, cloud_key, result, a, b, perf_params=None):
     """Homomorphic bootstrapped OR(a, NOT b): (0, 1/8) + a - b  (nufhe/gates.py:558-597)."""
-    _binary_gate(thr, cloud_key, result, a, b, phase_to_t32(1, 8), 1, -1)
+    _binary_gate(thr, cloud_key, result, a, b, phase_to_t32(1, 8), 1, -1, perf_params)
+
+
+def _mux_stepwise(thr, cloud_key, result, a, b, c, perf_params):
+    """AND(a, b) and AND(NOT a, c) bootstrapped WITHOUT keyswitch, (0, 1/8) + u1 + u2 under the extracted key, one
+    keyswitch (nufhe/gates.py:633-664)."""
+    params = cloud_key.params
+    bk, ks = cloud_key.bootstrap_key, cloud_key.keyswitch_key
+    temp = LweSampleArray.empty(thr, params.in_out_params, result.shape)
+    lwe_noiseless_trivial_constant(thr, temp, phase_to_t32(-1, 8))
+    lwe_add_to(thr, temp, a)
+    lwe_add_to(thr, temp, b)
+    u1 = LweSampleArray.empty(thr, bk.extract_params, result.shape)
+    bootstrap(thr, u1, bk, ks, MU, temp, perf_params, no_keyswitch=True)
+    lwe_noiseless_trivial_constant(thr, temp, phase_to_t32(-1, 8))
+    lwe_sub_to(thr, temp, a)
+    lwe_add_to(thr, temp, c)
+    u2 = LweSampleArray.empty(thr, bk.extract_params, result.shape)
+    bootstrap(thr, u2, bk, ks, MU, temp, perf_params, no_keyswitch=True)
+    total = LweSampleArray.empty(thr, bk.extract_params, result.shape)
+    lwe_noiseless_trivial_constant(thr, total, MU)
+    lwe_add_to(thr, total, u1)
+    lwe_add_to(thr, total, u2)
+    lwe_keyswitch(thr, result, ks, total)
 
 
 def gate_mux(thr, cloud_key, result, a, b, c, perf_params=None):
@@ -160,6 +211,8 @@ def gate_mux(thr, cloud_key, result, a, b, c, perf_params=None):
     check_shape(result, a, b, c)
     _check_sizes(cloud_key, result, a, b, c)
     thr.check_stream()
+    if not single_kernel(perf_params):
+        return _mux_stepwise(thr, cloud_key, result, a, b, c, perf_params)
     res = _Flat(result, result.shape, output=True)
     fa = _Flat(a, result.shape)
     fb = _Flat(b, result.shape)

@@ -1,8 +1,9 @@
 """
-PerformanceParameters: accepted for API compatibility with the reference
-(nufhe/performance.py:22-236) and ignored -- the reference's knobs select between CUDA/OpenCL code
-generation variants (constant memory, transforms per block, PTX vs C arithmetic, single- vs
-multi-kernel bootstrap) that do not exist in the ahead-of-time compiled gfx950 library.
+PerformanceParameters of the reference (nufhe/performance.py:22-236).  Its code-generation knobs -- constant
+memory, transforms per block, PTX vs C arithmetic -- select between CUDA/OpenCL variants that do not exist in the
+ahead-of-time compiled gfx950 library: they are accepted and ignored.  ``single_kernel_bootstrap`` is honoured:
+False runs a gate as the reference's multi-kernel sequence, one launch per step (nufhe_amd/bootstrap.py,
+nufhe_amd/gates.py), True / None takes the fused kernels.
 """
 
 

@@ -1,14 +1,15 @@
 """
-TLWE parameter / key records and the device side of TLWE key material
-(reference: nufhe/tlwe.py:48-207, nufhe/polynomials.py:30-86).
+TLWE parameter / key records, the accumulator container with the per-step operations of the step-by-step
+bootstrap driver, and the device side of TLWE key material (reference: nufhe/tlwe.py:48-207).
 """
 
 import numpy
 
 from . import _lib
 from .device import ptr
-from .lwe import LweParams
-from .numeric_functions import Torus32
+from .lwe import LweParams, LweSampleArray
+from .numeric_functions import Torus32, ErrorFloat
+from .polynomials import IntPolynomialArray, TorusPolynomialArray, shift_tp_minus_one_power_from_array
 from .random_numbers import rand_uniform_bool, rand_uniform_torus32, rand_gaussian_torus32
 
 
@@ -43,15 +44,6 @@ class TLweParams:
 TLweParams.__module__ = 'nufhe.tlwe'
 
 
-class IntPolynomialArray:
-    """nufhe/polynomials.py:30-40"""
-
-    def __init__(self, coeffs):
-        self.coeffs = coeffs
-        self.polynomial_degree = coeffs.shape[-1]
-        self.shape = tuple(coeffs.shape[:-1])
-
-
 class TLweKey:
     """nufhe/tlwe.py:77-91: ``mask_size`` binary polynomials."""
 
@@ -64,6 +56,80 @@ class TLweKey:
         key = IntPolynomialArray(
             rand_uniform_bool(thr, rng, (params.mask_size, params.polynomial_degree)))
         return cls(params, key)
+
+
+class TLweSampleArray:
+    """
+    The accumulator of the blind rotation (nufhe/tlwe.py:94-112): ``a`` = TorusPolynomialArray
+    ``[shape..., k + 1, N]`` (mask polynomials, then the body), ``current_variances [shape...]``.
+    """
+
+    def __init__(self, params: TLweParams, a: TorusPolynomialArray, current_variances):
+        self.a = a
+        self.current_variances = current_variances
+        self.shape = tuple(current_variances.shape)
+        self.params = params
+
+    @classmethod
+    def empty(cls, thr, params: TLweParams, shape):
+        shape = tuple(shape)
+        a = TorusPolynomialArray.empty(thr, params.polynomial_degree, shape + (params.mask_size + 1,))
+        return cls(params, a, thr.zeros(shape, ErrorFloat))
+
+
+def tlwe_noiseless_trivial(thr, result: TLweSampleArray, mu: TorusPolynomialArray):
+    """result = (0, ..., 0, mu) with variance 0 (nufhe/tlwe.py:156-158, TLweNoiselessTrivial tlwe_gpu.py:32-74,
+    tlwe_cpu.py:26-38)."""
+    if tuple(mu.coeffs.shape) != result.shape + (result.params.polynomial_degree,):
+        raise ValueError("mu has shape %s, the samples %s" % (tuple(mu.coeffs.shape), result.shape))
+    thr.check_stream()
+    k = result.params.mask_size
+    result.a.coeffs[..., :k, :] = 0
+    result.a.coeffs[..., k, :] = mu.coeffs
+    result.current_variances.zero_()
+
+
+def tlwe_extract_lwe_samples(thr, result: LweSampleArray, x: TLweSampleArray):
+    """LWE sample of the constant coefficient under the extracted key: a[m N + j] = A_m[0] for j = 0 and
+    -A_m[N - j] otherwise, b = B[0]; the variances are left alone, as in the reference
+    (nufhe/tlwe.py:161-164, tlwe_gpu.mako:54-84, tlwe_cpu.py:41-60)."""
+    k = x.params.mask_size
+    N = x.params.polynomial_degree
+    if N != 1024:
+        raise ValueError("the gfx950 kernels support N=1024")
+    if tuple(result.shape) != x.shape or result.a.shape[-1] != k * N:
+        raise ValueError("result of shape %s x %d does not take the extraction of %s TLWE samples (k = %d)" % (
+            tuple(result.shape), result.a.shape[-1], x.shape, k))
+    thr.check_stream()
+    batch = int(numpy.prod(x.shape)) if x.shape else 1
+    src = x.a.coeffs.contiguous()
+    a = result.a if result.a.is_contiguous() else result.a.new_empty(result.a.shape)
+    b = result.b if result.b.is_contiguous() else result.b.new_empty(result.b.shape)
+    _lib.call("nufhe_tlwe_extract", thr.handle, ptr(a), ptr(b), ptr(src), batch, k)
+    if a is not result.a:
+        result.a.copy_(a)
+    if b is not result.b:
+        result.b.copy_(b)
+
+
+def tlwe_shift_polynomials(thr, result: TLweSampleArray, bk: TLweSampleArray, powers, powers_idx: int):
+    """result.a = (X^powers[..., powers_idx] - 1) * bk.a, all k + 1 polynomials of a sample by the same power
+    (nufhe/tlwe.py:168-169; ``bk`` is the reference's name for the SOURCE sample, kept for keyword callers)."""
+    shift_tp_minus_one_power_from_array(thr, result.a, powers, powers_idx, bk.a)
+
+
+def tlwe_add_to(thr, result: TLweSampleArray, source: TLweSampleArray):
+    """result += source, int32 wraparound on the coefficients (nufhe/tlwe.py:173-175)."""
+    thr.check_stream()
+    result.a.coeffs += source.a.coeffs
+    result.current_variances += source.current_variances
+
+
+def tlwe_copy(thr, result: TLweSampleArray, source: TLweSampleArray):
+    """result = source (nufhe/tlwe.py:179-181)."""
+    thr.check_stream()
+    result.a.coeffs.copy_(source.a.coeffs)
+    result.current_variances.copy_(source.current_variances)
 
 
 def tlwe_encrypt_zero(thr, rng, shape, noise: float, key: TLweKey):

@@ -230,3 +230,27 @@ def test_bench_roofline_helpers_on_tracked_profiles():
     assert k2['bound'] == 'mfma' and 0.2 < k2['frac'] < 0.6
     assert bench.keyswitch_roofline(256, 0.2, False)['bound'] == 'lds'
     assert bench.pmc_traffic('NTT', 'nand', 4096) > 1e8
+
+
+def test_low_level_names_and_signatures_match_the_reference():
+    """The functions of the bootstrap path exist under the reference's module and function names and take the
+    reference's positional parameters in the reference's order (trailing optional parameters may be added), and the
+    containers have its constructors / (de)serializers: tests/golden/reference_signatures.json, extracted from the
+    reference's source by tests/golden/make_reference_signatures.py.  The `nufhe` alias package re-exports them."""
+    import importlib
+    import inspect
+    import json
+    ref = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'reference_signatures.json')))
+    for package in ('nufhe_amd', 'nufhe'):
+        for module, functions in ref['functions'].items():
+            mod = importlib.import_module(package + '.' + module)
+            for name, args in functions.items():
+                have = list(inspect.signature(getattr(mod, name)).parameters)
+                assert have[:len(args)] == args, (package, module, name, args, have)
+                extra = list(inspect.signature(getattr(mod, name)).parameters.values())[len(args):]
+                assert all(p.default is not inspect.Parameter.empty for p in extra), (module, name)
+        for module, classes in ref['classes'].items():
+            mod = importlib.import_module(package + '.' + module)
+            for cname, methods in classes.items():
+                cls = getattr(mod, cname)
+                assert all(callable(getattr(cls, m)) for m in methods), (module, cname)

@@ -247,6 +247,32 @@ def test_small_batch_team_kernel_equals_wave_kernel(env, orc):
         _lib.call("nufhe_ctx_set_team8", thr.handle, 1)
 
 
+def test_replacing_the_key_drops_the_half_ring_copy(env, orc):
+    """The 8-waves-per-bit kernel reads a second, lazily converted copy of the bootstrapping key; uploading other key
+    material into the same handle must invalidate it.  A small gate (makes the copy), a different key uploaded, the same
+    gate again: identical to the 4-waves-per-bit kernel, which reads the primary copy, and different from before."""
+    import ctypes
+    from nufhe_amd import _lib
+    H = env['H']; thr = env['thr']; ck = env['ck']; lwe_key = env['lwe_key']
+    import nufhe_amd
+    cloud_key = H.cloud_key_from_arrays(thr, ck)          # a handle of its own: the module fixture stays untouched
+    vm = env['ctx'].make_virtual_machine(cloud_key)
+    rng = orc.DeterministicRNG(5)
+    ms = [rng.uniform_bool((9,)).astype(bool) for _ in range(2)]
+    ds = [H.ciphertext_from_arrays(thr, orc.encrypt(rng, lwe_key, m)) for m in ms]
+    first = H.ct_arrays(vm.gate_nand(ds[0], ds[1]))
+    other = numpy.ascontiguousarray(numpy.roll(numpy.asarray(ck.bk, numpy.uint64), 1, axis=0))   # rows rotated by one
+    _lib.call("nufhe_bk_upload_reference", cloud_key.bootstrap_key._native.handle, other.ctypes.data_as(ctypes.c_void_p))
+    try:
+        with_copy = H.ct_arrays(vm.gate_nand(ds[0], ds[1]))
+        _lib.call("nufhe_ctx_set_team8", thr.handle, 0)
+        primary = H.ct_arrays(vm.gate_nand(ds[0], ds[1]))
+    finally:
+        _lib.call("nufhe_ctx_set_team8", thr.handle, 1)
+    assert all((x == y).all() for x, y in zip(with_copy, primary))
+    assert (first[0] != primary[0]).any()
+
+
 def test_medium_batch_pair_kernel_every_group_size(env, orc):
     """The 2-waves-per-bit kernel with 1, 2, 3 and 4 pairs per work-group (ragged last group included) against the
     wave-per-bit kernel on the same ciphertexts: bit-identical; the first 24 bits also against the oracle."""

@@ -1,0 +1,204 @@
+"""
+The reference's low-level functions of the bootstrap path under their own names (polynomials.py, tlwe.py, tgsw.py,
+numeric_functions.py, bootstrap.py) and its multi-kernel mode (`single_kernel_bootstrap=False`): every step against the
+CPU oracle, shaped like the reference's unit tests (test/test_polynomials.py:30-58, test_tlwe.py:39-94,
+test_tgsw.py:118-154, test_numeric_functions.py:27-45), and whole gates through the step-by-step driver against the
+fused kernels -- two independently composed device paths that must agree on every word.
+"""
+
+import numpy
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N = 1024
+
+
+@pytest.fixture(scope='module')
+def env(orc, oracle_keys):
+    import gpu_helpers as H
+    from nufhe_amd.device import DeviceThread
+    import nufhe_amd
+    thr = DeviceThread(0)
+    lwe_key, tlwe_key, ck = oracle_keys
+    cloud_key = H.cloud_key_from_arrays(thr, ck)
+    ctx = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(456), thread=thr)
+    return dict(H=H, thr=thr, ctx=ctx, ck=ck, lwe_key=lwe_key, cloud_key=cloud_key)
+
+
+def test_t32_to_phase_vs_oracle(env, orc):
+    from nufhe_amd.numeric_functions import t32_to_phase, Torus32
+    H = env['H']; thr = env['thr']
+    rs = numpy.random.RandomState(1)
+    for shape, mspace in (((10, 20), 2048), ((7,), 6), ((3, 2, 5), 2**31), ((0,), 2048)):
+        phase = rs.randint(-2**31, 2**31, size=shape, dtype=numpy.int64).astype(numpy.int32)
+        if phase.size:
+            phase.flat[0] = -1
+            phase.flat[-1] = 2**31 - 1
+        result = thr.array(shape, Torus32)
+        t32_to_phase(thr, result, H.dev(thr, phase), mspace)
+        assert (H.host(result) == orc.t32_to_phase(phase, mspace)).all(), (shape, mspace)
+    with pytest.raises(ValueError):
+        t32_to_phase(thr, thr.array((4,), Torus32), thr.array((5,), Torus32), 2048)
+    with pytest.raises(ValueError):
+        t32_to_phase(thr, thr.array((4,), Torus32), thr.array((4,), Torus32), 0)
+
+
+def test_shift_torus_polynomials_vs_oracle(env, orc):
+    """X^(2N - p) * source with one power per polynomial; (X^p - 1) * source with the power taken from column
+    ``power_idx`` of a 2-D array and shared by the trailing axes (test/test_polynomials.py:30-58)."""
+    from nufhe_amd.polynomials import (TorusPolynomialArray, shift_tp_inverted_power,
+                                       shift_tp_minus_one_power_from_array)
+    H = env['H']; thr = env['thr']
+    rs = numpy.random.RandomState(2)
+    shape = (2, 3)
+    source = rs.randint(-2**31, 2**31, size=shape + (N,), dtype=numpy.int64).astype(numpy.int32)
+    powers = rs.randint(0, 2 * N, size=shape).astype(numpy.int32)
+    powers[0, 0] = 0; powers[0, 1] = N; powers[1, 2] = 2 * N - 1
+    src = TorusPolynomialArray(H.dev(thr, source))
+    res = TorusPolynomialArray.empty(thr, N, shape)
+    shift_tp_inverted_power(thr, res, H.dev(thr, powers), src)
+    assert (H.host(res.coeffs) == orc.shift_torus_polynomial(source, powers, invert_powers=True)).all()
+
+    batch, k1, rows = (4,), 2, 5
+    source = rs.randint(-2**31, 2**31, size=batch + (k1, N), dtype=numpy.int64).astype(numpy.int32)
+    powers = rs.randint(0, 2 * N, size=batch + (rows,)).astype(numpy.int32)
+    powers[0, 3] = 0; powers[1, 3] = N
+    src = TorusPolynomialArray(H.dev(thr, source))
+    res = TorusPolynomialArray.empty(thr, N, batch + (k1,))
+    for idx in (0, 3, rows - 1):
+        shift_tp_minus_one_power_from_array(thr, res, H.dev(thr, powers), idx, src)
+        assert (H.host(res.coeffs) == orc.shift_torus_polynomial(source, powers[:, idx], minus_one=True)).all(), idx
+    with pytest.raises(ValueError):
+        shift_tp_minus_one_power_from_array(thr, res, H.dev(thr, powers), rows, src)
+    with pytest.raises(ValueError):
+        shift_tp_inverted_power(thr, src, H.dev(thr, powers[:, 0]), src)          # in place
+    with pytest.raises(ValueError):
+        shift_tp_inverted_power(thr, res, H.dev(thr, powers[:3, 0]), src)         # powers of another batch
+
+
+def test_tlwe_trivial_extract_add_copy_vs_oracle(env, orc):
+    """test/test_tlwe.py:39-94 for both mask sizes"""
+    from nufhe_amd.polynomials import TorusPolynomialArray
+    from nufhe_amd.tlwe import (TLweParams, TLweSampleArray, tlwe_noiseless_trivial, tlwe_extract_lwe_samples,
+                                tlwe_add_to, tlwe_copy)
+    from nufhe_amd.lwe import LweSampleArray
+    H = env['H']; thr = env['thr']
+    rs = numpy.random.RandomState(3)
+    for k in (1, 2):
+        params = TLweParams(N, k, 1e-9, 1e-3, 'NTT')
+        shape = (3, 2)
+        mu = rs.randint(-2**31, 2**31, size=shape + (N,), dtype=numpy.int64).astype(numpy.int32)
+        sample = TLweSampleArray.empty(thr, params, shape)
+        sample.a.coeffs.fill_(7); sample.current_variances.fill_(3.0)
+        tlwe_noiseless_trivial(thr, sample, TorusPolynomialArray(H.dev(thr, mu)))
+        exp_a, exp_cv = orc.tlwe_noiseless_trivial(mu, k)
+        assert (H.host(sample.a.coeffs) == exp_a).all() and (H.host(sample.current_variances) == exp_cv).all()
+
+        a = rs.randint(-2**31, 2**31, size=shape + (k + 1, N), dtype=numpy.int64).astype(numpy.int32)
+        sample = TLweSampleArray(params, TorusPolynomialArray(H.dev(thr, a)), thr.zeros(shape, numpy.float32))
+        out = LweSampleArray.empty(thr, params.extracted_lweparams, shape)
+        tlwe_extract_lwe_samples(thr, out, sample)
+        exp_a, exp_b = orc.tlwe_extract_lwe_samples(a)
+        assert (H.host(out.a) == exp_a).all() and (H.host(out.b) == exp_b).all()
+        with pytest.raises(ValueError):
+            tlwe_extract_lwe_samples(thr, LweSampleArray.empty(thr, params.extracted_lweparams, (3,)), sample)
+
+        other = TLweSampleArray.empty(thr, params, shape)
+        tlwe_copy(thr, other, sample)
+        other.current_variances.fill_(0.5)
+        tlwe_add_to(thr, other, sample)
+        assert (H.host(other.a.coeffs) == (a.astype(numpy.int64) * 2).astype(numpy.int32)).all()     # wraps
+        assert (H.host(other.current_variances) == 0.5).all()
+
+
+def test_external_mul_and_blind_rotate_steps_vs_oracle(env, orc):
+    """tgsw_transformed_external_mul on rows of the real key (test/test_tgsw.py:118-154), then `blind_rotate` over
+    the first rows composed from mux_rotate steps: against the oracle and against the fused loop of the library."""
+    from nufhe_amd import _lib
+    from nufhe_amd.device import ptr
+    from nufhe_amd.polynomials import TorusPolynomialArray
+    from nufhe_amd.tlwe import TLweSampleArray
+    from nufhe_amd.tgsw import tgsw_transformed_external_mul
+    from nufhe_amd.bootstrap import blind_rotate
+    H = env['H']; thr = env['thr']; ck = env['ck']; bk = env['cloud_key'].bootstrap_key
+    rs = numpy.random.RandomState(4)
+    shape = (3,)
+    accum = rs.randint(-2**31, 2**31, size=shape + (2, N), dtype=numpy.int64).astype(numpy.int32)
+    params = bk.accum_params
+    for row in (0, 7, 499):
+        sample = TLweSampleArray(params, TorusPolynomialArray(H.dev(thr, accum)), thr.zeros(shape, numpy.float32))
+        tgsw_transformed_external_mul(thr, sample, bk.tgsw, row)
+        assert (H.host(sample.a.coeffs) == orc.tgsw_external_mul(accum, ck.bk, row)).all(), row
+    with pytest.raises(ValueError):
+        tgsw_transformed_external_mul(thr, sample, bk.tgsw, 500)
+
+    rows = 9                                                   # odd: the result ends in the temporary and is copied back
+    bara = rs.randint(0, 2 * N, size=shape + (500,)).astype(numpy.int32)
+    bara[0, 2] = 0
+    sample = TLweSampleArray(params, TorusPolynomialArray(H.dev(thr, accum)), thr.zeros(shape, numpy.float32))
+    blind_rotate(thr, sample, bk, H.dev(thr, bara), rows)
+    exp = orc.blind_rotate(accum, ck.bk, bara, n_iter=rows)
+    assert (H.host(sample.a.coeffs) == exp).all()
+    fused = H.dev(thr, accum)
+    _lib.call("nufhe_blind_rotate", thr.handle, bk._native.handle, ptr(fused), ptr(H.dev(thr, bara)), 500, rows, 3)
+    assert (H.host(fused) == exp).all()
+
+
+def _stepwise_vm(env):
+    import nufhe_amd
+    params = env['cloud_key'].params
+    perf = nufhe_amd.PerformanceParameters(params, single_kernel_bootstrap=False)
+    return env['ctx'].make_virtual_machine(env['cloud_key'], perf_params=perf)
+
+
+def test_gates_step_by_step_equal_fused_and_oracle(env, orc):
+    """NAND, XOR (multiplying linear forms), ANDNY (mixed signs) and MUX through the reference's multi-kernel sequence
+    -- trivial constant, linear combinations, mod-switch, shift, trivial accumulator, 500 x (shift, external product,
+    add), extract, keyswitch, each one launch -- against the fused gate kernels and the oracle: every word and
+    variance identical."""
+    H = env['H']; thr = env['thr']; ck = env['ck']; lwe_key = env['lwe_key']
+    rng = orc.DeterministicRNG(31)
+    shape = (2, 3)
+    ms = [rng.uniform_bool(shape).astype(bool) for _ in range(3)]
+    cs = [orc.encrypt(rng, lwe_key, m) for m in ms]
+    ds = [H.ciphertext_from_arrays(thr, c) for c in cs]
+    fused = env['ctx'].make_virtual_machine(env['cloud_key'])
+    steps = _stepwise_vm(env)
+    assert steps.perf_params.single_kernel_bootstrap is False
+    for name in ('gate_nand', 'gate_xor', 'gate_andny'):
+        got = H.ct_arrays(getattr(steps, name)(ds[0], ds[1]))
+        ref = H.ct_arrays(getattr(fused, name)(ds[0], ds[1]))
+        exp = orc.gate(name, ck, cs[0], cs[1])
+        for g, r, e in zip(got, ref, exp):
+            assert (g == r).all() and (g == e).all(), name
+    got = H.ct_arrays(steps.gate_mux(ds[0], ds[1], ds[2]))
+    ref = H.ct_arrays(fused.gate_mux(ds[0], ds[1], ds[2]))
+    exp = orc.gate_mux(ck, cs[0], cs[1], cs[2])
+    for g, r, e in zip(got, ref, exp):
+        assert (g == r).all() and (g == e).all()
+    # broadcasting and a preallocated destination behave as in the fused mode
+    row = H.ciphertext_from_arrays(thr, tuple(x[0] for x in cs[1]))           # shape (3,)
+    dest = env['ctx'].make_virtual_machine(env['cloud_key']).empty_ciphertext(shape)
+    steps.gate_nand(ds[0], row, dest=dest)
+    ref = H.ct_arrays(fused.gate_nand(ds[0], row))
+    assert all((g == r).all() for g, r in zip(H.ct_arrays(dest), ref))
+
+
+def test_bootstrap_without_keyswitch_step_by_step(env, orc):
+    """`bootstrap(..., no_keyswitch=True)` through the step-by-step driver: the extracted LWE(1024) sample equals the
+    fused kernel's (gates.py:633-655 building block)."""
+    import nufhe_amd
+    from nufhe_amd.bootstrap import bootstrap
+    from nufhe_amd import lwe as L
+    H = env['H']; thr = env['thr']; lwe_key = env['lwe_key']; cloud_key = env['cloud_key']
+    rng = orc.DeterministicRNG(32)
+    m = rng.uniform_bool((4,)).astype(bool)
+    x = H.ciphertext_from_arrays(thr, orc.encrypt(rng, lwe_key, m))
+    bk, ks = cloud_key.bootstrap_key, cloud_key.keyswitch_key
+    perf = nufhe_amd.PerformanceParameters(cloud_key.params, single_kernel_bootstrap=False).for_device()
+    a = L.LweSampleArray.empty(thr, bk.extract_params, (4,))
+    b = L.LweSampleArray.empty(thr, bk.extract_params, (4,))
+    bootstrap(thr, a, bk, ks, 2**29, x, perf, no_keyswitch=True)
+    bootstrap(thr, b, bk, ks, 2**29, x, None, no_keyswitch=True)
+    assert (H.host(a.a) == H.host(b.a)).all() and (H.host(a.b) == H.host(b.b)).all()
