@@ -1,6 +1,7 @@
 """One-off extended parity run (not part of the test-suite: ~2 minutes of CPU oracle time on the GPU
 box): every output word of 2048-bit NAND / XOR / MUX gates from the GPU (wave-per-bit kernel), of
-300-bit gates (team kernel) and of a 256-bit k=2 NAND equals the CPU oracle.  Prints one JSON line."""
+700-bit gates (2-waves-per-bit kernel), 200-bit gates (8-waves-per-bit half-ring kernel; the MUX = 400 bootstraps goes
+to the pair kernel) and of a 256-bit k=2 NAND equals the CPU oracle.  Prints one JSON line."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -38,7 +39,7 @@ def run(thr, params, oparams, seed, sizes):
 
 def main():
     thr = DeviceThread(0)
-    res = {"k1": run(thr, nufhe_amd.NuFHEParameters(), orc.Params(), 123, [(2048, ['nand', 'xor', 'mux']), (300, ['nand', 'mux'])]),
+    res = {"k1": run(thr, nufhe_amd.NuFHEParameters(), orc.Params(), 123, [(2048, ['nand', 'xor', 'mux']), (700, ['nand']), (200, ['nand', 'xnor', 'mux']), (100, ['mux'])]),
            "k2": run(thr, nufhe_amd.NuFHEParameters(tlwe_mask_size=2), orc.Params(mask_size=2), 123, [(256, ['nand'])])}
     res["total_differing"] = sum(v["differing"] for part in ("k1", "k2") for v in res[part].values())
     print(json.dumps(res))
