@@ -232,7 +232,7 @@ int nufhe_ctx_set_team_max_bits(nufhe_ctx *ctx, long bits);
  * batch above the small-batch limit (rounds of 2 x CUs bits; with 0 the one-wavefront-per-bit kernels run instead). */
 int nufhe_ctx_set_pair_max_bits(nufhe_ctx *ctx, long bits);
 /* NTT, k = 1: batches up to the team limit run EIGHT wavefronts per bit (two per digit transform, the two half rings of
- * X^1024 + 1 = (X^512 - i)(X^512 + i); csrc/ntt512_half.h) instead of four -- 5.0 ms instead of 5.8 ms per gate (measured); the key
+ * X^1024 + 1 = (X^512 - i)(X^512 + i); csrc/ntt512_half.h) instead of four -- 4.8 ms instead of 5.8 ms per gate (measured); the key
  * is kept a second time in the half-ring layout (made on first use).  0 switches back to the 4-wave team kernel (default
  * 1).  Identical results either way. */
 int nufhe_ctx_set_team8(nufhe_ctx *ctx, int enable);

@@ -567,9 +567,10 @@ FF_FN void brt_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSou
 //   wave w = 4 m + 2 d + h   decomposes digit d of polynomial m of (X^a - 1) ACC (as in brt_step), folds it into half
 //                            ring h, transforms it (8 values per lane) and multiplies it with its half of BK_i[m][d][0..1]
 //   barrier; wave 2 mo + h (w < 4) adds the four partial sums of output polynomial mo in half ring h and transforms back
-//   barrier; the two halves of an output meet: wave (mo, 0) forms a_lo = Y^0 + Y^1 and updates ACC[mo][0..511],
-//            wave (mo, 1) forms a_hi = i (Y^1 - Y^0) and updates ACC[mo][512..1023]; barrier.
-// Critical path: one HALF forward + one HALF inverse transform (~0.6 of the 4-wave team's).  Every step is exact in
+//   barrier; the two halves of an output meet: a_lo = Y^0 + Y^1 updates ACC[mo][0..511], a_hi = i (Y^1 - Y^0) updates
+//            ACC[mo][512..1023] -- 4 x 512 coefficients, spread over all eight waves (256 each); barrier.
+// Critical path: one HALF forward + one HALF inverse transform (measured 0.85 of the 4-wave team's: the forward phase
+// is bound by the CU's issue slots, profiles/r03c_team8_phases.txt).  Every step is exact in
 // GF(P), so the result equals the other kernels bit for bit.  The key is read in the half-ring layout
 // [row][m][d][mo][h][reg 8][lane 64] (the same field elements in another order: nth_freq_index, k_bk_to_half).
 // ------------------------------------------------------------------------------------------
@@ -611,7 +612,7 @@ FF_FN void brh_step(u32 a, const u64 *row, const BrHalfLds &lds, int lane, int w
     BRH_BEGIN();
     const int m = w >> 2, h = w & 1;
     const int sh = (w & 2) ? 12 : 22;      // digit d = (w >> 1) & 1: shift 32 - 10 (d + 1)
-    // this wave's half of BK_i[m][d][mo], mo = 0, 1: 16 loads issued before anything else (the wave is alone on its SIMD)
+    // this wave's half of BK_i[m][d][mo], mo = 0, 1: 16 loads issued before anything else (registers to spare)
     u64 kq[2][8];
     {
         const u64 *kp = row + ((long)(w >> 1) * 2 * 2 + h) * BKH_POLY_ELEMS + lane;     // [m][d][mo = 0][h]
@@ -639,7 +640,7 @@ FF_FN void brh_step(u32 a, const u64 *row, const BrHalfLds &lds, int lane, int w
 #pragma unroll
     for (int mo = 0; mo < 2; mo++)
 #pragma unroll
-        for (int r = 0; r < 8; r++) lds.part[((w * 2 + mo) * 8 + r) * 64 + lane] = ff_mul(ff_canon(x[r]), kq[mo][r]);
+        for (int r = 0; r < 8; r++) lds.part[((w * 2 + mo) * 8 + r) * 64 + lane] = ff_mul(x[r], kq[mo][r]);   // any 64-bit representative of x
     BRH_MARK(2);
     team_sync();
     BRH_MARK(3);
@@ -663,10 +664,12 @@ FF_FN void brh_step(u32 a, const u64 *row, const BrHalfLds &lds, int lane, int w
     }
     team_sync();
     BRH_MARK(6);
-    if (w < 4) {
-        const int mo = w >> 1;
+    {
+        // wave w joins registers 4 (w >> 2) .. + 3 of output polynomial (w >> 1) & 1, coefficient half h
+        const int mo = (w >> 1) & 1;
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
+        for (int q = 0; q < 4; q++) {
+            const int r = 4 * (w >> 2) + q;
             const u64 y0 = lds.join[((mo * 2 + 0) * 8 + r) * 64 + lane], y1 = lds.join[((mo * 2 + 1) * 8 + r) * 64 + lane];
             // a_j' = Y^0 + Y^1 (half 0 writes it), a_(j'+512) = i (Y^1 - Y^0) (half 1); ntt.mako:402-408 for the conversion
             const u64 v = h == 0 ? ff_add(y0, y1) : ff_mul_pow2<48>(ff_sub(y1, y0));
