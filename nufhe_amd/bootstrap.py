@@ -25,8 +25,8 @@ from .device import ptr
 from .lwe import LweParams, LweKey, LweSampleArray, LweKeyswitchKey, _Flat, check_lwe_size, lwe_keyswitch
 from .numeric_functions import Torus32, t32_to_phase
 from .polynomials import TorusPolynomialArray, shift_tp_inverted_power
-from .tgsw import (TGswKey, TGswParams, TransformedTGswSampleArray, tgsw_encrypt_int,
-                   tgsw_transformed_external_mul)
+from .tgsw import (TGswKey, TGswParams, TGswSampleArray, TransformedTGswSampleArray, tgsw_encrypt_int,
+                   tgsw_transform_samples, tgsw_transformed_external_mul)
 from .tlwe import (TLweSampleArray, tlwe_noiseless_trivial, tlwe_extract_lwe_samples, tlwe_shift_polynomials,
                    tlwe_add_to, tlwe_copy)
 from .utils import arrays_equal
@@ -89,11 +89,13 @@ class BootstrapKey:
         bk_params = tgsw_key.params
         accum_params = bk_params.tlwe_params
         # non-transformed key: TGSW encryptions of the LWE key bits (bootstrap.py:67-69)
-        bk = tgsw_encrypt_int(thr, rng, lwe_key.key, accum_params.min_noise, tgsw_key)
+        bk = TGswSampleArray.empty(thr, bk_params, (in_out_params.size,))
+        tgsw_encrypt_int(thr, rng, bk, lwe_key.key, accum_params.min_noise, tgsw_key, perf_params)
         # to the transformed domain, where it is used (bootstrap.py:72-74)
-        _lib.call("nufhe_bk_from_coeffs", native.handle, ptr(bk.contiguous()))
+        key = cls(in_out_params, bk_params, native)
+        tgsw_transform_samples(thr, key.tgsw, bk, perf_params)
         thr.synchronize()
-        return cls(in_out_params, bk_params, native)
+        return key
 
     def transformed_reference_format(self):
         """Host array in the reference's storage format: uint64 [n, k+1, l, k+1, N] (NTT) or

@@ -51,24 +51,57 @@ class TGswKey:
         return cls(params, TLweKey.from_rng(thr, params.tlwe_params, rng))
 
 
-def tgsw_encrypt_int(thr, rng, messages, noise: float, key: TGswKey):
+class TGswSampleArray:
     """
-    TGSW encryptions of the integer ``messages`` (one per entry): int32 device array
-    ``messages.shape + (k+1, l, k+1, N)`` (nufhe/tgsw.py:155-161).
-    result = TGSW(0) + message * H, H = gadget: adds message * 2^(32 - Bgbit (d+1)) to
-    coefficient 0 of polynomial m of row (m, d)  (tgsw_cpu.py:121-124).
+    TGSW samples before the transform (nufhe/tgsw.py:81-96): ``samples`` is a TLweSampleArray of shape
+    ``shape + (k + 1, l)`` -- row (m, d) of a sample is the TLWE encryption that carries the gadget entry
+    2^(32 - Bgbit (d + 1)) on polynomial m.
     """
-    params = key.params
-    k1 = params.tlwe_params.mask_size + 1
-    l = params.decomp_length
-    shape = tuple(messages.shape)
-    if l != 2 or params.bs_log2_base != 10:
+
+    def __init__(self, params: TGswParams, samples: TLweSampleArray):
+        self.mask_size = params.tlwe_params.mask_size
+        self.decomp_length = params.decomp_length
+        self.samples = samples
+        self.params = params
+        self.shape = tuple(samples.shape[:-2])
+
+    @classmethod
+    def empty(cls, thr, params: TGswParams, shape):
+        rows = (params.tlwe_params.mask_size + 1, params.decomp_length)
+        return cls(params, TLweSampleArray.empty(thr, params.tlwe_params, tuple(shape) + rows))
+
+
+def _check_gadget(params: TGswParams):
+    if params.decomp_length != 2 or params.bs_log2_base != 10:
         raise ValueError("the gfx950 kernels support bs_decomp_length=2, bs_log2_base=10")
-    result = tlwe_encrypt_zero(thr, rng, shape + (k1, l), noise, key.tlwe_key)
-    count = int(numpy.prod(shape)) if len(shape) else 1
-    messages = int32_operand("TGSW messages", messages, thr.device)        # the kernel reads int32
-    _lib.call("nufhe_tgsw_add_message", thr.handle, ptr(result), ptr(messages), count, k1 - 1)
-    return result
+
+
+def tgsw_encrypt_zero(thr, rng, result: TGswSampleArray, noise: float, key: TGswKey, perf_params=None):
+    """result = TGSW(0): every row a fresh TLWE encryption of zero (nufhe/tgsw.py:148-151)."""
+    tlwe_encrypt_zero(thr, rng, result.samples, noise, key.tlwe_key, perf_params)
+
+
+def tgsw_add_message(thr, result: TGswSampleArray, messages):
+    """result += messages * H, H the gadget: adds message * 2^(32 - Bgbit (d + 1)) to coefficient 0 of polynomial m
+    of row (m, d) (nufhe/tgsw.py:142-145, TGswAddMessage tgsw_gpu.mako:18-39, reference tgsw_cpu.py:109-126);
+    ``messages``: one integer per sample."""
+    _check_gadget(result.params)
+    shape = result.shape
+    count = int(numpy.prod(shape)) if shape else 1
+    messages = int32_operand("TGSW messages", messages, thr.device, shape=shape)        # the kernel reads int32
+    thr.check_stream()
+    coeffs = result.samples.a.coeffs
+    work = coeffs if coeffs.is_contiguous() else coeffs.contiguous()
+    _lib.call("nufhe_tgsw_add_message", thr.handle, ptr(work), ptr(messages), count, result.mask_size)
+    if work is not coeffs:
+        coeffs.copy_(work)
+
+
+def tgsw_encrypt_int(thr, rng, result: TGswSampleArray, messages, noise: float, key: TGswKey, perf_params=None):
+    """result = TGSW encryptions of the integer ``messages`` (nufhe/tgsw.py:155-161)."""
+    _check_gadget(key.params)
+    tgsw_encrypt_zero(thr, rng, result, noise, key, perf_params)
+    tgsw_add_message(thr, result, messages)
 
 
 class TransformedTGswSampleArray:
@@ -80,9 +113,22 @@ class TransformedTGswSampleArray:
     """
 
     def __init__(self, params: TGswParams, native, length: int):
+        self.mask_size = params.tlwe_params.mask_size
+        self.decomp_length = params.decomp_length
         self.params = params
         self.shape = (int(length),)
         self._native = native
+
+    @classmethod
+    def empty(cls, thr, params: TGswParams, shape):
+        """Device storage for ``shape = (n,)`` transformed samples (a key handle of its own, without a keyswitch
+        key; nufhe/tgsw.py:108-114)."""
+        from .bootstrap import NativeCloudKey
+        shape = tuple(shape)
+        if len(shape) != 1:
+            raise ValueError("the transformed samples of a bootstrapping key form a one-dimensional array")
+        native = NativeCloudKey(thr, shape[0], params.tlwe_params.transform_type, params.tlwe_params.mask_size)
+        return cls(params, native, shape[0])
 
 
 def tgsw_transformed_external_mul(thr, result: TLweSampleArray, bootstrap_key: TransformedTGswSampleArray,
@@ -107,3 +153,13 @@ def tgsw_transformed_external_mul(thr, result: TLweSampleArray, bootstrap_key: T
     _lib.call("nufhe_external_mul", thr.handle, bootstrap_key._native.handle, ptr(work), int(bk_row_idx), batch)
     if work is not acc:
         acc.copy_(work)
+
+
+def tgsw_transform_samples(thr, result: TransformedTGswSampleArray, source: TGswSampleArray, perf_params=None):
+    """result = forward transform of every polynomial of ``source`` in the form the external product multiplies with
+    (nufhe/tgsw.py:134-138 -> tlwe_transform_samples tlwe.py:199-207, TLweTransformSamples tlwe_gpu.py:199-236: transform
+    + Montgomery preparation in the reference; here the library's wave layout)."""
+    if source.params != result.params or source.shape != result.shape:
+        raise ValueError("source of shape %s does not fill transformed samples of shape %s" % (source.shape, result.shape))
+    thr.check_stream()
+    _lib.call("nufhe_bk_from_coeffs", result._native.handle, ptr(source.samples.a.coeffs.contiguous()))

@@ -132,22 +132,27 @@ def tlwe_copy(thr, result: TLweSampleArray, source: TLweSampleArray):
     result.current_variances.copy_(source.current_variances)
 
 
-def tlwe_encrypt_zero(thr, rng, shape, noise: float, key: TLweKey):
+def tlwe_encrypt_zero(thr, rng, result: TLweSampleArray, noise: float, key: TLweKey, perf_params=None):
     """
-    Homogeneous TLWE samples of zero (nufhe/tlwe.py:185-196, TLweEncryptZero tlwe_gpu.py:111-196):
-    returns an int32 device array ``shape + (k + 1, N)``.  Randomness is drawn on the host in the
-    reference's order (uniform mask first, then the Gaussian body noise); the polynomial products
-    run on the GPU (forward NTT x forward NTT -> pointwise product -> inverse NTT).
+    Fills ``result`` with homogeneous TLWE samples of zero, variance noise^2 (nufhe/tlwe.py:185-196, TLweEncryptZero
+    tlwe_gpu.py:111-196, reference tlwe_cpu.py:64-89): a = (uniform mask, Gaussian noise + sum_i mask_i * key_i).
+    Randomness is drawn on the host in the reference's order (uniform mask first, then the Gaussian body noise); the
+    polynomial products run on the GPU (forward NTT x forward NTT -> pointwise product -> inverse NTT).
     """
     params = key.params
     if params.polynomial_degree != 1024:
         raise ValueError("the gfx950 kernels support N=1024")
+    if result.params != params:
+        raise ValueError("the samples and the key have different TLWE parameters")
     k = params.mask_size
-    shape = tuple(shape)
+    shape = result.shape
     noises1 = rand_uniform_torus32(thr, rng, shape + (k, 1024))
     noises2 = rand_gaussian_torus32(thr, rng, 0, noise, shape + (1024,))
-    batch = int(numpy.prod(shape))
-    result = thr.array(shape + (k + 1, 1024), Torus32)
-    _lib.call("nufhe_tlwe_encrypt_zero", thr.handle, ptr(result), ptr(key.key.coeffs.contiguous()),
+    batch = int(numpy.prod(shape)) if shape else 1
+    thr.check_stream()
+    out = result.a.coeffs if result.a.coeffs.is_contiguous() else result.a.coeffs.new_empty(result.a.coeffs.shape)
+    _lib.call("nufhe_tlwe_encrypt_zero", thr.handle, ptr(out), ptr(key.key.coeffs.contiguous()),
               ptr(noises1), ptr(noises2), batch, k)
-    return result
+    if out is not result.a.coeffs:
+        result.a.coeffs.copy_(out)
+    result.current_variances.fill_(float(noise) ** 2)

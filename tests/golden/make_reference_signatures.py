@@ -13,8 +13,10 @@ REF = '/root/reference/nufhe'
 FUNCTIONS = {
     'numeric_functions': ['phase_to_t32', 't32_to_phase', 'double_to_t32'],
     'polynomials': ['shift_tp_inverted_power', 'shift_tp_minus_one_power_from_array'],
-    'tlwe': ['tlwe_noiseless_trivial', 'tlwe_extract_lwe_samples', 'tlwe_shift_polynomials', 'tlwe_add_to', 'tlwe_copy'],
-    'tgsw': ['tgsw_transformed_external_mul'],
+    'tlwe': ['tlwe_noiseless_trivial', 'tlwe_extract_lwe_samples', 'tlwe_shift_polynomials', 'tlwe_add_to', 'tlwe_copy',
+             'tlwe_encrypt_zero'],
+    'tgsw': ['tgsw_transformed_external_mul', 'tgsw_encrypt_zero', 'tgsw_add_message', 'tgsw_encrypt_int',
+             'tgsw_transform_samples'],
     'bootstrap': ['mux_rotate', 'blind_rotate', 'blind_rotate_and_extract', 'bootstrap'],
     'lwe': ['lwe_keyswitch', 'lwe_noiseless_trivial', 'lwe_noiseless_trivial_constant', 'lwe_negate', 'lwe_copy',
             'lwe_add_to', 'lwe_add_mul_to', 'lwe_sub_to', 'lwe_sub_mul_to', 'lwe_encrypt', 'lwe_decrypt'],
@@ -24,7 +26,7 @@ FUNCTIONS = {
 CLASSES = {
     'polynomials': {'TorusPolynomialArray': ['empty']},
     'tlwe': {'TLweSampleArray': ['empty'], 'TLweParams': [], 'TLweKey': ['from_rng']},
-    'tgsw': {'TGswParams': [], 'TGswKey': ['from_rng'], 'TransformedTGswSampleArray': []},
+    'tgsw': {'TGswParams': [], 'TGswKey': ['from_rng'], 'TGswSampleArray': ['empty'], 'TransformedTGswSampleArray': ['empty']},
     'bootstrap': {'BootstrapKey': ['from_rng', 'dump', 'load']},
     'lwe': {'LweSampleArray': ['empty', 'copy', 'roll', 'dump', 'dumps', 'load', 'loads'],
             'LweKeyswitchKey': ['from_tgsw_key', 'dump', 'load'], 'LweParams': [], 'LweKey': ['from_rng', 'from_tlwe_key']},

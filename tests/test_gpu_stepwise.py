@@ -202,3 +202,63 @@ def test_bootstrap_without_keyswitch_step_by_step(env, orc):
     bootstrap(thr, a, bk, ks, 2**29, x, perf, no_keyswitch=True)
     bootstrap(thr, b, bk, ks, 2**29, x, None, no_keyswitch=True)
     assert (H.host(a.a) == H.host(b.a)).all() and (H.host(a.b) == H.host(b.b)).all()
+
+
+def test_key_generation_steps_vs_oracle(env, orc):
+    """The reference's key-generation functions under their own signatures (tgsw.py:134-161, tlwe.py:185-207;
+    test/test_tlwe.py:97-141, test_tgsw.py:157-196 shapes): TLWE / TGSW encryptions of zero from the reference's random
+    draws, the gadget message, and the transform into the key the external product reads."""
+    import nufhe_amd
+    from nufhe_amd.tlwe import TLweKey, TLweSampleArray, tlwe_encrypt_zero
+    from nufhe_amd.polynomials import IntPolynomialArray
+    from nufhe_amd.tgsw import (TGswKey, TGswSampleArray, TransformedTGswSampleArray, tgsw_encrypt_zero, tgsw_add_message,
+                                tgsw_encrypt_int, tgsw_transform_samples, tgsw_transformed_external_mul)
+    from nufhe_amd.tlwe import TLweSampleArray as Acc
+    from nufhe_amd.polynomials import TorusPolynomialArray
+    H = env['H']; thr = env['thr']
+    params = nufhe_amd.NuFHEParameters()
+    tgsw_params = params.tgsw_params
+    tlwe_params = tgsw_params.tlwe_params
+    noise = tlwe_params.min_noise
+    key_bits = numpy.random.RandomState(9).randint(0, 2, size=(1, N)).astype(numpy.int32)
+    tlwe_key = TLweKey(tlwe_params, IntPolynomialArray(H.dev(thr, key_bits)))
+
+    # TLWE encryptions of zero: the same draws through the oracle's RNG (uniform mask, then Gaussian noise)
+    shape = (3, 2)
+    seed = 77
+    sample = TLweSampleArray.empty(thr, tlwe_params, shape)
+    tlwe_encrypt_zero(thr, nufhe_amd.DeterministicRNG(seed), sample, noise, tlwe_key)
+    orng = orc.DeterministicRNG(seed)
+    n1 = orng.uniform_torus32(shape + (1, N))
+    n2 = orc.rand_gaussian_torus32(orng, 0, noise, shape + (N,))
+    exp_a, exp_cv = orc.tlwe_encrypt_zero(key_bits, n1, n2, noise)
+    assert (H.host(sample.a.coeffs) == exp_a).all() and (H.host(sample.current_variances) == exp_cv).all()
+
+    # TGSW(message): zero encryptions + gadget; then the transform, used by one external product
+    n = 5
+    messages = numpy.array([1, 0, 1, 1, 0], numpy.int32)
+    tgsw_key = TGswKey(tgsw_params, tlwe_key)
+    tgsw = TGswSampleArray.empty(thr, tgsw_params, (n,))
+    assert tgsw.shape == (n,) and tuple(tgsw.samples.a.coeffs.shape) == (n, 2, 2, 2, N)
+    tgsw_encrypt_int(thr, nufhe_amd.DeterministicRNG(seed + 1), tgsw, H.dev(thr, messages), noise, tgsw_key)
+    orng = orc.DeterministicRNG(seed + 1)
+    n1 = orng.uniform_torus32((n, 2, 2, 1, N))
+    n2 = orc.rand_gaussian_torus32(orng, 0, noise, (n, 2, 2, N))
+    zero_a, _ = orc.tlwe_encrypt_zero(key_bits, n1, n2, noise)
+    exp = orc.tgsw_add_message(zero_a, messages)
+    assert (H.host(tgsw.samples.a.coeffs) == exp).all()
+    again = TGswSampleArray.empty(thr, tgsw_params, (n,))
+    tgsw_encrypt_zero(thr, nufhe_amd.DeterministicRNG(seed + 1), again, noise, tgsw_key)
+    assert (H.host(again.samples.a.coeffs) == zero_a).all()
+    tgsw_add_message(thr, again, H.dev(thr, messages))
+    assert (H.host(again.samples.a.coeffs) == exp).all()
+    with pytest.raises(ValueError):
+        tgsw_add_message(thr, again, H.dev(thr, messages[:3]))
+
+    transformed = TransformedTGswSampleArray.empty(thr, tgsw_params, (n,))
+    tgsw_transform_samples(thr, transformed, tgsw)
+    bk = orc.tlwe_transform_samples(exp)                      # reference format: forward NTT + Montgomery preparation
+    accum = numpy.random.RandomState(10).randint(-2**31, 2**31, size=(2, 2, N), dtype=numpy.int64).astype(numpy.int32)
+    acc = Acc(tlwe_params, TorusPolynomialArray(H.dev(thr, accum)), thr.zeros((2,), numpy.float32))
+    tgsw_transformed_external_mul(thr, acc, transformed, 3)
+    assert (H.host(acc.a.coeffs) == orc.tgsw_external_mul(accum, bk, 3)).all()
