@@ -6,11 +6,25 @@ the functions here exist for callers of the reference's low-level API and for th
 (`PerformanceParameters(single_kernel_bootstrap=False)`, nufhe_amd/bootstrap.py).
 """
 
+import pickle
+
 import numpy
 
 from . import _lib
 from .device import ptr, int32_operand
 from .numeric_functions import Torus32
+from .utils import arrays_equal
+
+
+def transformed_dtype(transform_type):
+    """Element type of a transformed polynomial: residues mod 2^64 - 2^32 + 1 as uint64 (NTT,
+    polynomial_transform_ntt.py:33-34) or complex128 (FFT, polynomial_transform_fft.py:34-35)."""
+    return {'NTT': numpy.dtype('uint64'), 'FFT': numpy.dtype('complex128')}[transform_type]
+
+
+def transformed_length(transform_type, polynomial_degree: int):
+    """N values for the NTT, N / 2 for the folded FFT (polynomial_transform_ntt.py:45-46, _fft.py:46-47)."""
+    return {'NTT': polynomial_degree, 'FFT': polynomial_degree // 2}[transform_type]
 
 
 class IntPolynomialArray:
@@ -36,6 +50,47 @@ class TorusPolynomialArray:
     @classmethod
     def empty(cls, thr, polynomial_degree: int, shape):
         return cls(thr.array(tuple(shape) + (polynomial_degree,), Torus32))
+
+
+class TransformedPolynomialArray:
+    """Polynomials in the transformed domain in the REFERENCE's element order and scaling (natural frequency order; for
+    the NTT the Montgomery-prepared residues `tlwe_transform_samples` produces): ``coeffs [shape..., N or N / 2]``
+    (nufhe/polynomials.py:54-86).  The bootstrapping key the kernels read is a different object (library layout
+    behind a key handle, `tgsw.TransformedTGswSampleArray`); this container is the exchange and storage form."""
+
+    def __init__(self, transform_type, coeffs):
+        import torch
+        want = transformed_dtype(transform_type)
+        have = {torch.complex128: 'complex128', torch.int64: 'uint64'}.get(coeffs.dtype, str(coeffs.dtype).split('.')[-1])
+        if have != want.name:
+            raise TypeError("%s polynomials are %s, got %s" % (transform_type, want.name, coeffs.dtype))
+        self.transform_type = transform_type
+        self.coeffs = coeffs
+        self.shape = tuple(coeffs.shape[:-1])
+        self.polynomial_degree = coeffs.shape[-1]
+
+    @classmethod
+    def empty(cls, thr, transform_type, polynomial_degree: int, shape):
+        length = transformed_length(transform_type, polynomial_degree)
+        return cls(transform_type, thr.array(tuple(shape) + (length,), transformed_dtype(transform_type)))
+
+    def _host(self):
+        host = self.coeffs.detach().cpu().numpy()
+        return host.view(numpy.uint64) if host.dtype == numpy.int64 else host
+
+    def dump(self, file_obj):
+        pickle.dump(self.transform_type, file_obj)
+        pickle.dump(self._host(), file_obj)
+
+    @classmethod
+    def load(cls, file_obj, thr):
+        transform_type = pickle.load(file_obj)
+        coeffs = pickle.load(file_obj)
+        return cls(transform_type, thr.to_device(coeffs))
+
+    def __eq__(self, other):
+        return (self.__class__ == other.__class__ and self.transform_type == other.transform_type
+                and arrays_equal(self._host(), other._host()))
 
 
 def _shift(thr, result: TorusPolynomialArray, source: TorusPolynomialArray, powers, power_idx, minus_one, invert):

@@ -3,13 +3,17 @@ TLWE parameter / key records, the accumulator container with the per-step operat
 bootstrap driver, and the device side of TLWE key material (reference: nufhe/tlwe.py:48-207).
 """
 
+import pickle
+
 import numpy
 
 from . import _lib
 from .device import ptr
 from .lwe import LweParams, LweSampleArray
 from .numeric_functions import Torus32, ErrorFloat
-from .polynomials import IntPolynomialArray, TorusPolynomialArray, shift_tp_minus_one_power_from_array
+from .polynomials import (IntPolynomialArray, TorusPolynomialArray, TransformedPolynomialArray,
+                          shift_tp_minus_one_power_from_array)
+from .utils import arrays_equal
 from .random_numbers import rand_uniform_bool, rand_uniform_torus32, rand_gaussian_torus32
 
 
@@ -75,6 +79,63 @@ class TLweSampleArray:
         shape = tuple(shape)
         a = TorusPolynomialArray.empty(thr, params.polynomial_degree, shape + (params.mask_size + 1,))
         return cls(params, a, thr.zeros(shape, ErrorFloat))
+
+
+class TransformedTLweSampleArray:
+    """TLWE samples in the transformed domain, reference element order (nufhe/tlwe.py:115-153): ``a`` =
+    TransformedPolynomialArray ``[shape..., k + 1, N or N / 2]``."""
+
+    def __init__(self, params: TLweParams, a: TransformedPolynomialArray, current_variances):
+        self.a = a
+        self.current_variances = current_variances
+        self.shape = tuple(current_variances.shape)
+        self.params = params
+
+    @classmethod
+    def empty(cls, thr, params: TLweParams, shape):
+        shape = tuple(shape)
+        a = TransformedPolynomialArray.empty(thr, params.transform_type, params.polynomial_degree,
+                                             shape + (params.mask_size + 1,))
+        return cls(params, a, thr.zeros(shape, ErrorFloat))
+
+    def dump(self, file_obj):
+        pickle.dump(self.params, file_obj)
+        self.a.dump(file_obj)
+        pickle.dump(self.current_variances.detach().cpu().numpy(), file_obj)
+
+    @classmethod
+    def load(cls, file_obj, thr):
+        params = pickle.load(file_obj)
+        a = TransformedPolynomialArray.load(file_obj, thr)
+        current_variances = pickle.load(file_obj)
+        return cls(params, a, thr.to_device(current_variances))
+
+    def __eq__(self, other):
+        return (self.__class__ == other.__class__ and self.params == other.params and self.a == other.a
+                and arrays_equal(self.current_variances, other.current_variances))
+
+
+def tlwe_transform_samples(thr, result: TransformedTLweSampleArray, source: TLweSampleArray, perf_params=None):
+    """result = forward transform of every polynomial of ``source`` in the reference's element order: natural-order
+    negacyclic NTT followed by the Montgomery preparation x -> x 2^64 mod P, or the folded FFT-512; the variances are
+    copied (nufhe/tlwe.py:199-207, TLweTransformSamples tlwe_gpu.py:199-236, transform/arithmetic.py:172-195)."""
+    params = source.params
+    if params.polynomial_degree != 1024:
+        raise ValueError("the gfx950 kernels support N=1024")
+    if result.params != params or result.shape != source.shape:
+        raise ValueError("result does not match the source samples")
+    thr.check_stream()
+    src = source.a.coeffs.contiguous()
+    out = result.a.coeffs if result.a.coeffs.is_contiguous() else result.a.coeffs.new_empty(result.a.coeffs.shape)
+    batch = src.numel() // 1024
+    if params.transform_type == 'NTT':
+        _lib.call("nufhe_ntt_forward_i32", thr.handle, ptr(out), ptr(src), batch)
+        _lib.call("nufhe_ff_op", thr.handle, ptr(out), ptr(out), None, None, None, None, 6, 64, out.numel())
+    else:
+        _lib.call("nufhe_fft_forward_i32", thr.handle, ptr(out), ptr(src), batch)
+    if out is not result.a.coeffs:
+        result.a.coeffs.copy_(out)
+    result.current_variances.copy_(source.current_variances)
 
 
 def tlwe_noiseless_trivial(thr, result: TLweSampleArray, mu: TorusPolynomialArray):

@@ -14,7 +14,7 @@ FUNCTIONS = {
     'numeric_functions': ['phase_to_t32', 't32_to_phase', 'double_to_t32'],
     'polynomials': ['shift_tp_inverted_power', 'shift_tp_minus_one_power_from_array'],
     'tlwe': ['tlwe_noiseless_trivial', 'tlwe_extract_lwe_samples', 'tlwe_shift_polynomials', 'tlwe_add_to', 'tlwe_copy',
-             'tlwe_encrypt_zero'],
+             'tlwe_encrypt_zero', 'tlwe_transform_samples'],
     'tgsw': ['tgsw_transformed_external_mul', 'tgsw_encrypt_zero', 'tgsw_add_message', 'tgsw_encrypt_int',
              'tgsw_transform_samples'],
     'bootstrap': ['mux_rotate', 'blind_rotate', 'blind_rotate_and_extract', 'bootstrap'],
@@ -24,8 +24,9 @@ FUNCTIONS = {
               'gate_nor', 'gate_andny', 'gate_andyn', 'gate_orny', 'gate_oryn', 'gate_mux'],
 }
 CLASSES = {
-    'polynomials': {'TorusPolynomialArray': ['empty']},
-    'tlwe': {'TLweSampleArray': ['empty'], 'TLweParams': [], 'TLweKey': ['from_rng']},
+    'polynomials': {'TorusPolynomialArray': ['empty'], 'TransformedPolynomialArray': ['empty', 'dump', 'load']},
+    'tlwe': {'TLweSampleArray': ['empty'], 'TransformedTLweSampleArray': ['empty', 'dump', 'load'], 'TLweParams': [],
+             'TLweKey': ['from_rng']},
     'tgsw': {'TGswParams': [], 'TGswKey': ['from_rng'], 'TGswSampleArray': ['empty'], 'TransformedTGswSampleArray': ['empty']},
     'bootstrap': {'BootstrapKey': ['from_rng', 'dump', 'load']},
     'lwe': {'LweSampleArray': ['empty', 'copy', 'roll', 'dump', 'dumps', 'load', 'loads'],

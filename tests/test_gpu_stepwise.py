@@ -262,3 +262,47 @@ def test_key_generation_steps_vs_oracle(env, orc):
     acc = Acc(tlwe_params, TorusPolynomialArray(H.dev(thr, accum)), thr.zeros((2,), numpy.float32))
     tgsw_transformed_external_mul(thr, acc, transformed, 3)
     assert (H.host(acc.a.coeffs) == orc.tgsw_external_mul(accum, bk, 3)).all()
+
+
+def test_tlwe_transform_samples_reference_format(env, orc):
+    """`tlwe_transform_samples` into a TransformedTLweSampleArray: the reference's storage form of transformed samples
+    (natural order; NTT values Montgomery-prepared) -- equal to the oracle's, to the rows of the reference-format
+    bootstrapping key the library exports, and stable through dump / load (tlwe.py:115-153,199-207)."""
+    import io
+    import nufhe_amd
+    from oracle import oracle_fft
+    from nufhe_amd.polynomials import TorusPolynomialArray, TransformedPolynomialArray
+    from nufhe_amd.tlwe import TLweSampleArray, TransformedTLweSampleArray, tlwe_transform_samples
+    H = env['H']; thr = env['thr']
+    rs = numpy.random.RandomState(12)
+    shape = (2, 3)
+    a = rs.randint(-2**31, 2**31, size=shape + (2, N), dtype=numpy.int64).astype(numpy.int32)
+    cv = rs.rand(*shape).astype(numpy.float32)
+    for transform in ('NTT', 'FFT'):
+        params = nufhe_amd.NuFHEParameters(transform_type=transform).tgsw_params.tlwe_params
+        source = TLweSampleArray(params, TorusPolynomialArray(H.dev(thr, a)), H.dev(thr, cv))
+        result = TransformedTLweSampleArray.empty(thr, params, shape)
+        assert tuple(result.a.coeffs.shape) == shape + (2, N if transform == 'NTT' else N // 2)
+        tlwe_transform_samples(thr, result, source)
+        got = result.a._host()
+        if transform == 'NTT':
+            assert (got == orc.tlwe_transform_samples(a)).all()
+        else:
+            exp = oracle_fft.fft_forward(a)
+            assert numpy.abs(got - exp).max() <= 1e-12 * numpy.abs(exp).max()
+        assert (H.host(result.current_variances) == cv).all()
+        buf = io.BytesIO()
+        result.dump(buf)
+        buf.seek(0)
+        back = TransformedTLweSampleArray.load(buf, thr)
+        assert back == result and back.a.transform_type == transform
+        with pytest.raises(TypeError):
+            TransformedPolynomialArray(transform, H.dev(thr, a))
+    # the key the library holds, exported in the reference's format, is the same transform of the same TGSW samples
+    ck = env['ck']
+    tgsw = oracle_fft.tgsw_coeffs_from_reference_bk(ck.bk[:2])          # int32 [2, 2, 2, 2, N]
+    params = nufhe_amd.NuFHEParameters().tgsw_params.tlwe_params
+    source = TLweSampleArray(params, TorusPolynomialArray(H.dev(thr, tgsw)), thr.zeros((2, 2, 2), numpy.float32))
+    result = TransformedTLweSampleArray.empty(thr, params, (2, 2, 2))
+    tlwe_transform_samples(thr, result, source)
+    assert (result.a._host() == numpy.asarray(ck.bk[:2], numpy.uint64)).all()
