@@ -522,42 +522,51 @@ FF_FN void brt_step(u32 a, const u64 *row, const BrTeamLds &lds, const NttLane &
     team_sync();
 }
 
-// Whole bootstrap body of the team for one bit: tid = 64 w + lane in [0, 256).  The prologue and
-// the extraction are spread over all 256 threads; out_a has 1024 entries.
-template <class TeamSync>
-FF_FN void brt_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSource &s1, i32 c0, long bit,
-                         const u64 *bk, int n, i32 mu, const BrTeamLds &lds, const NttLane &L, int w,
-                         TeamSync &&team_sync)
+// Whole bootstrap body of a k = 1 team for one bit, shared by the 4-wave and the 8-wave team: mod-switch of the mask
+// into LDS, ACC = (0, X^(2N - barb) mu), the blind rotation through `step(a, row_index)` (all waves, same a != 0),
+// extraction.  tid in [0, 64 WAVES); prologue and extraction are spread over all threads; out_a has 1024 entries.
+template <int WAVES, class Step, class TeamSync>
+FF_FN void br_team_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSource &s1, i32 c0, long bit, int n,
+                             i32 mu, i32 *acc, uint16_t *bara, int tid, Step &&step, TeamSync &&team_sync)
 {
-    const int tid = 64 * w + L.lane;
-    for (int i = tid; i < n; i += 64 * BRT_WAVES) {
+    for (int i = tid; i < n; i += 64 * WAVES) {
         u32 v = 0;
         if (s0.p) v += (u32)s0.p * (u32)s0.a[bit * s0.a_stride + i];
         if (s1.p) v += (u32)s1.p * (u32)s1.a[bit * s1.a_stride + i];
-        lds.bara[i] = (uint16_t)br_modswitch(v);
+        bara[i] = (uint16_t)br_modswitch(v);
     }
     u32 vb = (u32)c0;
     if (s0.p) vb += (u32)s0.p * (u32)s0.b[bit * s0.b_stride];
     if (s1.p) vb += (u32)s1.p * (u32)s1.b[bit * s1.b_stride];
     const u32 barb = br_modswitch(vb);
     // ACC = (0, X^(2N - barb) * mu)  (bootstrap.py:176-182)
-    for (int j = tid; j < 1024; j += 64 * BRT_WAVES) {
+    for (int j = tid; j < 1024; j += 64 * WAVES) {
         const u32 t = ((u32)j + barb) & 2047u;
-        lds.acc[j] = 0;
-        lds.acc[1024 + j] = (t < 1024u) ? mu : (i32)(0u - (u32)mu);
+        acc[j] = 0;
+        acc[1024 + j] = (t < 1024u) ? mu : (i32)(0u - (u32)mu);
     }
     team_sync();
     for (int i = 0; i < n; i++) {
-        const u32 a = WAVE_UNIFORM((u32)lds.bara[i]);
+        const u32 a = WAVE_UNIFORM((u32)bara[i]);
         if (a == 0) continue;
-        brt_step(a, bk + (long)i * BK_ROW_ELEMS, lds, L, w, team_sync);
+        step(a, i);
     }
     // sample extraction (tlwe_cpu.py:55-58)
-    for (int j = tid; j < 1024; j += 64 * BRT_WAVES) {
-        const u32 v = (u32)lds.acc[j];
+    for (int j = tid; j < 1024; j += 64 * WAVES) {
+        const u32 v = (u32)acc[j];
         out_a[(1024 - j) & 1023] = (i32)(j == 0 ? v : 0u - v);
     }
-    if (tid == 0) *out_b = lds.acc[1024];
+    if (tid == 0) *out_b = acc[1024];
+}
+
+template <class TeamSync>
+FF_FN void brt_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSource &s1, i32 c0, long bit,
+                         const u64 *bk, int n, i32 mu, const BrTeamLds &lds, const NttLane &L, int w,
+                         TeamSync &&team_sync)
+{
+    br_team_bootstrap<BRT_WAVES>(out_a, out_b, s0, s1, c0, bit, n, mu, lds.acc, lds.bara, 64 * w + L.lane,
+                                 [&](u32 a, int i) { brt_step(a, bk + (long)i * BK_ROW_ELEMS, lds, L, w, team_sync); },
+                                 team_sync);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -680,40 +689,14 @@ FF_FN void brh_step(u32 a, const u64 *row, const BrHalfLds &lds, int lane, int w
     BRH_MARK(7);
 }
 
-// Whole bootstrap body of the half-ring team for one bit: tid = 64 w + lane in [0, 512); out_a has 1024 entries.
+// Whole bootstrap body of the half-ring team for one bit: tid = 64 w + lane in [0, 512)
 template <class TeamSync>
 FF_FN void brh_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSource &s1, i32 c0, long bit,
                          const u64 *bkh, int n, i32 mu, const BrHalfLds &lds, int lane, int w, TeamSync &&team_sync)
 {
-    const int tid = 64 * w + lane;
-    for (int i = tid; i < n; i += 64 * BRH_WAVES) {
-        u32 v = 0;
-        if (s0.p) v += (u32)s0.p * (u32)s0.a[bit * s0.a_stride + i];
-        if (s1.p) v += (u32)s1.p * (u32)s1.a[bit * s1.a_stride + i];
-        lds.bara[i] = (uint16_t)br_modswitch(v);
-    }
-    u32 vb = (u32)c0;
-    if (s0.p) vb += (u32)s0.p * (u32)s0.b[bit * s0.b_stride];
-    if (s1.p) vb += (u32)s1.p * (u32)s1.b[bit * s1.b_stride];
-    const u32 barb = br_modswitch(vb);
-    // ACC = (0, X^(2N - barb) * mu)  (bootstrap.py:176-182)
-    for (int j = tid; j < 1024; j += 64 * BRH_WAVES) {
-        const u32 t = ((u32)j + barb) & 2047u;
-        lds.acc[j] = 0;
-        lds.acc[1024 + j] = (t < 1024u) ? mu : (i32)(0u - (u32)mu);
-    }
-    team_sync();
-    for (int i = 0; i < n; i++) {
-        const u32 a = WAVE_UNIFORM((u32)lds.bara[i]);
-        if (a == 0) continue;
-        brh_step(a, bkh + (long)i * BK_ROW_ELEMS, lds, lane, w, team_sync);
-    }
-    // sample extraction (tlwe_cpu.py:55-58)
-    for (int j = tid; j < 1024; j += 64 * BRH_WAVES) {
-        const u32 v = (u32)lds.acc[j];
-        out_a[(1024 - j) & 1023] = (i32)(j == 0 ? v : 0u - v);
-    }
-    if (tid == 0) *out_b = lds.acc[1024];
+    br_team_bootstrap<BRH_WAVES>(out_a, out_b, s0, s1, c0, bit, n, mu, lds.acc, lds.bara, 64 * w + lane,
+                                 [&](u32 a, int i) { brh_step(a, bkh + (long)i * BK_ROW_ELEMS, lds, lane, w, team_sync); },
+                                 team_sync);
 }
 
 // ------------------------------------------------------------------------------------------
