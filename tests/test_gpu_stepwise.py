@@ -306,3 +306,24 @@ def test_tlwe_transform_samples_reference_format(env, orc):
     result = TransformedTLweSampleArray.empty(thr, params, (2, 2, 2))
     tlwe_transform_samples(thr, result, source)
     assert (result.a._host() == numpy.asarray(ck.bk[:2], numpy.uint64)).all()
+
+
+def test_step_by_step_driver_with_fft_and_mask_size_2(env):
+    """The step-by-step driver is transform- and k-agnostic (every step goes through the per-kernel entry points, which
+    take both from the key): NAND and MUX on keys generated here, against the fused kernels -- exact for the NTT with
+    k = 2, within the FFT tolerance (2^4 LSB, tests/test_gpu_fft.py) for the FFT -- and correct after decryption."""
+    import nufhe_amd
+    H = env['H']; thr = env['thr']
+    ctx = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(77), thread=thr)
+    bits = [numpy.array([True, False, True]), numpy.array([True, True, False]), numpy.array([False, True, True])]
+    for kwds, tol in ((dict(transform_type='FFT'), 16), (dict(tlwe_mask_size=2), 0)):
+        sk, ck = ctx.make_key_pair(**kwds)
+        cts = [ctx.encrypt(sk, b) for b in bits]
+        fused = ctx.make_virtual_machine(ck)
+        steps = ctx.make_virtual_machine(ck, perf_params=nufhe_amd.PerformanceParameters(ck.params, single_kernel_bootstrap=False))
+        for got, ref, truth in ((steps.gate_nand(cts[0], cts[1]), fused.gate_nand(cts[0], cts[1]), ~(bits[0] & bits[1])),
+                                (steps.gate_mux(*cts), fused.gate_mux(*cts), numpy.where(bits[0], bits[1], bits[2]))):
+            assert (ctx.decrypt(sk, got) == truth).all(), kwds
+            for g, r in zip(H.ct_arrays(got)[:2], H.ct_arrays(ref)[:2]):
+                diff = (g.astype(numpy.int64) - r.astype(numpy.int64) + 2**31) % 2**32 - 2**31
+                assert numpy.abs(diff).max() <= tol, (kwds, int(numpy.abs(diff).max()))
