@@ -91,8 +91,9 @@ def issue_roofline(transform, bits, rotations, n_iter, kernel_ms, live_clock_ghz
                       "frac_wave_cycles_issuing": d.get("frac_SQ_ACTIVE_INST_ANY"),
                       "frac_wave_cycles_waiting_for_issue": d.get("frac_SQ_WAIT_INST_ANY"),
                       "frac_wave_cycles_at_waitcnt": d.get("frac_SQ_WAIT_ANY"),
-                      "note": "counter passes of an earlier build (profiles/README.md); the instruction count is re-derived "
-                              "from the current ISA above"}
+                      "note": "rocprofv3 --pmc passes of tools/profile.sh on a separate run of this workload "
+                              "(profiles/pmc_*.json, see profiles/README.md), not of this process; the instruction count is "
+                              "re-derived from the current ISA above"}
     if live_clock_ghz:
         out["clock_ghz_in_kernel"] = live_clock_ghz     # s_memtime / s_memrealtime of one wave inside the timed launches
         clock = live_clock_ghz
