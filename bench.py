@@ -66,6 +66,13 @@ ALG_ADDSUB_PER_BIT_ITER = 6 * 10 * 512 * 2         # 61,440
 ALG_MODMUL_PER_BIT_ITER = 6 * 1024 + 8 * 1024      # 14,336
 
 
+# `roofline.frac` is FROZEN at the round-3 definition ("vs_measured_class_rates": issued instructions x the best rate
+# each issue class reaches on this chip at any occupancy, over the SIMD cycles of the launch) so that
+# rounds compare; the streaming-model fraction (BASELINE's HBM axis) and the nominal-2-cycle fraction ride beside it
+# unchanged under `streaming_model.frac` and `fractions.vs_nominal_2_cycle_issue`.
+FRAC_DEFINITION = "r03"
+
+
 def issue_roofline(transform, bits, rotations, n_iter, kernel_ms, live_clock_ghz=None):
     """What bounds the bootstrap kernel: VALU issue.  Everything comes from TRACKED files:
     profiles/isa_mix.json (tools/isa_mix.py: instructions per blind-rotate iteration by issue class, counted in the
@@ -144,7 +151,7 @@ def issue_roofline(transform, bits, rotations, n_iter, kernel_ms, live_clock_ghz
         out.update({"bound": "valu-issue", "achieved": cyc_machine * iters / (kernel_ms * 1e-3) / 1e9,
                     "peak": SIMDS * clock, "unit": "G SIMD issue cycles/s",
                     "frac": fracs["vs_measured_class_rates"]["frac"],
-                    "frac_is": "vs_measured_class_rates"})
+                    "frac_is": "vs_measured_class_rates", "frac_definition": FRAC_DEFINITION})
     else:
         flops = iters * 64.0 * k.get("f64_flops_per_lane", 0)
         fracs["fp64_fma_peak"] = {
@@ -155,6 +162,7 @@ def issue_roofline(transform, bits, rotations, n_iter, kernel_ms, live_clock_ghz
         out.update({"bound": "valu-issue (fp64)", "achieved": cyc_machine * iters / (kernel_ms * 1e-3) / 1e9,
                     "peak": SIMDS * clock, "unit": "G SIMD issue cycles/s",
                     "frac": fracs["vs_measured_class_rates"]["frac"], "frac_is": "vs_measured_class_rates",
+                    "frac_definition": FRAC_DEFINITION,
                     "fp64_tflops": flops / (kernel_ms * 1e-3) / 1e12})
     out["fractions"] = fracs
     return out
@@ -212,7 +220,21 @@ def cpu_baseline_and_parity(gate, sample_bits, cs_host, gpu_out):
     base = dict(value=n / dt, unit="gates/s", cores=orc.num_threads(), kind="port",
                 sample="first %d bits of the benchmarked %s batch, full n=500 bootstrap + keyswitch, %.1f s" % (
                     n, gate.upper(), dt),
-                ms_per_bit=1000.0 * dt / n)
+                ms_per_bit=1000.0 * dt / n,
+                where="this host, in this run (the C restatement of the reference's *_cpu.py composition, OpenMP over bits)")
+    # north_star's other baseline: the reference's OWN Python CPU functions.  They cannot run on the GPU box (the
+    # reference is not shipped there), so the figure is the one measured in the build container, carried with its
+    # provenance (tools/time_reference_cpu.py -> profiles/reference_python_cpu_timing.json); it was NOT timed in this run
+    ref = _profile_json("reference_python_cpu_timing.json")
+    if ref is not None:
+        mult = 2 if gate == "mux" else 1
+        base["reference_python"] = {
+            "ms_per_bit": ref["extrapolated_ms_per_bit"] * mult,
+            "value": 1000.0 / (ref["extrapolated_ms_per_bit"] * mult), "unit": "gates/s",
+            "cores": ref["cores_used"], "kind": "reference", "measured_in_this_run": False,
+            "where": "build container (%s), 1 core, K<=5 blind-rotate iterations at B=32 x (500/K); %s" % (
+                ref["cpu"], ref["label"]),
+            "source": "profiles/reference_python_cpu_timing.json (tools/time_reference_cpu.py)"}
     return base, parity
 
 
@@ -221,6 +243,9 @@ def shard_parity(gate, transform, sample_bits, cs_host, out_host, dist, dev, wor
     output of the last timed step) with the CPU oracle and the counts are all-reduced, so that a multi-GPU line
     carries a parity verdict over all ranks (the N = 1 line compares a larger sample, cpu_baseline_and_parity)."""
     from oracle import oracle as orc
+    # the ranks of this node share its host cores (torch.distributed.run exports OMP_NUM_THREADS=1 by default)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    orc.set_num_threads(max(1, (os.cpu_count() or 1) // max(1, local_world)))
     lwe_key, tlwe_key, ck = orc.make_key_pair(orc.DeterministicRNG(123))
     n = sample_bits
     cs = [tuple(x[:n] for x in c) for c in cs_host]
@@ -258,7 +283,20 @@ def main():
                     help="skip the secondary measurements (other gate / FFT transform) reported under 'other_configs'")
     args = ap.parse_args()
 
+    if "RANK" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` is a complete command: it starts its own N ranks on this node (one per GPU,
+        # torch.distributed.run, free port on 127.0.0.1) the way the reference's example starts its own per-GPU
+        # workers (examples/multi_gpu.py:86-114); rank 0 of the children prints the JSON line.  N = 1 never gets here.
+        from nufhe_amd import multi_gpu as _mg
+        try:
+            sys.exit(_mg.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus,
+                                      backend=os.environ.get("NUFHE_BENCH_BACKEND", "nccl")))
+        except RuntimeError as e:
+            sys.exit("bench.py: " + str(e))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "RANK" in os.environ and world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -275,6 +313,9 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
+            if torch.cuda.device_count() <= local_rank:
+                sys.exit("bench.py: rank %d (local %d) has no GPU of its own: %d visible; RCCL needs one per rank" % (
+                    rank, local_rank, torch.cuda.device_count()))
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
@@ -354,8 +395,9 @@ def main():
     last = 0
     for _ in range(args.steps):
         last = step()
-        if rank == 0:
-            # HIP-event timing of the kernels of this step (events recorded on the launch stream)
+        if True:
+            # HIP-event timing of the kernels of this step (events recorded on the launch stream), on EVERY rank so
+            # that all ranks are timed under the same conditions (the read-back synchronises on the step's events)
             a = ctypes.c_float(); b = ctypes.c_float()
             _lib.check(lib.nufhe_profile_last(thr.handle, ctypes.byref(a), ctypes.byref(b)))
             br_ms.append(a.value); ks_ms.append(b.value)
@@ -480,7 +522,7 @@ def main():
         if world > 1 and not args.no_cpu_baseline:
             def host_(ct):
                 return tuple(x.detach().cpu().numpy() for x in (ct.a, ct.b, ct.current_variances))
-            multi_parity = shard_parity(args.gate, args.transform, min(B, 32), [host_(c) for c in cs], host_(out),
+            multi_parity = shard_parity(args.gate, args.transform, min(B, args.cpu_sample_bits or 256), [host_(c) for c in cs], host_(out),
                                         dist, dev, world)
 
     if rank == 0:

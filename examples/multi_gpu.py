@@ -8,8 +8,13 @@ TO RANK 0 -- the reference's main thread collecting the parts (:104-107) -- as o
 per gate (a | b | variances of a slice share one buffer, nufhe_amd.multi_gpu.PackedCiphertext).
 Only rank 0 holds the gathered ciphertext and decrypts it; the other ranks get None back.
 
+    python examples/multi_gpu.py --gpus 8 --bits 32768          # starts its own 8 ranks (one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-        --master-port 29511 examples/multi_gpu.py --bits 32768
+        --master-port 29511 examples/multi_gpu.py --gpus 8 --bits 32768       # the same, launched from outside
+
+The cloud key reaches the other ranks as ONE device broadcast of its 98.6 MB image
+(multi_gpu.broadcast_cloud_key: RCCL over xGMI); ``--via-host`` takes the reference's route instead
+(the serialized key pickled through the host, every rank re-uploading it).
 
 ``--backend gloo`` is the test route (several ranks may share one GPU; slices are staged through
 the host); the default ``nccl`` is RCCL over xGMI.
@@ -32,8 +37,20 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bits", type=int, default=64)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=os.environ.get("NUFHE_BENCH_BACKEND", "nccl"))
+    ap.add_argument("--gpus", type=int, default=None, help="number of ranks (= GPUs) to run on; started here if "
+                    "this process was not launched by torch.distributed.run")
+    ap.add_argument("--via-host", action="store_true", help="ship the cloud key as the reference does (pickled "
+                    "through the host) instead of one device broadcast")
     args = ap.parse_args()
+    if "RANK" not in os.environ and args.gpus is not None and args.gpus > 1:
+        os.environ["NUFHE_BENCH_BACKEND"] = args.backend
+        try:
+            sys.exit(multi_gpu.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, backend=args.backend))
+        except RuntimeError as e:
+            sys.exit("multi_gpu.py: " + str(e))
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus is not None and "RANK" in os.environ and world != args.gpus:
+        sys.exit("multi_gpu.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = "RANK" in os.environ          # launched by torch.distributed.run, with any world size
     if args.backend == "gloo":
@@ -56,13 +73,17 @@ def main():
         rs = numpy.random.RandomState(1)
         bits1 = rs.randint(0, 2, size=args.bits).astype(bool)
         bits2 = rs.randint(0, 2, size=args.bits).astype(bool)
-        payload = [cloud_key.dumps(), ctx.encrypt(secret_key, bits1).dumps(), ctx.encrypt(secret_key, bits2).dumps()]
+        payload = [cloud_key.dumps() if args.via_host else None,
+                   ctx.encrypt(secret_key, bits1).dumps(), ctx.encrypt(secret_key, bits2).dumps()]
     else:
         payload = [None, None, None]
     if distributed and world > 1:
-        dist.broadcast_object_list(payload, src=0)
-    if rank != 0:
-        cloud_key = ctx.load_cloud_key(payload[0])
+        dist.broadcast_object_list(payload, src=0)           # the ciphertexts (and, with --via-host, the key) as bytes
+    if args.via_host:
+        if rank != 0:
+            cloud_key = ctx.load_cloud_key(payload[0])
+    elif distributed:
+        cloud_key = multi_gpu.broadcast_cloud_key(thr, cloud_key, src=0)     # one device collective
     ct1 = ctx.load_ciphertext(payload[1]); ct2 = ctx.load_ciphertext(payload[2])
 
     vm = ctx.make_virtual_machine(cloud_key)
@@ -80,8 +101,9 @@ def main():
     if rank == 0:
         assert result.shape == (args.bits,)
         assert (ctx.decrypt(secret_key, result) == ~(bits1 & bits2)).all()
-        print("multi-GPU gate_nand OK: %d bits over %d GPU(s)%s" % (
-            args.bits, world, ", gathered to rank 0 over %s" % args.backend if distributed else ""))
+        print("multi-GPU gate_nand OK: %d bits over %d GPU(s)%s%s" % (
+            args.bits, world, ", gathered to rank 0 over %s" % args.backend if distributed else "",
+            (", key via host pickle" if args.via_host else ", key as one device broadcast") if distributed else ""))
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

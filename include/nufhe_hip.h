@@ -41,8 +41,14 @@ extern "C" {
 typedef struct nufhe_ctx nufhe_ctx;            /* one GPU + one stream; replaces the Reikna Thread */
 typedef struct nufhe_cloudkey nufhe_cloudkey;  /* device copies of BootstrapKey + LweKeyswitchKey */
 
+/* Bumped whenever a struct passed by value or an entry point's signature changes (3: nufhe_lwe gained `size`;
+ * 4: output-stride checks, key images).  A binding compares nufhe_abi_version() with the macro of the header it
+ * was written against before the first real call (nufhe_amd/_lib.py does). */
+#define NUFHE_ABI_VERSION 4
+
 const char *nufhe_last_error(void);
 const char *nufhe_version(void);
+int nufhe_abi_version(void);
 
 /* ---- device / context (replaces reikna.cluda Thread creation, api_high_level.py:130-181) ---- */
 int nufhe_device_count(int *count);
@@ -84,6 +90,15 @@ int nufhe_bk_from_coeffs(nufhe_cloudkey *key, const int32_t *d_tgsw);
  * (lwe_cpu.py:30-33); it is checked and NUFHE_EINVAL is returned otherwise. */
 int nufhe_ks_upload(nufhe_cloudkey *key, const int32_t *h_ks_a, const int32_t *h_ks_b,
                     const float *h_ks_cv);
+/* Device image of a complete cloud key (bootstrapping key in the library's layout + keyswitch key) in ONE caller-owned
+ * device buffer of nufhe_cloudkey_image_bytes() bytes: export on the rank that made / loaded the key, move the buffer
+ * with a device collective (RCCL broadcast over xGMI; SURVEY 8e "or ncclBroadcast from rank 0" -- the reference ships
+ * pickles through the host, examples/multi_gpu.py:86-107), import into a key created with the same (lwe_size, transform,
+ * mask_size) on the receiving rank.  export enqueues copies on the stream; import synchronises (it rebuilds the derived
+ * layouts).  The image is only meaningful between libraries of the same NUFHE_ABI_VERSION. */
+int nufhe_cloudkey_image_bytes(nufhe_cloudkey *key, size_t *bytes);
+int nufhe_cloudkey_export_image(nufhe_cloudkey *key, void *d_image);
+int nufhe_cloudkey_import_image(nufhe_cloudkey *key, const void *d_image);
 /* MakeLweKeyswitchKey on the device (lwe.py:265-295, lwe_gpu.py:63-124, lwe_gpu.mako:18-56;
  * lwe_cpu.py:27-59): builds the key in the library's own layout from DEVICE arrays
  *   d_noises_a int32 [k*1024][8][3][n]  uniform masks of the digits 1..3 (become the key's `a` as they are)
@@ -105,7 +120,8 @@ int nufhe_tgsw_add_message(nufhe_ctx *ctx, int32_t *d_tgsw, const int32_t *d_mes
  * array shapes are part of the computation's signature and a mismatch is refused before anything is launched):
  * `size` is the LWE dimension of THIS operand and every entry point checks it against what its key / its other
  * operands require (n for gate operands and results, k * 1024 for extracted samples) and returns NUFHE_EINVAL
- * on a mismatch, a NULL a / b, a negative stride or 0 < a_stride < size -- never an out-of-bounds access. */
+ * on a mismatch, a NULL a / b, a negative stride or 0 < a_stride < size -- never an out-of-bounds access.  A RESULT of more than one bit must
+ * not have a zero (broadcast) stride: every bit's work-group would write the same row. */
 typedef struct {
     int32_t *a;
     int32_t *b;

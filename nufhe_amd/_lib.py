@@ -48,6 +48,9 @@ PROTOTYPES = {
     "nufhe_h2d": [_vp, _vp, _vp, ctypes.c_size_t],
     "nufhe_d2h": [_vp, _vp, _vp, ctypes.c_size_t],
     "nufhe_cloudkey_create": [_vp, _int, _int, _int, _pp],
+    "nufhe_cloudkey_image_bytes": [_vp, ctypes.POINTER(ctypes.c_size_t)],
+    "nufhe_cloudkey_export_image": [_vp, _vp],
+    "nufhe_cloudkey_import_image": [_vp, _vp],
     "nufhe_ctx_set_team_max_bits": [_vp, _long],
     "nufhe_ctx_set_pair_max_bits": [_vp, _long],
     "nufhe_ctx_set_team8": [_vp, _int],
@@ -91,6 +94,9 @@ PROTOTYPES = {
                             ctypes.POINTER(_int), _int, ctypes.POINTER(_int)],
 }
 
+# NUFHE_ABI_VERSION of the include/nufhe_hip.h these prototypes were written against
+ABI_VERSION = 4
+
 _lib = None
 
 
@@ -103,6 +109,15 @@ def lib():
                 "libnufhe_hip.so not found at %s: build it with `make -C nufhe_amd/csrc` "
                 "(there is no CPU fallback)" % LIB_PATH)
         handle = ctypes.CDLL(LIB_PATH)
+        try:
+            handle.nufhe_abi_version.restype = ctypes.c_int
+            handle.nufhe_abi_version.argtypes = []
+            abi = handle.nufhe_abi_version()
+        except AttributeError:
+            abi = None
+        if abi != ABI_VERSION:
+            raise NufheError("%s has ABI version %s, this binding needs %d (structs are passed by value: rebuild with "
+                             "`make -C nufhe_amd/csrc`)" % (LIB_PATH, abi, ABI_VERSION))
         for name, argtypes in PROTOTYPES.items():
             fn = getattr(handle, name)
             fn.argtypes = argtypes

@@ -146,6 +146,22 @@ class NuFHECloudKey:
             thr, rng, params.ks_decomp_length, params.ks_log2_base, secret_key.lwe_key, tgsw_key, native=native)
         return cls(params, bk, ks, native)
 
+    def device_image(self):
+        """(params, uint8 device tensor): the key as the kernels hold it, for device-to-device replication
+        (multi_gpu.broadcast_cloud_key); the serialized form for everything else is dump / dumps."""
+        return self.params, self._native.export_image()
+
+    @classmethod
+    def from_device_image(cls, thr, params: NuFHEParameters, image):
+        """Rebuilds a cloud key on ``thr`` from a device image made by ``device_image`` (same library build)."""
+        native = NativeCloudKey(thr, params.in_out_params.size, params._transform_type, params._tlwe_mask_size)
+        native.import_image(image)
+        bk = BootstrapKey(params.in_out_params, params.tgsw_params, native)
+        ks = LweKeyswitchKey(native=native, params=params.in_out_params,
+                             shape=(params._tlwe_mask_size * params.tgsw_params.tlwe_params.polynomial_degree,
+                                    params.ks_decomp_length, 2**params.ks_log2_base))
+        return cls(params, bk, ks, native)
+
     def dump(self, file_obj):
         pickle.dump(self.params, file_obj)
         self.bootstrap_key.dump(file_obj)

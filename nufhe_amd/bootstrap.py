@@ -51,6 +51,26 @@ class NativeCloudKey:
         _lib.register_stream_guard(handle, lambda: (ref() is not None) and ref().check_stream())
         thr._cloud_keys.add(self)
 
+    def image_bytes(self):
+        size = ctypes.c_size_t(0)
+        _lib.call("nufhe_cloudkey_image_bytes", self.handle, ctypes.byref(size))
+        return int(size.value)
+
+    def export_image(self, out=None):
+        """The whole key (bootstrapping key in the kernels' layout + keyswitch key) as ONE uint8 device tensor, the
+        unit a device collective moves (multi_gpu.broadcast_cloud_key)."""
+        import torch
+        if out is None:
+            out = torch.empty(self.image_bytes(), dtype=torch.uint8, device=self.thr.device)
+        _lib.call("nufhe_cloudkey_export_image", self.handle, ptr(out))
+        return out
+
+    def import_image(self, image):
+        if image.numel() * image.element_size() != self.image_bytes() or not image.is_contiguous():
+            raise ValueError("key image of %d bytes, this key needs %d contiguous bytes" % (
+                image.numel() * image.element_size(), self.image_bytes()))
+        _lib.call("nufhe_cloudkey_import_image", self.handle, ptr(image))
+
     def destroy(self):
         if self.handle:
             _lib.unregister_stream_guard(self.handle)
@@ -191,12 +211,19 @@ def _bootstrap_stepwise(thr, result, bk, ks, mu, x, perf_params, no_keyswitch):
     """nufhe/bootstrap.py:206-229 with ``single_kernel_bootstrap=False``"""
     N = bk.accum_params.polynomial_degree
     shape = tuple(result.shape)
+    xa, xb = x.a, x.b
     if tuple(x.shape) != shape:
-        raise ValueError("argument of shape %s, result of shape %s" % (tuple(x.shape), shape))
+        # the fused call broadcasts its argument to the result's shape (_Flat); so does this driver
+        try:
+            xb = xb.expand(shape).contiguous()
+            xa = xa.expand(shape + (xa.shape[-1],)).contiguous()
+        except RuntimeError:
+            raise ValueError("argument of shape %s cannot be broadcast to the result's shape %s" % (
+                tuple(x.shape), shape))
     barb = thr.array(shape, Torus32)
     bara = thr.array(shape + (bk.in_out_params.size,), Torus32)
-    t32_to_phase(thr, barb, x.b, 2 * N)
-    t32_to_phase(thr, bara, x.a, 2 * N)
+    t32_to_phase(thr, barb, xb, 2 * N)
+    t32_to_phase(thr, bara, xa, 2 * N)
     testvect = TorusPolynomialArray.empty(thr, N, shape)
     testvect.coeffs.fill_(int(numpy.int32(mu)))
     blind_rotate_and_extract(thr, result, testvect, bk, ks, barb, bara, perf_params, no_keyswitch=no_keyswitch)

@@ -105,8 +105,13 @@ inline BrSource source(const nufhe_lwe &x, i32 p) { return BrSource{x.a, x.b, x.
 
 // The checks the reference gets from its typed computation signatures (lwe_gpu.py:151-159, blind_rotate.py:226-234):
 // an operand whose LWE dimension is not the one the key / the operation needs is refused, not read out of bounds.
-static int check_lwe(const nufhe_lwe &x, int expect_size, const char *what, bool need_cv, long nbits)
+static int check_lwe(const nufhe_lwe &x, int expect_size, const char *what, bool need_cv, long nbits,
+                     bool is_output = false)
 {
+    // a RESULT of more than one bit must give every bit its own row: a broadcast (zero) stride, or rows of `b` that
+    // alias, would have all work-groups write the same words
+    if (is_output && nbits > 1 && (x.a_stride == 0 || x.b_stride == 0))
+        return fail(NUFHE_EINVAL, "%s: zero (broadcast) stride on an output of %ld bits", what, nbits);
     // (an empty batch has no storage: its pointers may be NULL)
     if (nbits > 0 && (x.a == nullptr || x.b == nullptr)) return fail(NUFHE_EINVAL, "%s: NULL a / b pointer", what);
     if (nbits > 0 && need_cv && x.cv == nullptr) return fail(NUFHE_EINVAL, "%s: NULL variance pointer", what);
@@ -192,7 +197,8 @@ int run_keyswitch(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result, 
 extern "C" {
 
 const char *nufhe_last_error(void) { return g_last_error.c_str(); }
-const char *nufhe_version(void) { return "nufhe_hip 0.1 (gfx950)"; }
+const char *nufhe_version(void) { return "nufhe_hip 0.4 (gfx950)"; }
+int nufhe_abi_version(void) { return NUFHE_ABI_VERSION; }
 
 int nufhe_device_count(int *count)
 {
@@ -517,6 +523,77 @@ int nufhe_ks_upload(nufhe_cloudkey *key, const int32_t *h_ks_a, const int32_t *h
     return NUFHE_OK;
 }
 
+// ---- device image of a whole cloud key (replication over RCCL: examples/multi_gpu.py) ----
+// bootstrapping key in the wave layout | ks_a3 | ks_b | ks_cv, each part starting at a multiple of 256 bytes
+static size_t image_part(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+
+static void image_layout(const nufhe_cloudkey *key, size_t off[5])
+{
+    const size_t rows = (size_t)key->ext_size() * NUFHE_KS_T;
+    off[0] = 0;
+    off[1] = off[0] + image_part((size_t)key->bk_polys() * BK_POLY_ELEMS * sizeof(u64));
+    off[2] = off[1] + image_part(rows * 3 * key->n * sizeof(int32_t));
+    off[3] = off[2] + image_part(rows * 4 * sizeof(int32_t));
+    off[4] = off[3] + image_part(rows * 4 * sizeof(float));
+}
+
+int nufhe_cloudkey_image_bytes(nufhe_cloudkey *key, size_t *bytes)
+{
+    if (!key || !bytes) return fail(NUFHE_EINVAL, "null argument");
+    size_t off[5];
+    image_layout(key, off);
+    *bytes = off[4];
+    return NUFHE_OK;
+}
+
+int nufhe_cloudkey_export_image(nufhe_cloudkey *key, void *d_image)
+{
+    if (!key || !d_image) return fail(NUFHE_EINVAL, "null argument");
+    nufhe_ctx *ctx = key->ctx;
+    int rc = check_key(ctx, key, true, true);
+    if (rc) return rc;
+    size_t off[5];
+    image_layout(key, off);
+    char *dst = (char *)d_image;
+    const void *src[4] = {key->d_bk, key->d_ks_a3, key->d_ks_b, key->d_ks_cv};
+    const size_t rows = (size_t)key->ext_size() * NUFHE_KS_T;
+    const size_t len[4] = {(size_t)key->bk_polys() * BK_POLY_ELEMS * sizeof(u64), rows * 3 * key->n * sizeof(int32_t),
+                           rows * 4 * sizeof(int32_t), rows * 4 * sizeof(float)};
+    for (int i = 0; i < 4; i++)
+        HIP_TRY(hipMemcpyAsync(dst + off[i], src[i], len[i], hipMemcpyDeviceToDevice, ctx->stream));
+    return NUFHE_OK;
+}
+
+int nufhe_cloudkey_import_image(nufhe_cloudkey *key, const void *d_image)
+{
+    if (!key || !d_image) return fail(NUFHE_EINVAL, "null argument");
+    nufhe_ctx *ctx = key->ctx;
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if ((rc = alloc_bk(key)) || (rc = alloc_ks(key))) return rc;
+    size_t off[5];
+    image_layout(key, off);
+    const char *src = (const char *)d_image;
+    void *dst[4] = {key->d_bk, key->d_ks_a3, key->d_ks_b, key->d_ks_cv};
+    const size_t rows = (size_t)key->ext_size() * NUFHE_KS_T;
+    const size_t len[4] = {(size_t)key->bk_polys() * BK_POLY_ELEMS * sizeof(u64), rows * 3 * key->n * sizeof(int32_t),
+                           rows * 4 * sizeof(int32_t), rows * 4 * sizeof(float)};
+    for (int i = 0; i < 4; i++)
+        HIP_TRY(hipMemcpyAsync(dst[i], src + off[i], len[i], hipMemcpyDeviceToDevice, ctx->stream));
+    key->bk_half_valid = false;
+    if ((rc = build_ks_planes(key))) return rc;
+    // the variance table of a uniform-variance key (what nufhe_ks_upload derives from the host arrays)
+    std::vector<float> cv(rows * 4);
+    HIP_TRY(hipMemcpyAsync(cv.data(), key->d_ks_cv, len[3], hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    bool uniform = true;
+    const float v0 = cv[1];
+    for (size_t r = 0; r < rows && uniform; r++)
+        for (int h = 1; h < 4; h++)
+            if (cv[r * 4 + h] != v0) { uniform = false; break; }
+    return set_cv_table(key, uniform && v0 >= 0.0f, v0);
+}
+
 int nufhe_ks_make(nufhe_cloudkey *key, const int32_t *d_noises_a, const int32_t *d_noises_b, const int32_t *d_in_key,
                   const int32_t *d_out_key, float variance)
 {
@@ -574,7 +651,7 @@ int nufhe_lwe_linear(nufhe_ctx *ctx, nufhe_lwe res, nufhe_lwe src, int32_t p, in
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (nbits < 0 || size < 1) return fail(NUFHE_EINVAL, "bad sizes");
-    if ((rc = check_lwe(res, size, "lwe_linear result", true, nbits)) || (rc = check_lwe(src, size, "lwe_linear source", true, nbits)))
+    if ((rc = check_lwe(res, size, "lwe_linear result", true, nbits, true)) || (rc = check_lwe(src, size, "lwe_linear source", true, nbits)))
         return rc;
     HIP_TRY(launch_lwe_linear(view(res), view(src), p, add_result, nbits, size, ctx->stream));
     return NUFHE_OK;
@@ -585,7 +662,7 @@ int nufhe_lwe_trivial_const(nufhe_ctx *ctx, nufhe_lwe res, int32_t mu, long nbit
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (nbits < 0 || size < 1) return fail(NUFHE_EINVAL, "bad sizes");
-    if ((rc = check_lwe(res, size, "lwe_trivial_const result", true, nbits))) return rc;
+    if ((rc = check_lwe(res, size, "lwe_trivial_const result", true, nbits, true))) return rc;
     HIP_TRY(launch_lwe_trivial_const(view(res), mu, nbits, size, ctx->stream));
     return NUFHE_OK;
 }
@@ -610,13 +687,17 @@ static int run_gate(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result
         // permutation of the same field elements), converted once per key on first use
         const long team_limit = ctx->team_max_bits < 0 ? (long)ctx->num_cus : ctx->team_max_bits;
         if (ctx->team8 && key->transform == NUFHE_TRANSFORM_NTT && key->mask_size == 1 && total <= team_limit) {
-            if (!key->d_bk_half)
-                HIP_TRY(hipMalloc((void **)&key->d_bk_half, (size_t)key->bk_polys() * BK_POLY_ELEMS * sizeof(u64)));
-            if (!key->bk_half_valid) {
-                HIP_TRY(launch_bk_to_half(key->d_bk_half, (const u64 *)key->d_bk, key->bk_polys(), ctx->stream));
-                key->bk_half_valid = true;
+            // (one-time, per key: 33 MB and one conversion launch.)  A failure here is not an error of the gate: the
+            // launch falls back to the 4-wave team kernel, which reads the ordinary layout (P.bk_half stays NULL).
+            if (!key->d_bk_half &&
+                hipMalloc((void **)&key->d_bk_half, (size_t)key->bk_polys() * BK_POLY_ELEMS * sizeof(u64)) != hipSuccess) {
+                key->d_bk_half = nullptr;
+                (void)hipGetLastError();
             }
-            P.bk_half = key->d_bk_half;
+            if (key->d_bk_half && !key->bk_half_valid &&
+                launch_bk_to_half(key->d_bk_half, (const u64 *)key->d_bk, key->bk_polys(), ctx->stream) == hipSuccess)
+                key->bk_half_valid = true;
+            if (key->d_bk_half && key->bk_half_valid) P.bk_half = key->d_bk_half;
         }
     }
     P.n = key->n;
@@ -664,7 +745,7 @@ int nufhe_bootstrap(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe
     int rc = check_key(ctx, key, true, !no_keyswitch);
     if (rc) return rc;
     if ((rc = check_lwe(x, key->n, "bootstrap input", false, nbits)) ||
-        (rc = check_lwe(result, no_keyswitch ? key->ext_size() : key->n, "bootstrap result", !no_keyswitch, nbits)))
+        (rc = check_lwe(result, no_keyswitch ? key->ext_size() : key->n, "bootstrap result", !no_keyswitch, nbits, true)))
         return rc;
     BrJob job;
     memset(&job, 0, sizeof(job));
@@ -679,7 +760,7 @@ int nufhe_keyswitch(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe
     if (rc) return rc;
     if (nbits < 0) return fail(NUFHE_EINVAL, "negative batch size");
     if ((rc = check_lwe(src, key->ext_size(), "keyswitch source", false, nbits)) ||
-        (rc = check_lwe(result, key->n, "keyswitch result", true, nbits)))
+        (rc = check_lwe(result, key->n, "keyswitch result", true, nbits, true)))
         return rc;
     if (nbits == 0) return NUFHE_OK;
     if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
@@ -698,7 +779,7 @@ int nufhe_gate_binary(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nuf
 {
     int rc = check_key(ctx, key, true, true);
     if (rc) return rc;
-    if ((rc = check_lwe(result, key->n, "gate result", true, nbits)) || (rc = check_lwe(a, key->n, "gate operand a", false, nbits)) ||
+    if ((rc = check_lwe(result, key->n, "gate result", true, nbits, true)) || (rc = check_lwe(a, key->n, "gate operand a", false, nbits)) ||
         (rc = check_lwe(b, key->n, "gate operand b", false, nbits)))
         return rc;
     BrJob job;
@@ -714,7 +795,7 @@ int nufhe_gate_mux(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe_
 {
     int rc = check_key(ctx, key, true, true);
     if (rc) return rc;
-    if ((rc = check_lwe(result, key->n, "mux result", true, nbits)) || (rc = check_lwe(a, key->n, "mux operand a", false, nbits)) ||
+    if ((rc = check_lwe(result, key->n, "mux result", true, nbits, true)) || (rc = check_lwe(a, key->n, "mux operand a", false, nbits)) ||
         (rc = check_lwe(b, key->n, "mux operand b", false, nbits)) || (rc = check_lwe(c, key->n, "mux operand c", false, nbits)))
         return rc;
     const i32 MU = (i32)(1u << 29);

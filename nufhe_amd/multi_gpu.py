@@ -20,6 +20,75 @@ The functions contain no device-specific code: they work on whatever tensors the
 import torch
 
 
+def launch_ranks(script: str, argv, nproc: int, backend: str = "nccl"):
+    """
+    Starts ``nproc`` ranks of ``script`` on THIS node (one process per GPU) and returns the exit status:
+    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node nproc --master-addr 127.0.0.1
+    --master-port <free port> script argv...``.  This is what lets ``python bench.py --gpus N`` and
+    ``python examples/multi_gpu.py --gpus N`` be complete commands, like the reference's example that
+    starts its own per-GPU workers (examples/multi_gpu.py:86-114).  A process that already has ``RANK``
+    in its environment must not call this (it IS a rank).
+
+    With the ``nccl`` (= RCCL) backend every rank needs its own GPU: fewer visible devices than ranks is
+    an error here, before anything is started.  ``gloo`` is the test route (ranks may share a GPU).
+    """
+    import os
+    import socket
+    import subprocess
+    import sys
+    if "RANK" in os.environ:
+        raise RuntimeError("launch_ranks called from inside a rank (RANK is set)")
+    if nproc < 1:
+        raise ValueError("nproc must be >= 1")
+    if backend == "nccl" and torch.cuda.device_count() < nproc:
+        raise RuntimeError("%d ranks over RCCL need %d GPUs, this node shows %d (set NUFHE_BENCH_BACKEND=gloo "
+                           "for the shared-GPU test route)" % (nproc, nproc, torch.cuda.device_count()))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // nproc)))
+    return subprocess.call(cmd, env=env)
+
+
+def broadcast_cloud_key(thr, cloud_key, src: int = 0, group=None):
+    """
+    Replicates a cloud key from rank ``src`` to every rank of the group as ONE device broadcast of the key image
+    (98.6 MB for the default parameters: bootstrapping key in the kernels' layout + keyswitch key; RCCL over xGMI
+    with the ``nccl`` backend) -- SURVEY 8e's "ncclBroadcast from rank 0".  The reference pickles the key through
+    the host for every worker (examples/multi_gpu.py:86-107); that route stays available as dumps / load_cloud_key.
+
+    ``cloud_key`` is the key on ``src`` and ignored (may be None) elsewhere; returns the rank's key.  The few
+    parameter bytes travel as a pickled object first so that the receivers can size their buffers.
+    """
+    import torch.distributed as dist
+    from .api_low_level import NuFHECloudKey
+    rank = dist.get_rank(group)
+    meta = [cloud_key.params if rank == src else None]
+    global_src = dist.get_global_rank(group, src) if group is not None else src
+    dist.broadcast_object_list(meta, src=global_src, group=group)
+    params = meta[0]
+    if rank == src:
+        image = cloud_key._native.export_image()
+    else:
+        from .bootstrap import NativeCloudKey
+        probe = NativeCloudKey(thr, params.in_out_params.size, params._transform_type, params._tlwe_mask_size)
+        image = torch.empty(probe.image_bytes(), dtype=torch.uint8, device=thr.device)
+        probe.destroy()
+    if dist.get_backend(group) == "gloo" and image.is_cuda:       # test route: ranks sharing a GPU, staged through the host
+        staged = image.cpu()
+        dist.broadcast(staged, src=global_src, group=group)
+        if rank != src:
+            image.copy_(staged)
+    else:
+        dist.broadcast(image, src=global_src, group=group)
+    if rank == src:
+        return cloud_key
+    return NuFHECloudKey.from_device_image(thr, params, image)
+
+
 def shard_bounds(nbits: int, world_size: int, rank: int):
     """Contiguous slice [lo, hi) of a flattened batch owned by ``rank`` (sizes differ by at most 1;
     the first ``nbits % world_size`` ranks get the extra bit)."""
@@ -159,8 +228,11 @@ class AsyncGather:
 
     ``wait()`` makes the caller's current stream wait for the collective (device-side for RCCL, so
     the host does not block) and returns, on the destination rank, (a, b, variances) full tensors
-    [nbits_total, ...] in rank order -- views of the receive buffer when the batch divides evenly;
-    None on the other ranks."""
+    [nbits_total, ...] in rank order; None on the other ranks.  The receive buffer holds one
+    a | b | variances block per rank, so for more than one rank the three arrays are assembled with one
+    ``torch.cat`` each (a copy of the gathered bytes on the current stream); only a single-rank group gets
+    views of the receive buffer.  Callers that consume the packed blocks themselves (``bench.py``) pass
+    ``unpack=False`` and pay nothing."""
 
     def __init__(self, work, recv, keep, world, cap, n, nbits_total, device, is_dst):
         self._work, self._recv, self._keep = work, recv, keep

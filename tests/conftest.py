@@ -13,7 +13,17 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "slow: long-running CPU test")
+    config.addinivalue_line("markers", "slow: long-running test (GPU ones run only when the -m expression names `slow`)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`-m gpu` (the round-end run) leaves out the GPU tests that are also marked slow; `-m "gpu and slow"` runs them."""
+    if 'slow' in (config.option.markexpr or ''):
+        return
+    skip = pytest.mark.skip(reason='gpu + slow: run with -m "gpu and slow"')
+    for item in items:
+        if 'gpu' in item.keywords and 'slow' in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope='session')

@@ -34,8 +34,14 @@ def test_library_exports_every_declared_symbol(built_lib):
     missing = [name for name in sorted(declared) if not hasattr(lib, name)]
     assert not missing, missing
     # the ctypes prototypes cover the header
-    proto = set(built_lib.PROTOTYPES) | {'nufhe_last_error', 'nufhe_version', 'nufhe_ctx_stream'}
+    proto = set(built_lib.PROTOTYPES) | {'nufhe_last_error', 'nufhe_version', 'nufhe_ctx_stream', 'nufhe_abi_version'}
     assert declared <= proto, sorted(declared - proto)
+    # the binding, the header and the binary agree on the ABI version (structs are passed by value)
+    macro = int(re.search(r'#define\s+NUFHE_ABI_VERSION\s+(\d+)', header).group(1))
+    lib.nufhe_abi_version.restype = ctypes.c_int
+    assert macro == built_lib.ABI_VERSION == lib.nufhe_abi_version()
+    lib.nufhe_version.restype = ctypes.c_char_p
+    assert b'0.4' in lib.nufhe_version()
 
 
 def test_no_cpu_fallback(built_lib):

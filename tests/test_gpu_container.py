@@ -208,6 +208,23 @@ def test_c_boundary_refuses_wrong_operand_sizes(thr):
     refused(L.nufhe_keyswitch(h, key, desc(0, ext), desc(1, ext), nbits), "keyswitch result: LWE size 1024, expected 500")
     refused(L.nufhe_lwe_linear(h, desc(0, n), desc(1, ext), 1, 0, nbits, n), "lwe_linear source: LWE size 1024")
     refused(L.nufhe_lwe_trivial_const(h, desc(0, ext), MU, nbits, n), "lwe_trivial_const result: LWE size 1024")
+    # a RESULT of several bits with a broadcast (zero) stride would have every bit's work-group write the same row
+    def bcast(i, size, which):
+        d = desc(i, size)
+        setattr(d, which, 0)
+        return d
+    refused(L.nufhe_gate_binary(h, key, bcast(0, n, 'a_stride'), desc(1, n), desc(2, n), MU, -1, -1, MU, nbits), "gate result: zero (broadcast) stride")
+    refused(L.nufhe_gate_binary(h, key, bcast(0, n, 'b_stride'), desc(1, n), desc(2, n), MU, -1, -1, MU, nbits), "gate result: zero (broadcast) stride")
+    refused(L.nufhe_gate_mux(h, key, bcast(0, n, 'a_stride'), desc(1, n), desc(2, n), desc(3, n), nbits), "mux result: zero (broadcast) stride")
+    refused(L.nufhe_bootstrap(h, key, bcast(0, ext, 'b_stride'), desc(1, n), MU, nbits, 1), "bootstrap result: zero (broadcast) stride")
+    refused(L.nufhe_keyswitch(h, key, bcast(0, n, 'a_stride'), desc(3, ext), nbits), "keyswitch result: zero (broadcast) stride")
+    refused(L.nufhe_lwe_linear(h, bcast(0, n, 'a_stride'), desc(1, n), 1, 0, nbits, n), "lwe_linear result: zero (broadcast) stride")
+    refused(L.nufhe_lwe_trivial_const(h, bcast(0, n, 'b_stride'), MU, nbits, n), "lwe_trivial_const result: zero (broadcast) stride")
+    # ... a broadcast OPERAND is fine (one ciphertext against a batch), and so is a one-bit result with any stride
+    assert L.nufhe_lwe_trivial_const(h, desc(1, n), MU, nbits, n) == 0
+    assert L.nufhe_gate_binary(h, key, ok, bcast(1, n, 'a_stride'), desc(1, n), MU, -1, -1, MU, nbits) == 0
+    assert L.nufhe_gate_binary(h, key, bcast(0, n, 'a_stride'), desc(1, n), desc(1, n), MU, -1, -1, MU, 1) == 0
+    assert L.nufhe_abi_version() == _lib.ABI_VERSION
     # a negative batch is refused as before, and the well-formed calls run
     refused(L.nufhe_gate_binary(h, key, ok, desc(1, n), desc(2, n), MU, -1, -1, MU, -1), "negative batch")
     assert L.nufhe_lwe_trivial_const(h, desc(1, n), MU, nbits, n) == 0

@@ -465,8 +465,8 @@ def test_bench_two_ranks_on_one_gpu():
     assert d['gather']['dst'] == 0 and d['gather']['verified'] is True and len(d['per_rank_ms_per_step']) == 2
     assert d['gather']['collectives_per_step'] == 1 and d['gather']['overlapped'] is True
     assert abs(d['value'] - 2 * 256 * 1000.0 / d['ms_per_step']) < 1e-6 * d['value']
-    # an N > 1 line carries parity from EVERY rank (first 32 ciphertexts of each shard vs the oracle) and the roofline
-    assert d['parity']['ranks_reporting'] == 2 and d['parity']['differing'] == 0 and d['parity']['words'] == 2 * 32 * 501
+    # an N > 1 line carries parity from EVERY rank (first 256 ciphertexts of each shard vs the oracle) and the roofline
+    assert d['parity']['ranks_reporting'] == 2 and d['parity']['differing'] == 0 and d['parity']['words'] == 2 * 256 * 501
     assert d['parity']['variances_differing'] == 0 and d['roofline']['kernel_ms'] > 0
 
 
@@ -562,3 +562,163 @@ def test_bench_rccl_route_world_size_one():
     assert d['n_gpus'] == 1 and d['correct']
     assert d['gather']['backend'] == 'nccl' and d['gather']['verified'] is True and d['gather_ms'] > 0
     assert len(d['per_rank_ms_per_step']) == 1
+
+
+def _bench_line(proc):
+    import json
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
+    lines = [l for l in proc.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` -- the driver's literal command form, NO torch.distributed.run around it -- starts
+    two ranks by itself (nufhe_amd.multi_gpu.launch_ranks; the reference's example starts its own per-GPU workers,
+    examples/multi_gpu.py:86-114) and prints ONE line with n_gpus == 2, per-rank step times and a parity verdict
+    from both ranks over 256 ciphertexts each.  Two ranks share this box's GPU over the gloo test route."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NUFHE_BENCH_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--bits', '256', '--no-extra']
+    d = _bench_line(subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root))
+    assert d['n_gpus'] == 2 and d['correct'] and d['scaling'] == 'weak'
+    assert len(d['per_rank_ms_per_step']) == 2 and all(t > 0 for t in d['per_rank_ms_per_step'])
+    assert d['parity']['ranks_reporting'] == 2 and d['parity']['differing'] == 0
+    assert d['parity']['bits_per_rank'] == 256 and d['parity']['words'] == 2 * 256 * 501
+    assert d['parity']['variances_differing'] == 0
+    assert abs(d['value'] - 2 * 256 * 1000.0 / d['ms_per_step']) < 1e-6 * d['value']
+    assert d['config']['workload'].endswith('(BASELINE config 4)')
+
+
+def test_bench_refuses_more_rccl_ranks_than_gpus():
+    """Over RCCL every rank needs a GPU of its own: `--gpus N` with fewer devices fails loudly BEFORE starting anything
+    (it must never fall back to measuring one GPU and printing n_gpus 1), and a launcher whose world size contradicts
+    --gpus is refused as well."""
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in (
+        'NUFHE_BENCH_BACKEND', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    n = torch.cuda.device_count() + 1
+    proc = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(n), '--steps', '1'],
+                          capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert proc.returncode != 0 and 'need %d GPUs' % n in proc.stderr and '{' not in proc.stdout
+    env2 = dict(env, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    proc = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1'],
+                          capture_output=True, text=True, timeout=300, env=env2, cwd=root)
+    assert proc.returncode != 0 and 'WORLD_SIZE=1' in proc.stderr and '{' not in proc.stdout
+
+
+@pytest.mark.parametrize('via_host', [False, True])
+def test_multi_gpu_example_gpus_2_starts_its_own_ranks(via_host):
+    """`python examples/multi_gpu.py --gpus 2` without a launcher; the cloud key reaches rank 1 as one device broadcast of
+    its image (default) or, with --via-host, pickled through the host like the reference's example."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in (
+        'NUFHE_BENCH_BACKEND', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    cmd = [sys.executable, os.path.join(root, 'examples', 'multi_gpu.py'), '--gpus', '2', '--bits', '45',
+           '--backend', 'gloo'] + (['--via-host'] if via_host else [])
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
+    assert 'multi-GPU gate_nand OK: 45 bits over 2 GPU(s), gathered to rank 0 over gloo' in proc.stdout
+    assert ('key via host pickle' if via_host else 'key as one device broadcast') in proc.stdout
+
+
+def test_cloud_key_device_image_round_trip(env, orc):
+    """NuFHECloudKey.device_image / from_device_image (nufhe_cloudkey_export_image / _import_image): the key rebuilt
+    from its device image is the same key -- reference-format bootstrapping and keyswitch arrays equal, and gates of
+    every kernel family (8-wave team: 5 bits, pair: 300, wave + matrix-core keyswitch: 2100) give identical words."""
+    import torch
+    from nufhe_amd.api_low_level import NuFHECloudKey
+    H = env['H']; thr = env['thr']; ctx = env['ctx']; sk = env['secret_key']; ck0 = env['cloud_key']
+    params, image = ck0.device_image()
+    assert image.dtype == torch.uint8 and image.numel() == ck0._native.image_bytes() >= 32_768_000 + 49_152_000
+    ck1 = NuFHECloudKey.from_device_image(thr, params, image.clone())
+    del image
+    assert ck1 == ck0                                    # downloads both keys in the reference's formats
+    vm0 = ctx.make_virtual_machine(ck0); vm1 = ctx.make_virtual_machine(ck1)
+    rng = numpy.random.RandomState(77)
+    for B in (5, 300, 2100):
+        m1 = rng.randint(0, 2, size=(B,)).astype(bool); m2 = rng.randint(0, 2, size=(B,)).astype(bool)
+        c1 = ctx.encrypt(sk, m1); c2 = ctx.encrypt(sk, m2)
+        r0 = vm0.gate_nand(c1, c2); r1 = vm1.gate_nand(c1, c2)
+        assert r0 == r1 and (ctx.decrypt(sk, r1) == ~(m1 & m2)).all()
+    with pytest.raises(ValueError):
+        ck1._native.import_image(torch.zeros(1000, dtype=torch.uint8, device=thr.device))
+
+
+@pytest.mark.parametrize('transform', ['NTT', 'FFT'])
+def test_secure_rng_end_to_end(transform):
+    """test/test_api_high_level.py:114-132 (`test_rngs[SecureRNG]`): Context(rng=SecureRNG()) -> key pair -> encrypt ->
+    gates -> decrypt equals the truth tables; NAND as in the reference's test plus MUX, on both transforms."""
+    import random
+    import nufhe_amd as nufhe
+    size = 32
+    bits = [[random.choice([False, True]) for _ in range(size)] for _ in range(3)]
+    ctx = nufhe.Context(rng=nufhe.SecureRNG())
+    secret_key, cloud_key = ctx.make_key_pair(transform_type=transform)
+    cts = [ctx.encrypt(secret_key, b) for b in bits]
+    vm = ctx.make_virtual_machine(cloud_key)
+    b = [numpy.array(x) for x in bits]
+    assert all(ctx.decrypt(secret_key, vm.gate_nand(cts[0], cts[1])) == ~(b[0] & b[1]))
+    assert all(ctx.decrypt(secret_key, vm.gate_mux(cts[0], cts[1], cts[2])) == numpy.where(b[0], b[1], b[2]))
+    # a second key pair from the same SecureRNG is a different key
+    sk2, _ = ctx.make_key_pair(transform_type=transform)
+    assert not (sk2 == secret_key)
+
+
+@pytest.mark.parametrize('single_kernel_bootstrap', [True, False])
+def test_gate_over_view(env, orc, single_kernel_bootstrap):
+    """test/test_gates.py:514-559 with its own slices: operands and result are strided views of (5, 8) arrays, through
+    vm.gate_nand, in both bootstrap modes (fused kernels / the reference's step-by-step sequence).  Beyond the
+    reference's decrypt check: the words written through the view equal the oracle's on the same operands, and
+    nothing outside the view is touched."""
+    import nufhe_amd
+    from nufhe_amd.performance import PerformanceParameters
+    H = env['H']; thr = env['thr']; ctx = env['ctx']; sk = env['secret_key']; cloud_key = env['cloud_key']; ck = env['ck']
+    vm = ctx.make_virtual_machine(cloud_key, perf_params=PerformanceParameters(
+        cloud_key.params, single_kernel_bootstrap=single_kernel_bootstrap))
+    rng = numpy.random.RandomState(5)
+    shape = (5, 8)
+    slices1 = (slice(3, 5), slice(1, 7, 2))
+    slices2 = (slice(1, 3), slice(2, 8, 2))
+    result_slices = (slice(2, 4), slice(0, 6, 2))
+    pts = [rng.randint(0, 2, size=shape).astype(bool) for _ in range(2)]
+    cts = [ctx.encrypt(sk, p) for p in pts]
+    answer = vm.empty_ciphertext(shape)
+    answer.a.fill_(7); answer.b.fill_(7); answer.current_variances.fill_(7.0)
+    vm.gate_nand(cts[0][slices1], cts[1][slices2], dest=answer[result_slices])
+    ha = [H.ct_arrays(c) for c in cts]
+    exp = orc.gate('gate_nand', ck, tuple(x[slices1] for x in ha[0][:2]), tuple(x[slices2] for x in ha[1][:2]))
+    ra, rb, rcv = H.ct_arrays(answer)
+    assert (ra[result_slices] == exp[0]).all() and (rb[result_slices] == exp[1]).all()
+    mask = numpy.ones(shape, bool); mask[result_slices] = False
+    assert (ra[mask] == 7).all() and (rb[mask] == 7).all() and (rcv[mask] == 7.0).all()
+    dec = ctx.decrypt(sk, answer)
+    assert (dec[result_slices] == ~(pts[0][slices1] & pts[1][slices2])).all()
+
+
+@pytest.mark.slow
+def test_extended_parity_every_word():
+    """tools/extended_parity.py as a test (`pytest -m "gpu and slow"`; skipped by a plain `-m gpu` run: ~2-3 minutes of
+    CPU oracle): EVERY output word of 2048-bit NAND / XOR / MUX (wave kernel), 700-bit NAND (pair kernel), 200-bit
+    NAND / XNOR / MUX and 100-bit MUX (8-wave half-ring team kernel / pair kernel) and a 256-bit k = 2 NAND equals the
+    CPU oracle -- 3.9 M words, zero differing."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.run([sys.executable, os.path.join(root, 'tools', 'extended_parity.py')],
+                          capture_output=True, text=True, timeout=3000, cwd=root)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+    d = json.loads([l for l in proc.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['total_differing'] == 0
+    assert sum(v['words'] for part in ('k1', 'k2') for v in d[part].values()) > 3_800_000

@@ -202,6 +202,15 @@ def test_bootstrap_without_keyswitch_step_by_step(env, orc):
     bootstrap(thr, a, bk, ks, 2**29, x, perf, no_keyswitch=True)
     bootstrap(thr, b, bk, ks, 2**29, x, None, no_keyswitch=True)
     assert (H.host(a.a) == H.host(b.a)).all() and (H.host(a.b) == H.host(b.b)).all()
+    # both modes broadcast their argument to the result's shape: one ciphertext (shape (4,)) into a (3, 4) result
+    a2 = L.LweSampleArray.empty(thr, bk.extract_params, (3, 4))
+    b2 = L.LweSampleArray.empty(thr, bk.extract_params, (3, 4))
+    bootstrap(thr, a2, bk, ks, 2**29, x, perf, no_keyswitch=True)
+    bootstrap(thr, b2, bk, ks, 2**29, x, None, no_keyswitch=True)
+    assert (H.host(a2.a) == H.host(b2.a)).all() and (H.host(a2.b) == H.host(b2.b)).all()
+    assert all((H.host(a2.a)[r] == H.host(a.a)).all() for r in range(3))
+    with pytest.raises(ValueError):
+        bootstrap(thr, L.LweSampleArray.empty(thr, bk.extract_params, (3, 5)), bk, ks, 2**29, x, perf, no_keyswitch=True)
 
 
 def test_key_generation_steps_vs_oracle(env, orc):

@@ -182,3 +182,70 @@ def test_shard_bounds_partition():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_bounds(10, 2, 2)
+
+
+_RANK_SCRIPT = '''
+import os, sys
+import torch, torch.distributed as dist
+dist.init_process_group("gloo")
+t = torch.tensor([dist.get_rank() + 1])
+dist.all_reduce(t)
+out = sys.argv[sys.argv.index("--out") + 1]
+open(os.path.join(out, "rank%d" % dist.get_rank()), "w").write(
+    "%d %s %d %s" % (dist.get_world_size(), os.environ["MASTER_ADDR"], int(t.item()), os.environ.get("OMP_NUM_THREADS")))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize('nproc', [2, 3])
+def test_launch_ranks_starts_n_ranks_from_a_plain_process(tmp_path, nproc):
+    """multi_gpu.launch_ranks -- what `python bench.py --gpus N` and `python examples/multi_gpu.py --gpus N` call when
+    no launcher started them: N ranks on this node under torch.distributed.run, rendezvous on 127.0.0.1 and a free port,
+    the host's threads shared out, the script's own arguments passed through, exit status returned."""
+    from nufhe_amd import multi_gpu
+    script = tmp_path / 'ranks.py'
+    script.write_text(_RANK_SCRIPT)
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'OMP_NUM_THREADS'):
+        os.environ.pop(k, None)
+    try:
+        rc = multi_gpu.launch_ranks(str(script), ['--out', str(tmp_path)], nproc, backend='gloo')
+    finally:
+        os.environ.clear(); os.environ.update(env)
+    assert rc == 0
+    for r in range(nproc):
+        world, addr, total, omp = (tmp_path / ('rank%d' % r)).read_text().split()
+        assert int(world) == nproc and addr == '127.0.0.1' and int(total) == nproc * (nproc + 1) // 2
+        assert int(omp) == max(1, (os.cpu_count() or 1) // nproc)
+    bad = tmp_path / 'bad.py'
+    bad.write_text('import sys; sys.exit(3)')
+    assert multi_gpu.launch_ranks(str(bad), [], 2, backend='gloo') != 0
+
+
+def test_launch_ranks_refusals(monkeypatch):
+    from nufhe_amd import multi_gpu
+    monkeypatch.delenv('RANK', raising=False)
+    if torch.cuda.device_count() < 2:
+        with pytest.raises(RuntimeError, match='need 2 GPUs'):           # RCCL: one GPU per rank, checked before starting
+            multi_gpu.launch_ranks('x.py', [], 2, backend='nccl')
+    with pytest.raises(ValueError):
+        multi_gpu.launch_ranks('x.py', [], 0, backend='gloo')
+    monkeypatch.setenv('RANK', '0')
+    with pytest.raises(RuntimeError, match='inside a rank'):
+        multi_gpu.launch_ranks('x.py', [], 2, backend='gloo')
+
+
+def test_bench_gpus_n_without_gpus_fails_loudly():
+    """`python bench.py --gpus 2` where RCCL cannot give every rank a GPU (this container has none) exits non-zero
+    with the reason and prints no JSON line -- it never degrades to a one-GPU measurement."""
+    import subprocess
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('two GPUs present')
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'NUFHE_BENCH_BACKEND')}
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'],
+                          capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert proc.returncode != 0 and 'need 2 GPUs' in proc.stderr and '{' not in proc.stdout
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'],
+                          capture_output=True, text=True, timeout=300, cwd=ROOT,
+                          env=dict(env, RANK='0', WORLD_SIZE='4', LOCAL_RANK='0'))
+    assert proc.returncode != 0 and 'WORLD_SIZE=4' in proc.stderr and '{' not in proc.stdout
