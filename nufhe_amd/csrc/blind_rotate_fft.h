@@ -142,7 +142,7 @@ FF_FN void brf_external_product(u32 (&res)[2][16], const u32 (&T)[2][16], const 
 #endif
         BR_PROBE_MARK(2 * m + 1);
     }
-    fft_inverse_n<2>(sum, bufs, lds.tw1, tw2, L);
+    fft_inverse_2s(sum, bufs, lds.tw1, tw2, L);
     BR_PROBE_MARK(4);
 #pragma unroll
     for (int mo = 0; mo < 2; mo++)

@@ -96,6 +96,9 @@ __device__ __forceinline__ void body(uint32_t (&a)[16], uint64_t (&w)[8], uint32
         else if (OP == 54) { if (i % 256 == 0) __builtin_amdgcn_s_barrier(); if (i % 256 < 192) A1("v_add_u32 %0, %0, %1"); else A1("v_lshl_add_u32 %0, %0, 3, %1"); }
         else if (OP == 55) { if (i % 64 == 0) __builtin_amdgcn_s_barrier(); A1("v_add_u32 %0, %0, %1"); }
         else if (OP == 56) { if (i % 64 == 0) __builtin_amdgcn_s_barrier(); if (i % 64 < 48) A1("v_add_u32 %0, %0, %1"); else A1("v_lshl_add_u32 %0, %0, 3, %1"); }
+        else if (OP == 90) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[i % 16]), "+v"(a[(i + 8) % 16]));
+        else if (OP == 91) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a[i % 16]), "+v"(a[(i + 8) % 16]));
+        else if (OP == 92) { if (i % 8 == 0) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[i % 16]), "+v"(a[(i + 8) % 16])); else asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(w[i % 8])); }
         else if (OP == 49) { if (i % 2 < 1) A1("v_add_u32 %0, %0, %1"); else A1("v_add_u32 %0, %3, %0"); }
     }
 }
@@ -267,8 +270,25 @@ static void run_pair(const char *name, uint32_t *d_out, long long *d_cyc)
     fflush(stdout);
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    if (argc > 1 && argv[1][0] == 'p') {         // only the cross-lane swaps of gfx950 (round 4)
+        hipDeviceProp_t p;
+        hipGetDeviceProperties(&p, 0);
+        g_cus = p.multiProcessorCount;
+        hipDeviceGetAttribute(&g_wall_khz, hipDeviceAttributeWallClockRate, 0);
+        uint32_t *d_out;
+        long long *d_cyc;
+        hipMalloc(&d_out, (size_t)g_cus * 2 * 1024 * 4);
+        hipMalloc(&d_cyc, (size_t)g_cus * 2 * 16 * 8 * 2);
+        printf("%-28s %6s %6s %6s %6s %6s\n", "opcode \\ waves per SIMD", "1", "2", "3", "4", "8");
+        run_op<15>("v_fma_f64", d_out, d_cyc);
+        run_op<90>("v_permlane32_swap_b32", d_out, d_cyc);
+        run_op<91>("v_permlane16_swap_b32", d_out, d_cyc);
+        run_op<92>("1 permlane32_swap : 7 fma_f64", d_out, d_cyc);
+        run_op<25>("v_mov_b32_dpp", d_out, d_cyc);
+        return 0;
+    }
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
     g_cus = p.multiProcessorCount;
