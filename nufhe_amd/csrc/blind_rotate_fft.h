@@ -104,8 +104,7 @@ FF_FN void brf_mac_pair(cplx (&sum)[2][8], const cplx (&x)[2][8], const cplx *ro
 #pragma unroll
         for (int i = 0; i < BRF_KEY_GROUP; i++) {
             const int r = BRF_KEY_GROUP * (g % GPP) + i;
-            sum[mo][r].re += x[d][r].re * q[0][i].re - x[d][r].im * q[0][i].im;
-            sum[mo][r].im += x[d][r].re * q[0][i].im + x[d][r].im * q[0][i].re;
+            c_fma_acc(sum[mo][r], x[d][r], q[0][i]);
         }
 #pragma unroll
         for (int j = 0; j < D; j++)
@@ -278,8 +277,7 @@ FF_FN void brfk_mac_pair(cplx (&sum)[K + 1][8], const cplx (&x)[2][8], const cpl
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int r = 4 * (g & 1) + i;
-            sum[mo][r].re += x[d][r].re * k[i].re - x[d][r].im * k[i].im;
-            sum[mo][r].im += x[d][r].re * k[i].im + x[d][r].im * k[i].re;
+            c_fma_acc(sum[mo][r], x[d][r], k[i]);
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) k[i] = n[i];
@@ -760,8 +758,7 @@ FF_FN void brf_mac_one(cplx (&out)[8], const cplx (&x)[2][8], const cplx *poly0,
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int r = 4 * (g & 1) + i;
-            out[r].re += x[d][r].re * k[i].re - x[d][r].im * k[i].im;
-            out[r].im += x[d][r].re * k[i].im + x[d][r].im * k[i].re;
+            c_fma_acc(out[r], x[d][r], k[i]);
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) k[i] = n[i];

@@ -42,6 +42,17 @@ FF_FN cplx c_add(cplx a, cplx b) { return cplx{a.re + b.re, a.im + b.im}; }
 FF_FN cplx c_sub(cplx a, cplx b) { return cplx{a.re - b.re, a.im - b.im}; }
 FF_FN cplx c_mul(cplx a, cplx b) { return cplx{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 FF_FN cplx c_mul_conj(cplx a, cplx b) { return cplx{a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im}; }  // a * conj(b)
+// acc += a * b as four fused multiply-adds chained through the accumulator.  Written out because the compiler may
+// contract a * b - c * d into mul + fma but may not re-associate the sum with the accumulator: `acc += a * b` compiles
+// to mul, fma, add per component (6 instructions per complex term instead of 4; round 4: 414 -> 286 in the product
+// phase of k_bootstrap_fft).
+FF_FN void c_fma_acc(cplx &acc, cplx a, cplx b)
+{
+    acc.re = fma(a.re, b.re, acc.re);
+    acc.re = fma(-a.im, b.im, acc.re);
+    acc.im = fma(a.re, b.im, acc.im);
+    acc.im = fma(a.im, b.re, acc.im);
+}
 FF_FN cplx c_mul_mi(cplx a) { return cplx{a.im, -a.re}; }   // a * (-i)
 FF_FN cplx c_mul_pi(cplx a) { return cplx{-a.im, a.re}; }   // a * (+i)
 
