@@ -19,6 +19,10 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this pool needs dmabuf IPC (the host driver has no legacy IPC): RCCL would fail with
+# `hipIpcGetMemHandle: invalid argument` without it; must be in the environment before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy
 import torch
 

@@ -23,6 +23,8 @@ import argparse
 import os
 import sys
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC between the ranks of a node (RCCL)
+
 import numpy
 import torch
 import torch.distributed as dist

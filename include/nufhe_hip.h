@@ -69,6 +69,15 @@ int nufhe_free(nufhe_ctx *ctx, void *d_ptr);
 int nufhe_h2d(nufhe_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);   /* synchronous */
 int nufhe_d2h(nufhe_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);   /* synchronous */
 
+/* ---- single-process multi-GPU result collection (the reference drives several GPUs from the threads of one process and
+ * its main thread collects the slices, examples/multi_gpu.py:46-114).  Slice i -- bytes[i] bytes at d_srcs[i] on the
+ * device of srcs[i] -- lands at d_dst + dst_offsets[i] on the device of `dst`: a peer copy enqueued on the SOURCE
+ * context's stream (ordered behind the gate that wrote the slice, no host synchronisation), and dst's stream waits for
+ * all of them.  Contexts of one device are allowed (own streams).  One process per GPU gathers over RCCL instead
+ * (nufhe_amd/multi_gpu.py); the library itself carries no RCCL dependency. */
+int nufhe_gather(nufhe_ctx *dst, void *d_dst, const size_t *dst_offsets, nufhe_ctx *const *srcs,
+                 const void *const *d_srcs, const size_t *bytes, int count);
+
 /* ---- cloud key (BootstrapKey bootstrap.py:44-92, LweKeyswitchKey lwe.py:254-308) ---- */
 /* transform: NUFHE_TRANSFORM_NTT or NUFHE_TRANSFORM_FFT; mask_size: tlwe_mask_size k, 1 or 2 (both transforms)
  * (NuFHEParameters(transform_type=..., tlwe_mask_size=...), api_low_level.py:44-47).  They fix the

@@ -48,6 +48,7 @@ PROTOTYPES = {
     "nufhe_h2d": [_vp, _vp, _vp, ctypes.c_size_t],
     "nufhe_d2h": [_vp, _vp, _vp, ctypes.c_size_t],
     "nufhe_cloudkey_create": [_vp, _int, _int, _int, _pp],
+    "nufhe_gather": [_vp, _vp, ctypes.POINTER(ctypes.c_size_t), _pp, _pp, ctypes.POINTER(ctypes.c_size_t), _int],
     "nufhe_cloudkey_image_bytes": [_vp, ctypes.POINTER(ctypes.c_size_t)],
     "nufhe_cloudkey_export_image": [_vp, _vp],
     "nufhe_cloudkey_import_image": [_vp, _vp],

@@ -350,6 +350,39 @@ int nufhe_d2h(nufhe_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
     return NUFHE_OK;
 }
 
+// ---- single-process multi-GPU: result collection (SURVEY 8b "nufhe_gather(ctxs...)") ------------------
+// The reference's multi-GPU scheme is ONE process with a thread and a Thread object per GPU whose main thread collects
+// the result slices (examples/multi_gpu.py:46-114).  For a host built that way: slice i (bytes[i] bytes at d_srcs[i], on
+// srcs[i]'s device) is copied to d_dst + dst_offsets[i] on dst's device by hipMemcpyPeerAsync ON THE SOURCE CONTEXT'S
+// STREAM -- behind the gate that produced it, without a host synchronisation -- and dst's stream is made to wait for
+// every copy, so whatever the caller enqueues on dst afterwards sees the gathered array.  (One process per GPU uses the
+// RCCL gather of nufhe_amd/multi_gpu.py instead.)
+int nufhe_gather(nufhe_ctx *dst, void *d_dst, const size_t *dst_offsets, nufhe_ctx *const *srcs, const void *const *d_srcs,
+                 const size_t *bytes, int count)
+{
+    if (!dst || !srcs || !d_srcs || !bytes || !dst_offsets || count < 0) return fail(NUFHE_EINVAL, "null argument");
+    for (int i = 0; i < count; i++) {
+        if (!srcs[i]) return fail(NUFHE_EINVAL, "null source context %d", i);
+        if (bytes[i] && (!d_srcs[i] || !d_dst)) return fail(NUFHE_EINVAL, "null buffer of slice %d", i);
+    }
+    for (int i = 0; i < count; i++) {
+        if (!bytes[i]) continue;
+        nufhe_ctx *src = srcs[i];
+        HIP_TRY(hipSetDevice(src->device));
+        if (src->device == dst->device)
+            HIP_TRY(hipMemcpyAsync((char *)d_dst + dst_offsets[i], d_srcs[i], bytes[i], hipMemcpyDeviceToDevice, src->stream));
+        else
+            HIP_TRY(hipMemcpyPeerAsync((char *)d_dst + dst_offsets[i], dst->device, d_srcs[i], src->device, bytes[i],
+                                       src->stream));
+        if (src == dst || src->stream == dst->stream) continue;      // same queue: already ordered
+        HIP_TRY(hipEventRecord(src->ev[3], src->stream));
+        HIP_TRY(hipSetDevice(dst->device));
+        HIP_TRY(hipStreamWaitEvent(dst->stream, src->ev[3], 0));
+    }
+    HIP_TRY(hipSetDevice(dst->device));
+    return NUFHE_OK;
+}
+
 // ---- cloud key ---------------------------------------------------------------------------
 
 int nufhe_cloudkey_create(nufhe_ctx *ctx, int lwe_size, int transform, int mask_size, nufhe_cloudkey **key)

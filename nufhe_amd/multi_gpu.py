@@ -50,6 +50,7 @@ def launch_ranks(script: str, argv, nproc: int, backend: str = "nccl"):
            "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // nproc)))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs between the ranks of one node
     return subprocess.call(cmd, env=env)
 
 
@@ -87,6 +88,61 @@ def broadcast_cloud_key(thr, cloud_key, src: int = 0, group=None):
     if rank == src:
         return cloud_key
     return NuFHECloudKey.from_device_image(thr, params, image)
+
+
+def gather_threads(dst_thr, parts):
+    """
+    Single-process counterpart of the RCCL gather: the reference drives several GPUs from the threads of ONE process and
+    its main thread collects the result slices (examples/multi_gpu.py:46-114).  ``parts`` = [(DeviceThread, LweSampleArray
+    slice), ...] in slice order, each slice living on its thread's device; returns the concatenated LweSampleArray on
+    ``dst_thr``'s device.  The copies are peer-to-peer (``nufhe_gather``: enqueued on each SOURCE stream behind the gate
+    that produced the slice; the destination stream waits for them) -- nothing goes through the host.
+    """
+    import ctypes
+    from . import _lib
+    from .lwe import LweSampleArray
+    if not parts:
+        raise ValueError("nothing to gather")
+    params = parts[0][1].params
+    lead = [int(numpy_prod(ct.shape)) for _, ct in parts]
+    total = sum(lead)
+    n = params.size
+    with torch.cuda.device(dst_thr.device):
+        a = torch.empty((total, n), dtype=torch.int32, device=dst_thr.device)
+        b = torch.empty((total,), dtype=torch.int32, device=dst_thr.device)
+        cv = torch.empty((total,), dtype=torch.float32, device=dst_thr.device)
+    keep = []
+    for dst, field, row in ((a, 'a', 4 * n), (b, 'b', 4), (cv, 'current_variances', 4)):
+        count = len(parts)
+        srcs = (ctypes.c_void_p * count)()
+        ptrs = (ctypes.c_void_p * count)()
+        sizes = (ctypes.c_size_t * count)()
+        offs = (ctypes.c_size_t * count)()
+        pos = 0
+        for i, (thr, ct) in enumerate(parts):
+            if ct.params != params:
+                raise ValueError("slices with different LWE parameters")
+            src = getattr(ct, field)
+            with torch.cuda.stream(thr._torch_stream):     # a packing copy belongs on the slice's own queue
+                t = src.reshape((lead[i], n) if field == 'a' else (lead[i],)).contiguous()
+            if t.data_ptr() != src.data_ptr():
+                keep.append((thr, t))      # a strided slice was packed into a temporary: it must outlive its copy
+            srcs[i] = thr.handle.value
+            ptrs[i] = t.data_ptr() if lead[i] else None
+            sizes[i] = lead[i] * row
+            offs[i] = pos * row
+            pos += lead[i]
+        _lib.check(_lib.lib().nufhe_gather(dst_thr.handle, ctypes.c_void_p(dst.data_ptr()), offs, srcs, ptrs, sizes, count))
+    for thr in {id(t): t for t, _ in keep}.values():
+        thr.synchronize()              # (only when a temporary was made; contiguous slices are copied in place, no sync)
+    return LweSampleArray(params, a, b, cv)
+
+
+def numpy_prod(shape):
+    out = 1
+    for d in shape:
+        out *= int(d)
+    return out
 
 
 def shard_bounds(nbits: int, world_size: int, rank: int):

@@ -82,3 +82,51 @@ def test_two_contexts_in_two_threads():
     # a DeviceID survives pickling (it is what the reference ships to worker processes)
     import pickle
     assert str(pickle.loads(pickle.dumps(devices[0]))) == str(devices[0])
+
+
+def test_gather_threads_single_process_collection():
+    """multi_gpu.gather_threads / nufhe_gather: the reference's own multi-GPU shape -- one process, one Thread object per
+    GPU, the main thread collecting the result slices (examples/multi_gpu.py:46-114) -- with device-to-device copies
+    instead of pickles.  On this one-GPU box the three "GPUs" are three contexts of device 0, two of them on streams of
+    their own, so the copy-on-the-source-stream + destination-waits-for-event path runs for real; an even and a ragged
+    split, a strided slice (packed through a temporary) and an empty slice are covered, and the gathered ciphertext equals
+    the unsharded gate word for word."""
+    import torch
+    import nufhe_amd as nufhe
+    from nufhe_amd import multi_gpu
+    from nufhe_amd.device import DeviceThread
+    main = DeviceThread(0)
+    ctx = nufhe.Context(rng=nufhe.DeterministicRNG(5), thread=main)
+    sk, ck = ctx.make_key_pair()
+    blob = ck.dumps()
+    rs = numpy.random.RandomState(9)
+    B = 70
+    m1 = rs.randint(0, 2, B).astype(bool); m2 = rs.randint(0, 2, B).astype(bool)
+    c1 = ctx.encrypt(sk, m1); c2 = ctx.encrypt(sk, m2)
+    whole = ctx.make_virtual_machine(ck).gate_nand(c1, c2)
+    streams = [None, torch.cuda.Stream(), torch.cuda.Stream()]
+    bounds = [(0, 30), (30, 30), (30, 70)]                     # even-ish, EMPTY, ragged
+    parts = []
+    for s, (lo, hi) in zip(streams, bounds):
+        scope = torch.cuda.stream(s) if s is not None else torch.cuda.stream(torch.cuda.current_stream())
+        with scope:
+            thr = DeviceThread(0) if s is not None else main
+            wctx = nufhe.Context(rng=nufhe.DeterministicRNG(1), thread=thr)
+            wck = ck if s is None else wctx.load_cloud_key(blob)
+            vm = wctx.make_virtual_machine(wck)
+            if s is not None:
+                s.wait_stream(torch.cuda.default_stream())         # the inputs were made on the main stream
+            parts.append((thr, vm.gate_nand(c1[lo:hi], c2[lo:hi]), s))
+    # one worker's slice handed over as a strided view (every second bit of a double-size result)
+    with torch.cuda.stream(streams[2]):
+        thr2, r2, _ = parts[2]
+        wide = nufhe.api_low_level.empty_ciphertext(thr2, ck.params, (2 * 40,))
+        wide[::2] = r2
+        parts[2] = (thr2, wide[::2], streams[2])
+    # the collection itself is called under the DESTINATION's stream (main)
+    full = multi_gpu.gather_threads(main, [(t, r) for t, r, _ in parts])
+    assert full.shape == (B,)
+    assert full == whole
+    assert (ctx.decrypt(sk, full) == ~(m1 & m2)).all()
+    with pytest.raises(ValueError):
+        multi_gpu.gather_threads(main, [])
