@@ -27,5 +27,6 @@ from .gates import (
     gate_nor, gate_andny, gate_andyn, gate_orny, gate_oryn, gate_mux,
     )
 from .performance import PerformanceParameters
+from .graph import GateGraph
 
-__version__ = '0.1.0'
+__version__ = '0.4.0'

@@ -151,6 +151,11 @@ def gate_constant(thr, cloud_key, result, vals, perf_params=None):
         raise ValueError(
             "The shape of the values {vshape} cannot be broadcasted to the shape of the destination {rshape}".format(
                 vshape=vals.shape, rshape=result.shape))
+    if vals.ndim == 0:
+        # one constant for the whole array: filled on the device, nothing crosses PCIe (and the call can be part of a
+        # captured circuit, nufhe_amd/graph.py)
+        lwe_noiseless_trivial_constant(thr, result, MU if bool(vals) else -MU)
+        return
     mus = numpy.where(vals.astype(bool), MU, -MU).astype(numpy.int32)
     lwe_noiseless_trivial(thr, result, mus)
 

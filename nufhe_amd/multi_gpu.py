@@ -134,7 +134,8 @@ def gather_threads(dst_thr, parts):
             pos += lead[i]
         _lib.check(_lib.lib().nufhe_gather(dst_thr.handle, ctypes.c_void_p(dst.data_ptr()), offs, srcs, ptrs, sizes, count))
     for thr in {id(t): t for t, _ in keep}.values():
-        thr.synchronize()              # (only when a temporary was made; contiguous slices are copied in place, no sync)
+        with torch.cuda.stream(thr._torch_stream):
+            thr.synchronize()          # (only when a temporary was made; contiguous slices are copied in place, no sync)
     return LweSampleArray(params, a, b, cv)
 
 
