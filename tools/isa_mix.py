@@ -34,7 +34,7 @@ KERNELS = {'k_bootstrap<1>': '_Z11k_bootstrapILi1EEv8BrLaunch', 'k_bootstrap_fft
 def source_hash():
     h = hashlib.sha256()
     for name in sorted(os.listdir(CSRC)):
-        if name.endswith(('.h', '.hip')):
+        if name.endswith(('.h', '.hip')) and name != 'api.hip':     # api.hip is the host-side translation unit: no device code
             h.update(name.encode())
             h.update(open(os.path.join(CSRC, name), 'rb').read())
     return h.hexdigest()[:16]
