@@ -168,8 +168,8 @@ FF_FN void br_mac(u64 (&sum)[K + 1][16], const u64 (&x)[16], const u64 *poly, in
 // of work-group 0 in the segments of one external product, summed over the blind rotation.  Never part of
 // the shipped library.
 #if defined(BR_PROBE) && defined(__HIPCC__)
-__device__ unsigned long long g_br_probe[16];
-__device__ unsigned int g_br_probe_life[2 * 8192];   // per wave: start, end (wall_clock64, 10 ns units, low 32 bits)
+static __device__ unsigned long long g_br_probe[16];
+static __device__ unsigned int g_br_probe_life[2 * 8192];   // per wave: start, end (wall_clock64, 10 ns units, low 32 bits)
 #endif
 #if defined(BR_PROBE) && defined(__HIP_DEVICE_COMPILE__)
 struct BrProbe { long long t[8]; long long last; };
@@ -598,7 +598,7 @@ struct BrHalfLds {
 };
 
 #if defined(BR_PROBE) && defined(__HIPCC__)
-__device__ unsigned long long g_brh_probe[8];
+static __device__ unsigned long long g_brh_probe[8];
 #endif
 #if defined(BR_PROBE) && defined(__HIP_DEVICE_COMPILE__)
 #define BRH_MARK(i)                                                                                   \

@@ -179,35 +179,11 @@ __global__ __launch_bounds__(64 * BRT_WAVES, 1) void k_bootstrap_team(BrLaunch P
                   [] { __syncthreads(); });
 }
 
-// Smallest batches (k = 1): the half-ring team, EIGHT waves per bit (blind_rotate.h, brh_*; ntt512_half.h).
-// LDS: half-ring tables | ACC 8 KiB | bara 1 KiB | partial sums 64 KiB | join 16 KiB | 8 exchange buffers
-#define NTH_TABLE_BYTES (NTH_TABLE_ELEMS * 8)
-#define TEAM8_LDS_BYTES (NTH_TABLE_BYTES + 2 * 1024 * 4 + WAVE_BARA_BYTES + BRH_PART_ELEMS * 8 + BRH_JOIN_ELEMS * 8 + BRH_WAVES * NTH_XBUF_ELEMS * 8)
-static_assert(TEAM8_LDS_BYTES <= 160 * 1024, "LDS budget of the half-ring team kernel");
-__global__ __launch_bounds__(64 * BRH_WAVES, 1) void k_bootstrap_team8(BrLaunch P)
-{
-    {
-        u64 *t = (u64 *)g_smem;
-        const u64 *g = (const u64 *)P.tw_half;
-        for (int i = threadIdx.x; i < NTH_TABLE_ELEMS; i += blockDim.x) t[i] = g[i];
-        __syncthreads();
-    }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long gbit = blockIdx.x;
-    const int job = gbit >= P.bits_per_job ? 1 : 0;
-    const long bit = gbit - (job ? P.bits_per_job : 0);
-    unsigned char *base = g_smem + NTH_TABLE_BYTES;
-    BrHalfLds lds;
-    lds.tables = (const u64 *)g_smem;
-    lds.acc = (i32 *)base;
-    lds.bara = (uint16_t *)(base + 2 * 1024 * 4);
-    lds.part = (u64 *)(base + 2 * 1024 * 4 + WAVE_BARA_BYTES);
-    lds.join = lds.part + BRH_PART_ELEMS;
-    lds.xbuf = lds.join + BRH_JOIN_ELEMS + wave * NTH_XBUF_ELEMS;
-    brh_bootstrap(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, P.job[job].s0, P.job[job].s1,
-                  P.job[job].c0, bit, (const u64 *)P.bk_half, P.n, P.mu, lds, lane, WAVE_UNIFORM(wave),
-                  [] { __syncthreads(); });
-}
+// Smallest batches (k = 1): the half-ring team, EIGHT waves per bit -- k_bootstrap_team8 lives in kernels_team8.hip, a
+// translation unit of its own because it is the one kernel that gains from the back end's max-ilp scheduling strategy
+// (its reducer waves run alone on their SIMDs; NOTES.md round 3: -3 %, every other kernel loses with that flag).
+hipError_t team8_init();
+hipError_t launch_team8(const BrLaunch &P, hipStream_t stream);
 
 // Small-batch variant for tlwe_mask_size = 2: a team of 3 waves per bit (blind_rotate.h, brtk_*).
 // LDS: tables | ACC 12 KiB | bara 1 KiB | partial sums 72 KiB | 3 exchange buffers
@@ -1325,7 +1301,7 @@ hipError_t kernels_init_device(int *num_cus)
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap_fft_team, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAMF_LDS_BYTES);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void *)k_bootstrap_team8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAM8_LDS_BYTES);
+    e = team8_init();
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap_team, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAM_LDS_BYTES);
     if (e != hipSuccess) return e;
@@ -1409,7 +1385,8 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, lon
         team_max_bits = (transform == 0) ? (long)num_cus : 2L * num_cus;
     if (transform == 0 && mask_size == 1 && P.nbits_total <= team_max_bits && P.bk_half != nullptr) {
         // smallest batches: 8 waves per bit (two per digit transform, half rings), one bit per CU at a time
-        hipLaunchKernelGGL(k_bootstrap_team8, dim3((unsigned)P.nbits_total), dim3(64 * BRH_WAVES), TEAM8_LDS_BYTES, stream, P);
+        hipError_t e8 = launch_team8(P, stream);
+        if (e8 != hipSuccess) return e8;
     } else if (transform == 0 && mask_size == 1 && P.nbits_total <= team_max_bits) {
         // small batch: 4 waves per bit, one bit per CU at a time
         hipLaunchKernelGGL(k_bootstrap_team, dim3((unsigned)P.nbits_total), dim3(64 * BRT_WAVES), TEAM_LDS_BYTES, stream, P);
@@ -1915,13 +1892,6 @@ hipError_t launch_tlwe_extract(i32 *ra, i32 *rb, const i32 *tlwe, long batch, in
 
 #if defined(BR_PROBE)
 // variant builds only (blind_rotate.h, BR_PROBE): read and clear the segment tick counters
-extern "C" int nufhe_probe_read_team8(unsigned long long *out8)
-{
-    unsigned long long zero[8] = {0};
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_brh_probe), sizeof(zero)) != hipSuccess) return -1;
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_brh_probe), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
-}
-
 extern "C" int nufhe_probe_read(unsigned long long *out16)
 {
     unsigned long long zero[16] = {0};
