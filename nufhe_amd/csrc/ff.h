@@ -128,6 +128,37 @@ FF_FN void ff_mul_wide(u64 a, u64 b, u64 &lo, u64 &hi)
 #endif
 }
 
+// a * b + c for ANY 64-bit a, b, c, exactly: (2^64 - 1)^2 + 2^64 - 1 < 2^128, so the sum has no fifth word.  On the device
+// the addend rides in the FIRST multiply-add and its overflow joins the second partial sum as the top word of that
+// addend (a1 b0 + u.hi + 2^32 k < 2^64: if k = 1 the wrapped u is below 2^64 - 2^33): one select instead of the four
+// add-with-carry instructions of a separate 128-bit addition.
+FF_FN void ff_mul_wide_add(u64 a, u64 b, u64 c, u64 &lo, u64 &hi)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FF_MULWIDE_PLAIN)
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 u, k, w, carry;
+    u32 kc, cc;
+    asm("v_mad_u64_u32 %0, %1, %3, %4, %5\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32 %2, 0, 1, %1"
+        : "=&v"(u), "=&s"(k), "=v"(kc)
+        : "v"(a0), "v"(b0), "v"(c));
+    const u64 t = (u64)a1 * b0 + (((u64)kc << 32) | (u32)(u >> 32));
+    asm("v_mad_u64_u32 %0, %1, %3, %4, %5\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32 %2, 0, 1, %1"
+        : "=&v"(w), "=&s"(carry), "=v"(cc)
+        : "v"(a0), "v"(b1), "v"(t));
+    hi = (u64)a1 * b1 + (((u64)cc << 32) | (u32)(w >> 32));
+    lo = (w << 32) | (u32)u;
+#else
+    u64 l, h;
+    ff_mul_wide(a, b, l, h);
+    lo = l + c;
+    hi = h + (lo < l ? 1 : 0);
+#endif
+}
+
 // a0 * b0 + a1 * b1 [+ c] for canonical operands with ONE reduction: the two 128-bit products (each
 // < 2^128 - 2^97) and the optional canonical addend c are summed exactly in 129 bits
 // lo + 2^64 (h0 + 2^32 h1) + 2^128 top, and 2^128 = -2^32 (mod P), so the top bit joins h1 as a

@@ -311,9 +311,20 @@ template <bool ADD>
 FF_FN void l4_dot2(L4 &r, u64 a0, u64 b0, u64 a1, u64 b1, u64 c)
 {
     u64 lo0, hi0, lo1, hi1;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FF_MULWIDE_PLAIN)
+    // the addend joins the first product inside its multiply-add chain (ff_mul_wide_add): a0 b0 + c is still a 128-bit number
+    if constexpr (ADD) ff_mul_wide_add(a0, b0, c, lo0, hi0);
+    else ff_mul_wide(a0, b0, lo0, hi0);
+    ff_mul_wide(a1, b1, lo1, hi1);
+    unsigned cy;
+    u32 l0 = __builtin_addc((u32)lo0, (u32)lo1, 0u, &cy);
+    u32 l1 = __builtin_addc((u32)(lo0 >> 32), (u32)(lo1 >> 32), cy, &cy);
+    u32 h0 = __builtin_addc((u32)hi0, (u32)hi1, cy, &cy);
+    u32 h1 = __builtin_addc((u32)(hi0 >> 32), (u32)(hi1 >> 32), cy, &cy);
+    u32 top = cy;
+#elif defined(__HIP_DEVICE_COMPILE__)
     ff_mul_wide(a0, b0, lo0, hi0);
     ff_mul_wide(a1, b1, lo1, hi1);
-#if defined(__HIP_DEVICE_COMPILE__)
     unsigned cy;
     u32 l0 = __builtin_addc((u32)lo0, (u32)lo1, 0u, &cy);
     u32 l1 = __builtin_addc((u32)(lo0 >> 32), (u32)(lo1 >> 32), cy, &cy);
@@ -328,6 +339,8 @@ FF_FN void l4_dot2(L4 &r, u64 a0, u64 b0, u64 a1, u64 b1, u64 c)
         top += cy;
     }
 #else
+    ff_mul_wide(a0, b0, lo0, hi0);
+    ff_mul_wide(a1, b1, lo1, hi1);
     unsigned __int128 sum = (((unsigned __int128)hi0 << 64) | lo0);
     unsigned __int128 t = sum + (((unsigned __int128)hi1 << 64) | lo1);
     u32 top = t < sum;
