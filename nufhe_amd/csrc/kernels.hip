@@ -155,59 +155,18 @@ __global__ __launch_bounds__(64 * BR_K2_ROOMY_WAVES, 1) void k_bootstrap_k2_room
     bootstrap_wave_body<2>(P);
 }
 
-// Small-batch variant: a team of 4 waves (one work-group) per bit, see blind_rotate.h (brt_*).
-// LDS: tables | ACC 8 KiB | bara 1 KiB | partial sums 64 KiB | 4 exchange buffers
-#define TEAM_LDS_BYTES (TABLE_LDS_BYTES + 2 * 1024 * 4 + WAVE_BARA_BYTES + BRT_PART_ELEMS * 8 + BRT_WAVES * WAVE_XBUF_BYTES)
-__global__ __launch_bounds__(64 * BRT_WAVES, 1) void k_bootstrap_team(BrLaunch P)
-{
-    load_tables((const u64 *)P.tw_a, (const u64 *)P.tw_b);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long gbit = blockIdx.x;
-    const int job = gbit >= P.bits_per_job ? 1 : 0;
-    const long bit = gbit - (job ? P.bits_per_job : 0);
-    unsigned char *base = g_smem + TABLE_LDS_BYTES;
-    BrTeamLds lds;
-    lds.acc = (i32 *)base;
-    lds.bara = (uint16_t *)(base + 2 * 1024 * 4);
-    lds.part = (u64 *)(base + 2 * 1024 * 4 + WAVE_BARA_BYTES);
-    lds.xbuf = (u64 *)(base + 2 * 1024 * 4 + WAVE_BARA_BYTES + BRT_PART_ELEMS * 8 + wave * WAVE_XBUF_BYTES);
-    lds.tw1x = (const u64 *)g_smem;
-    lds.tw1i = (const u64 *)g_smem + 1024;
-    const NttLane L = ntt_lane_init(lane);
-    brt_bootstrap(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, P.job[job].s0, P.job[job].s1,
-                  P.job[job].c0, bit, (const u64 *)P.bk, P.n, P.mu, lds, L, WAVE_UNIFORM(wave),
-                  [] { __syncthreads(); });
-}
-
 // Smallest batches (k = 1): the half-ring team, EIGHT waves per bit -- k_bootstrap_team8 lives in kernels_team8.hip, a
 // translation unit of its own because it is the one kernel that gains from the back end's max-ilp scheduling strategy
 // (its reducer waves run alone on their SIMDs; NOTES.md round 3: -3 %, every other kernel loses with that flag).
 hipError_t team8_init();
 hipError_t launch_team8(const BrLaunch &P, hipStream_t stream);
 
-// Small-batch variant for tlwe_mask_size = 2: a team of 3 waves per bit (blind_rotate.h, brtk_*).
-// LDS: tables | ACC 12 KiB | bara 1 KiB | partial sums 72 KiB | 3 exchange buffers
-#define TEAM2_LDS_BYTES (TABLE_LDS_BYTES + 3 * 1024 * 4 + WAVE_BARA_BYTES + BRTK_PART_ELEMS(2) * 8 + 3 * WAVE_XBUF_BYTES)
-__global__ __launch_bounds__(64 * 3, 1) void k_bootstrap_team_k2(BrLaunch P)
-{
-    load_tables((const u64 *)P.tw_a, (const u64 *)P.tw_b);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long gbit = blockIdx.x;
-    const int job = gbit >= P.bits_per_job ? 1 : 0;
-    const long bit = gbit - (job ? P.bits_per_job : 0);
-    unsigned char *base = g_smem + TABLE_LDS_BYTES;
-    BrTeamLds lds;
-    lds.acc = (i32 *)base;
-    lds.bara = (uint16_t *)(base + 3 * 1024 * 4);
-    lds.part = (u64 *)(base + 3 * 1024 * 4 + WAVE_BARA_BYTES);
-    lds.xbuf = (u64 *)(base + 3 * 1024 * 4 + WAVE_BARA_BYTES + BRTK_PART_ELEMS(2) * 8 + wave * WAVE_XBUF_BYTES);
-    lds.tw1x = (const u64 *)g_smem;
-    lds.tw1i = (const u64 *)g_smem + 1024;
-    const NttLane L = ntt_lane_init(lane);
-    brtk_bootstrap<2>(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, P.job[job].s0, P.job[job].s1,
-                      P.job[job].c0, bit, (const u64 *)P.bk, P.n, P.mu, lds, L, WAVE_UNIFORM(wave),
-                      [] { __syncthreads(); });
-}
+// The lone-wave team kernels k_bootstrap_team (k = 1, 4 waves per bit) and k_bootstrap_team_k2 (k = 2, 3 waves per bit) live
+// in kernels_team.hip: built with the carry-free form of the 64 x 64 product (ff.h, FF_MULWIDE_PLAIN) -- one wave per
+// SIMD is bound by dependent-instruction latency, where the shorter chain wins (round 4: k = 2 team 9.90 -> 9.62 ms).
+hipError_t team_init();
+hipError_t launch_team(const BrLaunch &P, hipStream_t stream);
+hipError_t launch_team_k2(const BrLaunch &P, hipStream_t stream);
 
 // Test hook / multi-kernel-style entry: blind rotate (or a single external product) on
 // accumulators held in global memory: accum int32 [batch][2][1024]
@@ -1303,9 +1262,7 @@ hipError_t kernels_init_device(int *num_cus)
     if (e != hipSuccess) return e;
     e = team8_init();
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void *)k_bootstrap_team, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAM_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void *)k_bootstrap_team_k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAM2_LDS_BYTES);
+    e = team_init();
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)brp_lds_bytes(BRP_MAX_PAIRS));
     if (e != hipSuccess) return e;
@@ -1389,7 +1346,8 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, lon
         if (e8 != hipSuccess) return e8;
     } else if (transform == 0 && mask_size == 1 && P.nbits_total <= team_max_bits) {
         // small batch: 4 waves per bit, one bit per CU at a time
-        hipLaunchKernelGGL(k_bootstrap_team, dim3((unsigned)P.nbits_total), dim3(64 * BRT_WAVES), TEAM_LDS_BYTES, stream, P);
+        hipError_t e4 = launch_team(P, stream);
+        if (e4 != hipSuccess) return e4;
     } else if (transform == 0 && mask_size == 1 && P.nbits_total <= pair_max_bits) {
         // medium batch: 2 waves per bit; as few pairs per work-group as still give one round
         long pairs = (P.nbits_total + num_cus - 1) / num_cus;
@@ -1415,7 +1373,8 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, lon
         hipLaunchKernelGGL(k_bootstrap<1>, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), br_lds_bytes(1, w), stream, P);
     } else if (transform == 0 && mask_size == 2 && P.nbits_total <= team_max_bits) {
         // small batch, k = 2: 3 waves per bit (one team per CU at a time)
-        hipLaunchKernelGGL(k_bootstrap_team_k2, dim3((unsigned)P.nbits_total), dim3(64 * 3), TEAM2_LDS_BYTES, stream, P);
+        hipError_t e3 = launch_team_k2(P, stream);
+        if (e3 != hipSuccess) return e3;
     } else if (transform == 0 && mask_size == 2 && pair_max_bits > 0) {
         // k = 2 beyond the team kernel: 3 waves per bit without the partial-sum buffer, 2 teams per work-group: rounds of
         // 2 x CUs bits in 12.3 ms (the wave kernels below: 4 x CUs in 27 ms / 6 x CUs in 43 ms); any non-zero pair limit

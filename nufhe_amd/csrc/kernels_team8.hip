@@ -3,7 +3,9 @@
 // `-mllvm -amdgpu-sched-strategy=max-ilp` (Makefile).  In its inverse phase four waves run alone on their SIMDs, where an
 // instruction that reads the result of the one before it costs 8 cycles instead of 4; scheduling for instruction-level
 // parallelism is worth -3 % there (NOTES.md round 3: 4.79 -> 4.65 ms per gate), while the kernels that run two paced waves
-// per SIMD lose 1.5-3 % with the same flag -- hence the separate unit.
+// per SIMD lose 1.5-3 % with the same flag -- hence the separate unit.  For the same reason this unit is built with
+// -DFF_MULWIDE_PLAIN: the carry-out form of the 64 x 64 product (ff.h, round 4) has fewer instructions but a longer
+// dependent chain with an SGPR hop; the wave kernels gain 2.5 % from it, this kernel loses 3.5 % (4.60 -> 4.76 ms).
 #include <hip/hip_runtime.h>
 
 #include "blind_rotate.h"

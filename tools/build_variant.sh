@@ -9,8 +9,10 @@ cd "$ROOT/nufhe_amd/csrc"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-pass-failed -Wno-unused-value $@"
 /opt/rocm/bin/hipcc $FLAGS -c kernels.hip -o "$ROOT/gpurun_variants/obj_$NAME/kernels.o" &
 /opt/rocm/bin/hipcc $FLAGS -c api.hip -o "$ROOT/gpurun_variants/obj_$NAME/api.o" &
-/opt/rocm/bin/hipcc $FLAGS ${TEAM8_FLAGS--mllvm -amdgpu-sched-strategy=max-ilp} -c kernels_team8.hip -o "$ROOT/gpurun_variants/obj_$NAME/kernels_team8.o" &
+/opt/rocm/bin/hipcc $FLAGS ${TEAM8_FLAGS--mllvm -amdgpu-sched-strategy=max-ilp -DFF_MULWIDE_PLAIN} -c kernels_team8.hip -o "$ROOT/gpurun_variants/obj_$NAME/kernels_team8.o" &
+/opt/rocm/bin/hipcc $FLAGS ${TEAM_FLAGS--DFF_MULWIDE_PLAIN} -c kernels_team.hip -o "$ROOT/gpurun_variants/obj_$NAME/kernels_team.o" &
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/gpurun_variants/libnufhe_hip_$NAME.so" \
-    "$ROOT/gpurun_variants/obj_$NAME/kernels.o" "$ROOT/gpurun_variants/obj_$NAME/kernels_team8.o" "$ROOT/gpurun_variants/obj_$NAME/api.o"
+    "$ROOT/gpurun_variants/obj_$NAME/kernels.o" "$ROOT/gpurun_variants/obj_$NAME/kernels_team8.o" \
+    "$ROOT/gpurun_variants/obj_$NAME/kernels_team.o" "$ROOT/gpurun_variants/obj_$NAME/api.o"
 ls -la "$ROOT/gpurun_variants/libnufhe_hip_$NAME.so"
