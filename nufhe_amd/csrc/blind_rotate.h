@@ -73,8 +73,12 @@ FF_FN void br_pace(const BrPace &p, u32 done)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (p.mine == nullptr) return;
-    *(volatile u32 *)p.mine = done;
-    const u32 o = WAVE_UNIFORM(*(const volatile u32 *)p.other);
+    // the pacing words live in LDS: address-space-3 accesses (ds_write_b32 / ds_read_b32, one lgkmcnt wait).  Through
+    // generic volatile pointers the compiler emitted flat_store / flat_load with system-scope cache flags and a
+    // `s_waitcnt vmcnt(0)` after each -- two serialised round trips at the top of every iteration (round 4).
+    typedef __attribute__((address_space(3))) volatile u32 lds_vu32;
+    *(lds_vu32 *)p.mine = done;
+    const u32 o = WAVE_UNIFORM(*(lds_vu32 *)p.other);
     if (done > o) __builtin_amdgcn_s_setprio(0);
     else __builtin_amdgcn_s_setprio(2);
 #else
@@ -86,7 +90,8 @@ FF_FN void br_pace_done(const BrPace &p)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (p.mine == nullptr) return;
-    *(volatile u32 *)p.mine = 0xFFFFFFFFu;
+    typedef __attribute__((address_space(3))) volatile u32 lds_vu32;
+    *(lds_vu32 *)p.mine = 0xFFFFFFFFu;
     __builtin_amdgcn_s_setprio(0);
 #else
     (void)p;
@@ -376,13 +381,14 @@ FF_FN void br_step(u32 a, const u64 *row, const BrLds &lds, const NttLane &L BR_
     br_external_product<K>(
         [&](int m, u32 (&T)[16]) {
             // T = (X^a - 1) ACC_m  (polynomials_cpu.py:46-58 with minus_one)
+            const u32 base = (u32)lane - a;                      // (mod 2^32; only bits 0..10 are used)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const u32 j = (u32)(lane + 64 * r);
-                const u32 t = (j - a) & 2047u;
+                const u32 t = base + 64u * (u32)r;               // source coefficient in bits 0..9; bit 10: it comes back negated
                 const u32 v = (u32)lds.acc[m * 1024 + (t & 1023u)];
-                const u32 self = (u32)lds.acc[m * 1024 + j];
-                T[r] = ((t & 1024u) ? 0u - v : v) - self;
+                const u32 self = (u32)lds.acc[m * 1024 + lane + 64 * r];
+                const u32 sm = (u32)((i32)(t << 21) >> 31);      // 0 or 0xFFFFFFFF from bit 10 (one v_bfe_i32)
+                T[r] = ((v ^ sm) - sm) - self;                   // 6 instructions per coefficient instead of 9 (round 4)
             }
         },
         [&](int mo, int r, u32 v) { lds.acc[mo * 1024 + lane + 64 * r] += (i32)v; }, row, lds, L BR_PROBE_PASS);
