@@ -398,22 +398,22 @@ def main():
     t0 = time.perf_counter()
     last = 0
     for _ in range(args.steps):
-        last = step()
-        if True:
-            # HIP-event timing of the kernels of this step (events recorded on the launch stream), on EVERY rank so
-            # that all ranks are timed under the same conditions (the read-back synchronises on the step's events)
-            a = ctypes.c_float(); b = ctypes.c_float()
-            _lib.check(lib.nufhe_profile_last(thr.handle, ctypes.byref(a), ctypes.byref(b)))
-            br_ms.append(a.value); ks_ms.append(b.value)
-            g = ctypes.c_double(); w = ctypes.c_double()
-            if lib.nufhe_profile_clock(thr.handle, ctypes.byref(g), ctypes.byref(w)) == 0:
-                clock_ghz.append(g.value); wave_ms.append(w.value)
+        last = step()               # nothing in the loop waits for the device: the library records HIP events around the
+                                    # kernels of every gate (on the launch stream) and keeps them (nufhe_profile_history)
     drain()                                         # every gather of the timed steps completes inside the timed region
     torch.cuda.synchronize()
     own_elapsed = time.perf_counter() - t0          # this rank alone (a straggler shows up here)
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    # HIP-event durations of the bootstrap kernel / the keyswitch stage of EVERY timed step, read after the timed region
+    hist_n = min(args.steps, 256)
+    hist_br = (ctypes.c_float * hist_n)(); hist_ks = (ctypes.c_float * hist_n)(); got = ctypes.c_int(0)
+    _lib.check(lib.nufhe_profile_history(thr.handle, hist_br, hist_ks, hist_n, ctypes.byref(got)))
+    br_ms = [hist_br[i] for i in range(got.value)]; ks_ms = [hist_ks[i] for i in range(got.value)]
+    g = ctypes.c_double(); w = ctypes.c_double()
+    if lib.nufhe_profile_clock(thr.handle, ctypes.byref(g), ctypes.byref(w)) == 0:      # in-kernel clock of the last step
+        clock_ghz.append(g.value); wave_ms.append(w.value)
     per_rank_ms = [1e3 * own_elapsed / args.steps]
     if use_dist:
         dev = thr.device if dist.get_backend() == "nccl" else "cpu"

@@ -272,6 +272,10 @@ int nufhe_ctx_set_keyswitch_mfma(nufhe_ctx *ctx, int mode);
  * context's stream (milliseconds; blind-rotate kernel and keyswitch kernels separately) ---- */
 int nufhe_profile_enable(nufhe_ctx *ctx, int enable);
 int nufhe_profile_last(nufhe_ctx *ctx, float *blind_rotate_ms, float *keyswitch_ms);
+/* The same two durations for EVERY gate profiled since nufhe_profile_enable / the previous call (the most recent
+ * `capacity` of at most 256, oldest first), read in one go: a timed loop records events and never waits on one.
+ * Synchronises on the last gate's end event; resets the history. */
+int nufhe_profile_history(nufhe_ctx *ctx, float *blind_rotate_ms, float *keyswitch_ms, int capacity, int *count);
 /* Sustained shader clock of the last profiled bootstrap launch, measured inside the kernel: one wavefront of the
  * wave-per-bit kernel reads the shader-clock counter and the constant 100 MHz counter around its blind rotation;
  * *shader_ghz = their ratio, *wave_ms = how long that wavefront ran (the kernel runs ceil(bits / (8 x CUs)) such

@@ -90,6 +90,7 @@ PROTOTYPES = {
     "nufhe_tlwe_encrypt_zero": [_vp, _vp, _vp, _vp, _vp, _long, _int],
     "nufhe_profile_enable": [_vp, _int],
     "nufhe_profile_last": [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)],
+    "nufhe_profile_history": [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _int, ctypes.POINTER(_int)],
     "nufhe_profile_clock": [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],
     "nufhe_profile_waves": [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                             ctypes.POINTER(_int), _int, ctypes.POINTER(_int)],

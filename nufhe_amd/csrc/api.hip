@@ -43,6 +43,8 @@ struct Scratch {
 
 }  // namespace
 
+#define PROFILE_RING 256
+
 struct nufhe_ctx {
     int device = 0;
     int num_cus = 256;         // of this context's device
@@ -61,8 +63,12 @@ struct nufhe_ctx {
     long pair_max_bits = -1;   // above that and up to this size: the 2-waves-per-bit kernel; -1 = 4 x CUs
     int ks_mfma = 1;           // keyswitch on the matrix cores (k_keyswitch_mfma): 0 never, 1 batches > 2 x CUs bits, 2 always
     bool profile = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // [0..2]: begin / after bootstrap / end of the LAST profiled gate
     bool ev_valid = false;
+    // history of the profiled gates since the last nufhe_profile_history: PROFILE_RING event triples, so that a timed loop
+    // never has to synchronise on an event in order to keep its kernel timings (created on first use)
+    std::vector<hipEvent_t> ring;
+    long ring_count = 0;
 };
 
 struct nufhe_cloudkey {
@@ -138,6 +144,19 @@ int check_key(nufhe_ctx *ctx, nufhe_cloudkey *key, bool need_bk, bool need_ks)
     if (key->ctx != ctx) return fail(NUFHE_EINVAL, "cloud key belongs to a different context");
     if (need_bk && !key->d_bk) return fail(NUFHE_ENOKEY, "bootstrapping key not uploaded");
     if (need_ks && !key->d_ks_a3) return fail(NUFHE_ENOKEY, "keyswitch key not uploaded");
+    return NUFHE_OK;
+}
+
+// the three events of the gate about to be profiled: a fresh slot of the history ring (ev[0..2] alias the last one)
+int profile_slot(nufhe_ctx *ctx)
+{
+    if (ctx->ring.empty()) {
+        ctx->ring.resize(3 * PROFILE_RING, nullptr);
+        for (auto &e : ctx->ring) HIP_TRY(hipEventCreate(&e));
+    }
+    const long slot = ctx->ring_count % PROFILE_RING;
+    ctx->ring_count++;
+    for (int k = 0; k < 3; k++) ctx->ev[k] = ctx->ring[3 * slot + k];
     return NUFHE_OK;
 }
 
@@ -265,7 +284,7 @@ int nufhe_ctx_create(int device, void *stream, int own_stream, nufhe_ctx **out)
     if (e == hipSuccess) e = hipMemcpy(ctx->d_ftw1, g1.data(), FFT_TW1_ELEMS * sizeof(cplx), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ctx->d_ftw2, g2.data(), FFT_TW2_ELEMS * sizeof(cplx), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = kernels_init_device(&ctx->num_cus);
-    for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipEventCreate(&ctx->ev[k]);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev[3]);      // nufhe_gather; ev[0..2] alias slots of the profile ring
     if (e != hipSuccess) {
         nufhe_ctx_destroy(ctx);
         return fail(NUFHE_EHIP, "context setup: %s", hipGetErrorString(e));
@@ -290,8 +309,9 @@ int nufhe_ctx_destroy(nufhe_ctx *ctx)
     if (ctx->ext_b.ptr) hipFree(ctx->ext_b.ptr);
     if (ctx->ks_acc.ptr) hipFree(ctx->ks_acc.ptr);
     if (ctx->ks_digits.ptr) hipFree(ctx->ks_digits.ptr);
-    for (int k = 0; k < 4; k++)
-        if (ctx->ev[k]) hipEventDestroy(ctx->ev[k]);
+    if (ctx->ev[3]) hipEventDestroy(ctx->ev[3]);
+    for (hipEvent_t e : ctx->ring)
+        if (e) hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return NUFHE_OK;
@@ -752,6 +772,8 @@ static int run_gate(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result
         P.out_b = result.b; P.out_b_stride = result.b_stride;
     }
     if (ctx->profile) {
+        int rcp = profile_slot(ctx);
+        if (rcp) return rcp;
         HIP_TRY(hipMemsetAsync(ctx->d_clock, 0, CLOCK_PROBE_WORDS * sizeof(unsigned long long), ctx->stream));
         HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
     }
@@ -796,8 +818,12 @@ int nufhe_keyswitch(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe
         (rc = check_lwe(result, key->n, "keyswitch result", true, nbits, true)))
         return rc;
     if (nbits == 0) return NUFHE_OK;
-    if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-    if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+    if (ctx->profile) {
+        int rcp = profile_slot(ctx);
+        if (rcp) return rcp;
+        HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+        HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+    }
     rc = run_keyswitch(ctx, key, result, src.a, src.a_stride, src.b, src.b_stride, nullptr, 0, nullptr, 0, 0, nbits);
     if (rc) return rc;
     if (ctx->profile) {
@@ -1067,6 +1093,25 @@ int nufhe_profile_enable(nufhe_ctx *ctx, int enable)
     if (!ctx) return fail(NUFHE_EINVAL, "null context");
     ctx->profile = enable != 0;
     ctx->ev_valid = false;
+    ctx->ring_count = 0;
+    return NUFHE_OK;
+}
+
+int nufhe_profile_history(nufhe_ctx *ctx, float *blind_rotate_ms, float *keyswitch_ms, int capacity, int *count)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!count || capacity < 0 || (capacity > 0 && (!blind_rotate_ms || !keyswitch_ms))) return fail(NUFHE_EINVAL, "null argument");
+    const long have = ctx->ring_count < PROFILE_RING ? ctx->ring_count : PROFILE_RING;
+    const long n = have < capacity ? have : capacity;
+    if (have > 0) HIP_TRY(hipEventSynchronize(ctx->ev[2]));          // the last gate's end: everything before it is complete
+    for (long i = 0; i < n; i++) {
+        const long slot = (ctx->ring_count - n + i) % PROFILE_RING;      // the n most recent, oldest first
+        HIP_TRY(hipEventElapsedTime(&blind_rotate_ms[i], ctx->ring[3 * slot], ctx->ring[3 * slot + 1]));
+        HIP_TRY(hipEventElapsedTime(&keyswitch_ms[i], ctx->ring[3 * slot + 1], ctx->ring[3 * slot + 2]));
+    }
+    *count = (int)n;
+    ctx->ring_count = 0;
     return NUFHE_OK;
 }
 

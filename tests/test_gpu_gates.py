@@ -383,6 +383,23 @@ def test_profile_clock_of_the_wave_kernel(env, orc):
         assert 0.5 * br.value < wave.value <= br.value
         vm.gate_nand(ds[0][:16], ds[1][:16])
         assert lib.nufhe_profile_clock(thr.handle, ctypes.byref(ghz), ctypes.byref(wave)) != 0
+        # nufhe_profile_history: the durations of EVERY gate since the last read, oldest first, without a wait per gate
+        lib.nufhe_profile_enable(thr.handle, 1)
+        sizes = (B, 16, B, 300)
+        for n in sizes:
+            vm.gate_nand(ds[0][:n], ds[1][:n])                       # nothing synchronises between these
+        hb = (ctypes.c_float * 8)(); hk = (ctypes.c_float * 8)(); got = ctypes.c_int(-1)
+        _lib.check(lib.nufhe_profile_history(thr.handle, hb, hk, 8, ctypes.byref(got)))
+        assert got.value == 4 and all(hb[i] > 0 and hk[i] > 0 for i in range(4))
+        assert hb[0] > 2 * hb[1] and hb[2] > 2 * hb[1] and abs(hb[0] - hb[2]) < 0.1 * hb[0]     # big, small, big
+        _lib.check(lib.nufhe_profile_last(thr.handle, ctypes.byref(br), ctypes.byref(ks)))
+        assert br.value == hb[3]                                      # "last" is the newest entry of the history
+        _lib.check(lib.nufhe_profile_history(thr.handle, hb, hk, 8, ctypes.byref(got)))
+        assert got.value == 0                                         # reading resets it
+        for _ in range(3):
+            vm.gate_nand(ds[0][:16], ds[1][:16])
+        _lib.check(lib.nufhe_profile_history(thr.handle, hb, hk, 2, ctypes.byref(got)))
+        assert got.value == 2                                         # capacity-limited: the two most recent
     finally:
         lib.nufhe_profile_enable(thr.handle, 0)
 
