@@ -130,6 +130,9 @@ FF_FN u32 br_prologue(const BrSource &s0, const BrSource &s1, i32 c0, long bit, 
 template <int DIGIT>
 FF_FN i32 br_digit(u32 t)
 {
+    // the top digit in two instructions: the 2^31 of the offset flips the top bit of the top field, which is what
+    // "mask, then subtract 512" undoes -- (t + 2^21) >> 22 arithmetically is the same number
+    if constexpr (DIGIT == 0) return (i32)(t + (TGSW_OFFSET - 0x80000000u)) >> 22;
     const i32 x = (i32)(t + TGSW_OFFSET);
     return ((x >> (32 - 10 * (DIGIT + 1))) & 1023) - 512;
 }

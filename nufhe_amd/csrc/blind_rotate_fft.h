@@ -33,6 +33,13 @@ struct BrFftLds {
     BrPace pace;         // blind_rotate.h
 };
 
+// nothing moves across (instruction scheduling): used to issue a batch of LDS reads before the first use
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BRF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define BRF_SCHED_FENCE() ((void)0)
+#endif
+
 // LDS slot of parked value j (0 .. BRF_PARK-1) of this lane
 FF_FN u32 *brf_park_slot(const BrFftLds &lds, int j, int lane)
 {
@@ -113,15 +120,14 @@ FF_FN void brf_mac_pair(cplx (&sum)[2][8], const cplx (&x)[2][8], const cplx *ro
     }
 }
 
-// res[mo][r] = coefficient lane + 64 r of  sum_{m,d} digit_d(T_m) (*) BK_row[m][d][mo];
+// sum[mo][r] = (a_{lane + 64 r}, -a_{lane + 64 r + 512}) BEFORE rounding of  sum_{m,d} digit_d(T_m) (*) BK_row[m][d][mo];
 // T[m][r] = coefficient lane + 64 r of input polynomial m.  The two digit polynomials of each m are
 // transformed together, and so are the two output polynomials (fft_*_n<2>).
 template <class TW2>
-FF_FN void brf_external_product(u32 (&res)[2][16], const u32 (&T)[2][16], const cplx *row, const BrFftLds &lds,
-                                const TW2 &tw2, const FftLane &L BR_PROBE_ARG)
+FF_FN void brf_external_product_sums(cplx (&sum)[2][8], const u32 (&T)[2][16], const cplx *row, const BrFftLds &lds,
+                                     const TW2 &tw2, const FftLane &L BR_PROBE_ARG)
 {
     cplx *const bufs[2] = {lds.xbufA, lds.xbufB};
-    cplx sum[2][8];
 #pragma unroll
     for (int r = 0; r < 8; r++) { sum[0][r] = cplx{0.0, 0.0}; sum[1][r] = cplx{0.0, 0.0}; }
 #pragma unroll
@@ -141,14 +147,23 @@ FF_FN void brf_external_product(u32 (&res)[2][16], const u32 (&T)[2][16], const 
 #endif
         BR_PROBE_MARK(2 * m + 1);
     }
-    fft_inverse_2s(sum, bufs, lds.tw1, tw2, L);
+    fft_inverse_2s<true>(sum, bufs, lds.tw1, tw2, L);
     BR_PROBE_MARK(4);
+}
+
+// res[mo][r] = coefficient lane + 64 r of  sum_{m,d} digit_d(T_m) (*) BK_row[m][d][mo]  (tgsw_cpu.py:82-106)
+template <class TW2>
+FF_FN void brf_external_product(u32 (&res)[2][16], const u32 (&T)[2][16], const cplx *row, const BrFftLds &lds,
+                                const TW2 &tw2, const FftLane &L BR_PROBE_ARG)
+{
+    cplx sum[2][8];
+    brf_external_product_sums(sum, T, row, lds, tw2, L BR_PROBE_PASS);
 #pragma unroll
     for (int mo = 0; mo < 2; mo++)
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             res[mo][r] = fft_round_to_u32(sum[mo][r].re);
-            res[mo][r + 8] = fft_round_to_u32(-sum[mo][r].im);
+            res[mo][r + 8] = fft_round_to_u32(sum[mo][r].im);
         }
 }
 
@@ -174,33 +189,47 @@ FF_FN void brf_step(u32 (&acc)[2][16], u32 a, const cplx *row, const BrFftLds &l
     BR_PROBE_BEGIN();
     const int lane = L.lane;
     i32 *mirror = brf_acc_mirror(lds);
+    // (X^a - 1) ACC, polynomials_cpu.py:46-58: coefficient j comes from j - a mod 2048, negated when that wraps (bit 10).
+    // All 16 paired reads are issued before the first one is used (left alone the compiler waits for each in turn:
+    // 16 LDS round trips in a row); sign mask s = 0 / -1: +-v - acc = (v ^ s) + (-s - acc), one v_xad_u32.
+    const u32 base = (u32)lane - a;
+    u32 V[2][16], sm[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const u32 t = base + 64u * (u32)r;
+        V[0][r] = (u32)mirror[t & 1023u];
+        V[1][r] = (u32)mirror[1024 + (t & 1023u)];
+        sm[r] = (u32)((i32)(t << 21) >> 31);
+    }
+    BRF_SCHED_FENCE();
     u32 T[2][16];
 #pragma unroll
-    for (int m = 0; m < 2; m++)
+    for (int r = 0; r < 16; r++) {
+        const u32 nsm = 0u - sm[r];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const u32 j = (u32)(lane + 64 * r);
-            const u32 t = (j - a) & 2047u;
-            const u32 v = (u32)mirror[m * 1024 + (t & 1023u)];
-            T[m][r] = ((t & 1024u) ? 0u - v : v) - acc[m][r];     // polynomials_cpu.py:46-58
-        }
+        for (int m = 0; m < 2; m++) T[m][r] = (V[m][r] ^ sm[r]) + (nsm - acc[m][r]);
+    }
     WAVE_SYNC();    // every lane has read the mirror before buffer B is reused for exchanges
     // park BRF_PARK accumulator words in LDS for the duration of the product (they are only needed
     // again for the update below)
 #pragma unroll
     for (int r = 0; r < BRF_PARK; r++) *brf_park_slot(lds, r, lane) = acc[0][r];
-    u32 res[2][16];
+    cplx sum[2][8];
     BR_PROBE_MARK(5);
-    brf_external_product(res, T, row, lds, tw2, L BR_PROBE_PASS);
+    brf_external_product_sums(sum, T, row, lds, tw2, L BR_PROBE_PASS);
 #pragma unroll
     for (int r = 0; r < BRF_PARK; r++) acc[0][r] = *brf_park_slot(lds, r, lane);
 #pragma unroll
     for (int mo = 0; mo < 2; mo++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            acc[mo][r] += res[mo][r];
-            mirror[mo * 1024 + lane + 64 * r] = (i32)acc[mo][r];
+        for (int r = 0; r < 8; r++) {
+            acc[mo][r] = fft_round_add_u32(acc[mo][r], sum[mo][r].re);           // rounding and accumulation in one
+            acc[mo][r + 8] = fft_round_add_u32(acc[mo][r + 8], sum[mo][r].im);   // (imaginary parts arrive negated)
         }
+#pragma unroll
+    for (int mo = 0; mo < 2; mo++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) mirror[mo * 1024 + lane + 64 * r] = (i32)acc[mo][r];
     WAVE_SYNC();
     BR_PROBE_MARK(6);
 }

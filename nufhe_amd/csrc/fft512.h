@@ -42,6 +42,7 @@ FF_FN cplx c_add(cplx a, cplx b) { return cplx{a.re + b.re, a.im + b.im}; }
 FF_FN cplx c_sub(cplx a, cplx b) { return cplx{a.re - b.re, a.im - b.im}; }
 FF_FN cplx c_mul(cplx a, cplx b) { return cplx{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 FF_FN cplx c_mul_conj(cplx a, cplx b) { return cplx{a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im}; }  // a * conj(b)
+FF_FN cplx c_mul_conj_negim(cplx a, cplx b) { return cplx{a.re * b.re + a.im * b.im, a.re * b.im - a.im * b.re}; }  // conj(a * conj(b))
 // acc += a * b as four fused multiply-adds chained through the accumulator.  Written out because the compiler may
 // contract a * b - c * d into mul + fma but may not re-associate the sum with the accumulator: `acc += a * b` compiles
 // to mul, fma, add per component (6 instructions per complex term instead of 4; round 4: 414 -> 286 in the product
@@ -304,7 +305,9 @@ FF_FN void fft_inverse_n(cplx (&x)[NX][8], cplx *const (&xbuf)[NX], const cplx *
 #define FFT_PIN() ((void)0)
 #endif
 
-template <class TW2>
+// NEGIM: the imaginary parts come out negated (what the coefficient layout wants: a_{j+512} = -Im y_j) -- the sign moves
+// into the operands of the last multiplication instead of costing the rounding an integer instruction per value.
+template <bool NEGIM = false, class TW2>
 FF_FN void fft_inverse_2s(cplx (&x)[2][8], cplx *const (&xbuf)[2], const cplx *tw1, const TW2 &tw2, const FftLane &L)
 {
     auto p3_write = [&](int t) {
@@ -338,9 +341,12 @@ FF_FN void fft_inverse_2s(cplx (&x)[2][8], cplx *const (&xbuf)[2], const cplx *t
         cplx y[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) y[br3(i)] = x[t][i];
-        x[t][0] = cplx{y[0].re * sc, y[0].im * sc};
+        x[t][0] = cplx{y[0].re * sc, y[0].im * (NEGIM ? -sc : sc)};
 #pragma unroll
-        for (int j = 1; j < 8; j++) x[t][j] = c_mul_conj(y[j], cplx{FFT_G_RE(j) * sc, FFT_G_IM(j) * sc});
+        for (int j = 1; j < 8; j++) {
+            const cplx g = cplx{FFT_G_RE(j) * sc, FFT_G_IM(j) * sc};
+            x[t][j] = NEGIM ? c_mul_conj_negim(y[j], g) : c_mul_conj(y[j], g);
+        }
     };
     p3_write(0);
     WAVE_SYNC();
@@ -406,6 +412,32 @@ FF_FN u32 fft_round_to_u32(double v)
     const u32 r = (u32)c.u;
     const u32 m = (u32)((i32)(u32)(s.u >> 32) >> 31);     // 0 or 0xFFFFFFFF
     return (r ^ m) - m;
+}
+
+// acc + round(v) modulo 2^32: the same rounding with the sign fix folded into the accumulation --
+// (r ^ m) - m + acc = (r ^ m) + (acc - m), one subtraction and one v_xad_u32 after the sign mask.
+FF_FN u32 fft_round_add_u32(u32 acc, double v)
+{
+#if defined(NUFHE_EMU)
+    return acc + fft_round_to_u32(v);
+#else
+    const double magic = 4503599627370496.0;   // 2^52
+    union { double d; u64 u; } c, s;
+    c.d = fabs(v) + magic;
+    s.d = v;
+    const u32 r = (u32)c.u;
+    const u32 m = (u32)((i32)(u32)(s.u >> 32) >> 31);     // 0 or 0xFFFFFFFF
+#if defined(__HIP_DEVICE_COMPILE__)
+    // written out: left alone the compiler turns acc - m into acc + (sign >> 31), a second shift of the same word, and
+    // keeps xor and add apart
+    u32 t, d;
+    asm("v_sub_u32 %0, %1, %2" : "=v"(t) : "v"(acc), "v"(m));
+    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(r), "v"(m), "v"(t));
+    return d;
+#else
+    return (r ^ m) + (acc - m);
+#endif
+#endif
 }
 
 // host-side table construction (w = exp(-i pi / 1024))

@@ -313,6 +313,10 @@ __global__ __launch_bounds__(64 * BR_WAVES_K(K), K == 1 ? 2 : 1) void k_blind_ro
 #define FTABLE_LDS_BYTES ((FFT_TW1_ELEMS + FFT_TW2_ELEMS) * 16)
 #define WAVE_FXBUF_BYTES (FFT_XBUF_ELEMS * 16)
 #define WAVE_BRF_LDS_BYTES (2 * WAVE_FXBUF_BYTES + BRF_PARK_EXTRA_BYTES)   /* acc mirror and bara are aliased: blind_rotate_fft.h */
+#define BRF_BASE_PAD 128   /* tables | pacing words | pad: every per-wave region then starts at a multiple of 256 bytes and the
+                              constant part of the accumulator-mirror addresses folds into the offsets of ds_read2st64_b32 */
+static_assert((FTABLE_LDS_BYTES + BR_PACE_BYTES + BRF_BASE_PAD) % 256 == 0 && WAVE_BRF_LDS_BYTES % 256 == 0 && WAVE_FXBUF_BYTES % 256 == 0,
+              "per-wave LDS regions of k_bootstrap_fft are 256-byte aligned");
 
 __device__ __forceinline__ void load_ftables(const cplx *__restrict__ g_tw1, const cplx *__restrict__ g_tw2)
 {
@@ -325,7 +329,7 @@ __device__ __forceinline__ void load_ftables(const cplx *__restrict__ g_tw1, con
 
 __device__ __forceinline__ BrFftLds carve_brf_lds(int wave)
 {
-    unsigned char *base = g_smem + FTABLE_LDS_BYTES + BR_PACE_BYTES + wave * WAVE_BRF_LDS_BYTES;
+    unsigned char *base = g_smem + FTABLE_LDS_BYTES + BR_PACE_BYTES + BRF_BASE_PAD + wave * WAVE_BRF_LDS_BYTES;
     BrFftLds lds;
     lds.pace.mine = nullptr;
     lds.pace.other = nullptr;
@@ -1218,7 +1222,8 @@ static inline unsigned blocks_for(long n, int per) { return (unsigned)((n + per 
 static constexpr size_t br_lds_bytes(int K, int waves) { return TABLE_LDS_BYTES + BR_PACE_BYTES + (size_t)waves * WAVE_BR_LDS_BYTES_K(K); }
 static constexpr size_t br_lds_bytes(int K) { return br_lds_bytes(K, BR_WAVES_K(K)); }
 static constexpr size_t brp_lds_bytes(int pairs) { return TABLE_LDS_BYTES + BR_PACE_BYTES + (size_t)pairs * PAIR_LDS_BYTES; }
-static constexpr size_t brf_lds_bytes(int waves) { return FTABLE_LDS_BYTES + BR_PACE_BYTES + (size_t)waves * WAVE_BRF_LDS_BYTES; }
+static constexpr size_t brf_lds_bytes(int waves) { return FTABLE_LDS_BYTES + BR_PACE_BYTES + BRF_BASE_PAD + (size_t)waves * WAVE_BRF_LDS_BYTES; }
+static_assert(brf_lds_bytes(BR_WAVES_PER_BLOCK) <= 160 * 1024, "LDS budget of k_bootstrap_fft");
 static const size_t kBrfLds = brf_lds_bytes(BR_WAVES_PER_BLOCK);
 
 // Waves (= bits) per work-group for a batch of nbits: one work-group per CU and `max_waves` waves
