@@ -202,24 +202,62 @@ struct BrProbe { long long t[8]; long long last; };
 #define BR_PROBE_MARK(i)
 #endif
 
+// The key words of one lane: element pair (2 lane, 2 lane + 1) of the 128-element block at `elem` (a compile-time
+// offset in u64 units from a wave-uniform polynomial pointer).  With BR_KEY_BUFFER_LOADS (the translation unit of the
+// one-wave-per-bit kernels) these are buffer loads: the uniform part of the address sits in scalar registers and is added
+// by the scalar unit, the lane contributes one 32-bit offset; a per-lane 64-bit pointer costs a v_add_co / v_addc pair
+// for every 4 KiB the 12-bit immediate offset cannot reach.  `poly` MUST be wave-uniform there.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(BR_KEY_BUFFER_LOADS)
+struct BrKeyStream {
+    __amdgpu_buffer_rsrc_t rsrc;
+    u32 voff;
+};
+FF_FN BrKeyStream br_key_stream(const u64 *poly, int lane, int bytes)
+{
+    BrKeyStream s;
+    s.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)poly, (short)0, bytes, 0x00020000);
+    s.voff = (u32)lane * 16u;
+    return s;
+}
+FF_FN void br_key_load2(u64 &a, u64 &b, const BrKeyStream &s, int elem)
+{
+    typedef u32 br_u32x4 __attribute__((ext_vector_type(4)));
+    const int byte = elem * 8;
+    const br_u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, s.voff + (u32)(byte & 4095), byte & ~4095, 0);
+    a = ((u64)w[1] << 32) | w[0];
+    b = ((u64)w[3] << 32) | w[2];
+}
+#else
+struct BrKeyStream {
+    const u64 *p;
+};
+FF_FN BrKeyStream br_key_stream(const u64 *poly, int lane, int) { return BrKeyStream{poly + lane * 2}; }
+FF_FN void br_key_load2(u64 &a, u64 &b, const BrKeyStream &s, int elem)
+{
+    a = s.p[elem];
+    b = s.p[elem + 1];
+}
+#endif
+
 template <int K, bool FIRST>
 FF_FN void br_mac2(u64 (&sum)[K + 1][16], const u64 (&x0)[16], const u64 (&x1)[16], const u64 *poly, int lane)
 {
-    constexpr int STEPS = 8 * (K + 1), D = BR_KEY_DEPTH;
-    const u64 *p = poly + lane * 2;
-    const u64 *pd = p + (K + 1) * BK_POLY_ELEMS;
+    constexpr int STEPS = 8 * (K + 1), D = BR_KEY_DEPTH, PD = (K + 1) * BK_POLY_ELEMS;
+    const BrKeyStream ks = br_key_stream(poly, lane, 2 * PD * 8);
     auto off = [](int t) { return (t >> 3) * BK_POLY_ELEMS + (t & 7) * 128; };
     u64 q[D + 1][4];                      // ring of pending steps: q[i] belongs to step t + i
 #pragma unroll
     for (int i = 0; i < D; i++) {
-        q[i][0] = p[off(i)]; q[i][1] = p[off(i) + 1]; q[i][2] = pd[off(i)]; q[i][3] = pd[off(i) + 1];
+        br_key_load2(q[i][0], q[i][1], ks, off(i));
+        br_key_load2(q[i][2], q[i][3], ks, PD + off(i));
     }
 #pragma unroll
     for (int t = 0; t < STEPS; t++) {
         const int mo = t >> 3, h = t & 7;
         if (t + D < STEPS) {
             const int o = off(t + D);
-            q[D][0] = p[o]; q[D][1] = p[o + 1]; q[D][2] = pd[o]; q[D][3] = pd[o + 1];
+            br_key_load2(q[D][0], q[D][1], ks, o);
+            br_key_load2(q[D][2], q[D][3], ks, PD + o);
             BR_ISSUE_FENCE();
         }
         sum[mo][2 * h] = ff_dot2<!FIRST>(x0[2 * h], q[0][0], x1[2 * h], q[0][2], sum[mo][2 * h]);
@@ -238,19 +276,20 @@ template <int K>
 FF_FN void br_mac2_l4(L4 (&out)[16], const u64 (&prev)[16], const u64 (&x0)[16], const u64 (&x1)[16],
                       const u64 *poly, int lane)
 {
-    constexpr int D = BR_KEY_DEPTH;
-    const u64 *p = poly + lane * 2;
-    const u64 *pd = p + (K + 1) * BK_POLY_ELEMS;
+    constexpr int D = BR_KEY_DEPTH, PD = (K + 1) * BK_POLY_ELEMS;
+    const BrKeyStream ks = br_key_stream(poly, lane, (PD + BK_POLY_ELEMS) * 8);
     u64 q[D + 1][4];
 #pragma unroll
     for (int i = 0; i < D; i++) {
-        q[i][0] = p[i * 128]; q[i][1] = p[i * 128 + 1]; q[i][2] = pd[i * 128]; q[i][3] = pd[i * 128 + 1];
+        br_key_load2(q[i][0], q[i][1], ks, i * 128);
+        br_key_load2(q[i][2], q[i][3], ks, PD + i * 128);
     }
 #pragma unroll
     for (int h = 0; h < 8; h++) {
         if (h + D < 8) {
             const int o = (h + D) * 128;
-            q[D][0] = p[o]; q[D][1] = p[o + 1]; q[D][2] = pd[o]; q[D][3] = pd[o + 1];
+            br_key_load2(q[D][0], q[D][1], ks, o);
+            br_key_load2(q[D][2], q[D][3], ks, PD + o);
             BR_ISSUE_FENCE();
         }
         l4_dot2<true>(out[2 * h], x0[2 * h], q[0][0], x1[2 * h], q[0][2], prev[2 * h]);

@@ -90,21 +90,38 @@ FF_FN void brf_mac_pair(cplx (&sum)[2][8], const cplx (&x)[2][8], const cplx *ro
 {
     // group g: polynomial (m, d, mo) = g / GROUPS_PER_POLY, registers GROUP * (g % GROUPS_PER_POLY) ...
     constexpr int GPP = 8 / BRF_KEY_GROUP, NG = 4 * GPP;
-    const cplx *base = row + (long)(m * 2) * 2 * BKF_POLY_ELEMS + lane;
-    auto addr = [&](int g, int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // buffer loads: the wave-uniform part of the address (row, polynomial, 4 KiB window) lives in scalar registers and is
+    // added by the scalar unit, the lane contributes a 32-bit offset -- a per-lane 64-bit pointer costs a v_add_co / v_addc
+    // pair for every 4 KiB the 12-bit immediate offset cannot reach (30 VALU instructions per iteration)
+    typedef u32 brf_u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(row + (long)(m * 2) * 2 * BKF_POLY_ELEMS), (short)0, 4 * BKF_POLY_ELEMS * (int)sizeof(cplx), 0x00020000);
+    const u32 voff = (u32)lane * (u32)sizeof(cplx);
+    auto load = [&](int g, int i) {
         const int poly = g / GPP, r = BRF_KEY_GROUP * (g % GPP) + i;    // poly = d * 2 + mo
-        return base + poly * BKF_POLY_ELEMS + r * 64;
+        const int byte = (poly * BKF_POLY_ELEMS + r * 64) * (int)sizeof(cplx);
+        union { brf_u32x4 w; cplx c; } u;
+        u.w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + (u32)(byte & 4095), byte & ~4095, 0);
+        return u.c;
     };
+#else
+    const cplx *base = row + (long)(m * 2) * 2 * BKF_POLY_ELEMS + lane;
+    auto load = [&](int g, int i) {
+        const int poly = g / GPP, r = BRF_KEY_GROUP * (g % GPP) + i;    // poly = d * 2 + mo
+        return base[poly * BKF_POLY_ELEMS + r * 64];
+    };
+#endif
     cplx q[D + 1][BRF_KEY_GROUP];          // ring of pending groups: q[j] belongs to group g + j
 #pragma unroll
     for (int j = 0; j < D; j++)
 #pragma unroll
-        for (int i = 0; i < BRF_KEY_GROUP; i++) q[j][i] = *addr(j, i);
+        for (int i = 0; i < BRF_KEY_GROUP; i++) q[j][i] = load(j, i);
 #pragma unroll
     for (int g = 0; g < NG; g++) {
         if (g + D < NG) {
 #pragma unroll
-            for (int i = 0; i < BRF_KEY_GROUP; i++) q[D][i] = *addr(g + D, i);
+            for (int i = 0; i < BRF_KEY_GROUP; i++) q[D][i] = load(g + D, i);
             BR_ISSUE_FENCE();
         }
         const int d = (g / GPP) >> 1, mo = (g / GPP) & 1;

@@ -3,6 +3,7 @@
 // __global__ wrappers (LDS carving, wave -> bit mapping) and the launch geometry.
 #include <hip/hip_runtime.h>
 
+#define BR_KEY_BUFFER_LOADS 1   /* key words through buffer loads (blind_rotate.h, br_key_stream): every row pointer in this unit is wave-uniform */
 #include "blind_rotate.h"
 #include "ff.h"
 #include "kernels.h"
