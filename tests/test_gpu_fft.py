@@ -187,6 +187,47 @@ def test_fft_external_mul_at_the_largest_reachable_magnitude(thr, H):
     assert numpy.abs(dref).max() <= 4 * FFT_TOLERANCE_LSB
 
 
+def test_fft_blind_rotate_step_at_the_largest_reachable_magnitude(thr, H):
+    """The same edge through the path a gate takes: one blind-rotate STEP (`nufhe_blind_rotate`, one row, bara = 1024 so
+    that (X^a - 1) ACC = -2 ACC) with accumulators chosen so that -2 ACC has the extreme digit patterns above.  The step's
+    rounding is fused with the accumulation (fft_round_add_u32: |v| + 2^52, sign mask, one subtraction and one v_xad_u32 on
+    the device) and the inverse transform hands it the imaginary parts negated -- another instruction sequence than
+    nufhe_external_mul's, which rounds without accumulating -- so it gets its own check where |v| reaches 1.5 x 2^51."""
+    rs = numpy.random.RandomState(78)
+    B = 4
+    lo_t = 0x100000000 - 0x80200000
+    hi_t = (0xFFFFF000 - 0x80200000) & 0xFFFFFFFF
+    T = numpy.empty((B, 2, 1024), numpy.int64)
+    T[0] = lo_t
+    T[1] = hi_t
+    T[2:] = numpy.where(rs.randint(0, 2, size=(2, 2, 1024)).astype(bool), lo_t, hi_t)
+    T += 2 * rs.randint(0, 0x800, size=T.shape)                     # low 12 bits do not reach a digit; T stays even
+    # ACC with -2 ACC = T (mod 2^32): ACC = -(T / 2), plus 2^31 on a random half (both solutions)
+    accum = ((-(T // 2)) + (rs.randint(0, 2, size=T.shape).astype(numpy.int64) << 31)) & 0xFFFFFFFF
+    assert (((-2 * accum) & 0xFFFFFFFF) == (T & 0xFFFFFFFF)).all()
+    tgsw = numpy.empty((1, 2, 2, 2, 1024), numpy.int32)
+    tgsw[:] = -2**31
+    tgsw[0, :, :, 1] = 2**31 - 1
+    tgsw[0, 1, 1, :, ::2] = rs.choice([-2**31, 2**31 - 1], size=(2, 512))
+    exact = _exact_external_mul((T & 0xFFFFFFFF).astype(numpy.uint32).view(numpy.int32), tgsw, 0)
+    assert numpy.abs(exact).max() >= 1.5 * 2**51 and (numpy.abs(exact) >= 2**51).sum() > 1000
+    expect = ((accum + exact) & 0xFFFFFFFF).astype(numpy.uint32)
+
+    from nufhe_amd.bootstrap import NativeCloudKey
+    native = NativeCloudKey(thr, 1, 'FFT')
+    d_tgsw = H.dev(thr, tgsw)
+    call("nufhe_bk_from_coeffs", native.handle, ptr(d_tgsw))
+    acc = H.dev(thr, accum.astype(numpy.uint32).view(numpy.int32).reshape(B, 1, 2, 1024).copy())
+    d_bara = H.dev(thr, numpy.full((B, 1), 1024, numpy.int32))
+    call("nufhe_blind_rotate", thr.handle, native.handle, ptr(acc), ptr(d_bara), 1, 1, B)
+    got = H.host(acc).reshape(B, 2, 1024).view(numpy.uint32)
+    delta = (got.astype(numpy.int64) - expect.astype(numpy.int64) + 2**31) % 2**32 - 2**31
+    big = numpy.abs(exact) >= 2**51
+    print("FFT blind-rotate step at |v| up to 2^%.2f: max |delta| %d LSB overall, %d LSB where |v| >= 2^51 (%d values)"
+          % (numpy.log2(float(numpy.abs(exact).max())), numpy.abs(delta).max(), numpy.abs(delta[big]).max(), int(big.sum())))
+    assert numpy.abs(delta).max() <= FFT_TOLERANCE_LSB
+
+
 @pytest.fixture(scope='module')
 def fft_env(thr, H, orc, oracle_keys):
     import nufhe_amd
