@@ -60,8 +60,10 @@ REGION_END = ('s_cbranch', 's_branch', 's_endpgm', 's_setprio', 's_barrier', 's_
               's_decperflevel', 's_ttrace', 's_icache_inv', 's_dcache', 's_memtime', 's_memrealtime')
 MEM_PREFIX = ('ds_', 'global_', 'flat_', 'scratch_', 'buffer_', 's_load', 's_buffer_load', 's_store', 's_atc')
 
-REG_RE = re.compile(r'\b(?:(v|s|a)(\d+)|(v|s|a)\[(\d+):(\d+)\]|(vcc_lo|vcc_hi|vcc|exec_lo|exec_hi|exec|m0|scc|'
-                    r'flat_scratch_lo|flat_scratch_hi|flat_scratch|xnack_mask))\b')
+# (the closing word boundary must not follow the `]` of a register range: there is none between `]` and `,` -- until
+# round 4 ranges were silently ignored, i.e. the round-3 reorderings missed every dependence through a 64-bit operand)
+REG_RE = re.compile(r'\b(?:(v|s|a)(\d+)\b|(v|s|a)\[(\d+):(\d+)\]|(vcc_lo|vcc_hi|vcc|exec_lo|exec_hi|exec|m0|scc|'
+                    r'flat_scratch_lo|flat_scratch_hi|flat_scratch|xnack_mask)\b)')
 
 
 def regs_of(text):

@@ -15,6 +15,7 @@ $LLVM/clang-offload-bundler -type=o -bundle-align=4096 -targets=host-x86_64-unkn
 cd "$ROOT/nufhe_amd/csrc"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-pass-failed -Wno-unused-value $@"
 /opt/rocm/bin/hipcc $FLAGS --cuda-host-only -Xclang -fcuda-include-gpubinary -Xclang "$OBJ/kernels.hipfb" -c kernels.hip -o "$OBJ/kernels.o"
-[ -f api.o ] || make api.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/gpurun_variants/libnufhe_hip_$NAME.so" "$OBJ/kernels.o" api.o
+make api.o kernels_team8.o kernels_team.o > /dev/null     # the other translation units are the regular ones
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/gpurun_variants/libnufhe_hip_$NAME.so" "$OBJ/kernels.o" \
+    kernels_team8.o kernels_team.o api.o
 ls -la "$ROOT/gpurun_variants/libnufhe_hip_$NAME.so"
