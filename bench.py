@@ -229,17 +229,24 @@ def cpu_baseline_and_parity(gate, sample_bits, cs_host, gpu_out):
     # north_star's other baseline: the reference's OWN Python CPU functions.  They cannot run on the GPU box (the
     # reference is not shipped there), so the figure is the one measured in the build container, carried with its
     # provenance (tools/time_reference_cpu.py -> profiles/reference_python_cpu_timing.json); it was NOT timed in this run
-    ref = _profile_json("reference_python_cpu_timing.json")
-    if ref is not None:
-        mult = 2 if gate == "mux" else 1
-        base["reference_python"] = {
-            "ms_per_bit": ref["extrapolated_ms_per_bit"] * mult,
-            "value": 1000.0 / (ref["extrapolated_ms_per_bit"] * mult), "unit": "gates/s",
-            "cores": ref["cores_used"], "kind": "reference", "measured_in_this_run": False,
-            "where": "build container (%s), 1 core, K<=5 blind-rotate iterations at B=32 x (500/K); %s" % (
-                ref["cpu"], ref["label"]),
-            "source": "profiles/reference_python_cpu_timing.json (tools/time_reference_cpu.py)"}
+    ref_py = reference_python_entry(gate)
+    if ref_py is not None:
+        base["reference_python"] = ref_py
     return base, parity
+
+
+def reference_python_entry(gate):
+    ref = _profile_json("reference_python_cpu_timing.json")
+    if ref is None:
+        return None
+    mult = 2 if gate == "mux" else 1
+    return {
+        "ms_per_bit": ref["extrapolated_ms_per_bit"] * mult,
+        "value": 1000.0 / (ref["extrapolated_ms_per_bit"] * mult), "unit": "gates/s",
+        "cores": ref["cores_used"], "kind": "reference", "measured_in_this_run": False,
+        "where": "build container (%s), 1 core, K<=5 blind-rotate iterations at B=32 x (500/K); %s" % (
+            ref["cpu"], ref["label"]),
+        "source": "profiles/reference_python_cpu_timing.json (tools/time_reference_cpu.py)"}
 
 
 def shard_parity(gate, transform, sample_bits, cs_host, out_host, dist, dev, world):
@@ -253,7 +260,10 @@ def shard_parity(gate, transform, sample_bits, cs_host, out_host, dist, dev, wor
     lwe_key, tlwe_key, ck = orc.make_key_pair(orc.DeterministicRNG(123))
     n = sample_bits
     cs = [tuple(x[:n] for x in c) for c in cs_host]
+    dist.barrier()                  # all ranks start their oracle run together: the host cores are shared evenly
+    t_cpu = time.time()
     ref = orc.gate_mux(ck, cs[0], cs[1], cs[2]) if gate == 'mux' else orc.gate('gate_nand', ck, cs[0], cs[1])
+    t_cpu = time.time() - t_cpu
     da = (out_host[0][:n].astype(numpy.int64) - ref[0].astype(numpy.int64) + 2**31) % 2**32 - 2**31
     db = (out_host[1][:n].astype(numpy.int64) - ref[1].astype(numpy.int64) + 2**31) % 2**32 - 2**31
     sums = torch.tensor([int((da != 0).sum() + (db != 0).sum()), int(da.size + db.size),
@@ -269,7 +279,21 @@ def shard_parity(gate, transform, sample_bits, cs_host, out_host, dist, dev, wor
         entry["max_abs_diff_lsb"] = int(worst.item())
         entry["tolerance_lsb"] = 16
     assert entry["ranks_reporting"] == world
-    return entry
+    # the CPU baseline of an N > 1 line: THIS rank's oracle run (its share of the host cores, the other ranks of the
+    # node running theirs at the same time), scaled to the node: `world` ranks finished `world * n` bits in the
+    # slowest rank's time
+    slowest = torch.tensor([t_cpu], dtype=torch.float64, device=dev)
+    dist.all_reduce(slowest, op=dist.ReduceOp.MAX)
+    dt = float(slowest.item())
+    base = dict(value=world * n / dt, unit="gates/s", cores=orc.num_threads() * local_world, kind="port",
+                sample="first %d bits of EVERY rank's %s shard (%d ranks x %d threads at the same time on this host), full "
+                       "n=500 bootstrap + keyswitch, slowest rank %.1f s" % (n, gate.upper(), world, orc.num_threads(), dt),
+                ms_per_bit=1000.0 * dt / (world * n), threads_per_rank=orc.num_threads(), ranks=world,
+                where="this host, in this run (the C restatement of the reference's *_cpu.py composition, OpenMP over bits)")
+    ref_py = reference_python_entry(gate)
+    if ref_py is not None:
+        base["reference_python"] = ref_py
+    return entry, base
 
 
 def main():
@@ -415,6 +439,7 @@ def main():
     if lib.nufhe_profile_clock(thr.handle, ctypes.byref(g), ctypes.byref(w)) == 0:      # in-kernel clock of the last step
         clock_ghz.append(g.value); wave_ms.append(w.value)
     per_rank_ms = [1e3 * own_elapsed / args.steps]
+    per_rank_kernel = None
     if use_dist:
         dev = thr.device if dist.get_backend() == "nccl" else "cpu"
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -424,6 +449,15 @@ def main():
         every = torch.zeros(world, dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(every, own)
         per_rank_ms = [float(x) for x in every.cpu()]
+        # the dominant kernel on every rank: mean HIP-event duration of its timed launches and its in-kernel clock, so
+        # that a slow GPU shows in the roofline figure (rank 0's kernel is the one `roofline` is computed from)
+        mine = torch.tensor([float(numpy.mean(br_ms)) if br_ms else 0.0, float(numpy.mean(ks_ms)) if ks_ms else 0.0,
+                             clock_ghz[0] if clock_ghz else 0.0], dtype=torch.float64, device=dev)
+        allk = torch.zeros(3 * world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allk, mine)
+        allk = allk.cpu().view(world, 3)
+        per_rank_kernel = {"kernel_ms": [float(x) for x in allk[:, 0]], "keyswitch_ms": [float(x) for x in allk[:, 1]],
+                           "clock_ghz_in_kernel": [float(x) for x in allk[:, 2]]}
 
     # the result gather alone (reported separately; it is also part of every timed step)
     gather_ms = None
@@ -517,7 +551,7 @@ def main():
     dec = ctx.decrypt(secret_key, out)
     expect = numpy.where(ms[0], ms[1], ms[2]) if args.gate == "mux" else ~(ms[0] & ms[1])
     correct = bool((dec == expect).all())
-    multi_parity = None
+    multi_parity = multi_base = None
     if use_dist:
         dev = thr.device if dist.get_backend() == "nccl" else "cpu"
         okt = torch.tensor([1 if correct else 0], dtype=torch.int64, device=dev)
@@ -526,7 +560,7 @@ def main():
         if world > 1 and not args.no_cpu_baseline:
             def host_(ct):
                 return tuple(x.detach().cpu().numpy() for x in (ct.a, ct.b, ct.current_variances))
-            multi_parity = shard_parity(args.gate, args.transform, min(B, args.cpu_sample_bits or 256), [host_(c) for c in cs], host_(out),
+            multi_parity, multi_base = shard_parity(args.gate, args.transform, min(B, args.cpu_sample_bits or 256), [host_(c) for c in cs], host_(out),
                                         dist, dev, world)
 
     if rank == 0:
@@ -593,6 +627,14 @@ def main():
         if live_clock:
             checks["clock_ok"] = bool(live_clock >= 2.2 or args.transform == "FFT" and live_clock >= 2.0)
         roof["self_check"] = checks
+        if per_rank_kernel is not None:
+            km, cg = per_rank_kernel["kernel_ms"], per_rank_kernel["clock_ghz_in_kernel"]
+            per_rank_kernel.update({
+                "kernel_ms_min": min(km), "kernel_ms_max": max(km), "clock_ghz_min": min(cg), "clock_ghz_max": max(cg),
+                "streaming_frac_min": a_kernel / (max(km) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "streaming_frac_max": a_kernel / (min(km) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "one entry per rank, rank order; `roofline` above is rank 0's kernel; the slowest rank sets `value`"})
+            roof["per_rank"] = per_rank_kernel
         result["roofline"] = roof
         result["per_rank_ms_per_step"] = per_rank_ms
         if gather_ms is not None:
@@ -606,6 +648,7 @@ def main():
                                         "gather_ms = the same collective alone, blocking"}
         if multi_parity is not None:
             result["parity"] = multi_parity
+            result["cpu_baseline"] = multi_base
             bad_multi = (multi_parity["differing"] != 0 if args.transform == "NTT"
                          else multi_parity["max_abs_diff_lsb"] > multi_parity["tolerance_lsb"])
             result["correct"] = bool(result["correct"] and not bad_multi)

@@ -42,9 +42,10 @@ typedef struct nufhe_ctx nufhe_ctx;            /* one GPU + one stream; replaces
 typedef struct nufhe_cloudkey nufhe_cloudkey;  /* device copies of BootstrapKey + LweKeyswitchKey */
 
 /* Bumped whenever a struct passed by value or an entry point's signature changes (3: nufhe_lwe gained `size`;
- * 4: output-stride checks, key images).  A binding compares nufhe_abi_version() with the macro of the header it
- * was written against before the first real call (nufhe_amd/_lib.py does). */
-#define NUFHE_ABI_VERSION 4
+ * 4: output-stride checks, key images; 5: key images carry a header, nufhe_gate_batch, nufhe_ctx_pin_scratch).  A
+ * binding compares nufhe_abi_version() with the macro of the header it was written against before the first real
+ * call (nufhe_amd/_lib.py does). */
+#define NUFHE_ABI_VERSION 5
 
 const char *nufhe_last_error(void);
 const char *nufhe_version(void);
@@ -74,7 +75,11 @@ int nufhe_d2h(nufhe_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);   /
  * device of srcs[i] -- lands at d_dst + dst_offsets[i] on the device of `dst`: a peer copy enqueued on the SOURCE
  * context's stream (ordered behind the gate that wrote the slice, no host synchronisation), and dst's stream waits for
  * all of them.  Contexts of one device are allowed (own streams).  One process per GPU gathers over RCCL instead
- * (nufhe_amd/multi_gpu.py); the library itself carries no RCCL dependency. */
+ * (nufhe_amd/multi_gpu.py); the library itself carries no RCCL dependency.
+ * Ordering contract: the copies are ordered BEHIND everything already queued on dst's stream when the call is made (d_dst
+ * may be a recycled block still in use by a kernel on that stream) and dst's stream is ordered behind the copies; work
+ * queued on OTHER streams that touches d_dst is the caller's to order.  The calling thread's current HIP device is the
+ * same after the call as before it. */
 int nufhe_gather(nufhe_ctx *dst, void *d_dst, const size_t *dst_offsets, nufhe_ctx *const *srcs,
                  const void *const *d_srcs, const size_t *bytes, int count);
 
@@ -104,7 +109,10 @@ int nufhe_ks_upload(nufhe_cloudkey *key, const int32_t *h_ks_a, const int32_t *h
  * with a device collective (RCCL broadcast over xGMI; SURVEY 8e "or ncclBroadcast from rank 0" -- the reference ships
  * pickles through the host, examples/multi_gpu.py:86-107), import into a key created with the same (lwe_size, transform,
  * mask_size) on the receiving rank.  export enqueues copies on the stream; import synchronises (it rebuilds the derived
- * layouts).  The image is only meaningful between libraries of the same NUFHE_ABI_VERSION. */
+ * layouts).  The image starts with a 256-byte header (magic, NUFHE_ABI_VERSION, lwe_size, transform, mask_size, byte
+ * count): import returns NUFHE_EINVAL for a buffer that is not an image, comes from another library build or holds a key
+ * of other parameters (NTT and FFT keys have the same size -- the header is what tells them apart).  export synchronises
+ * too (the header is staged from the host). */
 int nufhe_cloudkey_image_bytes(nufhe_cloudkey *key, size_t *bytes);
 int nufhe_cloudkey_export_image(nufhe_cloudkey *key, void *d_image);
 int nufhe_cloudkey_import_image(nufhe_cloudkey *key, const void *d_image);
@@ -164,6 +172,29 @@ int nufhe_gate_binary(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nuf
 /* Fused MUX (gates.py:600-664): a ? b : c */
 int nufhe_gate_mux(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe_lwe a, nufhe_lwe b,
                    nufhe_lwe c, long nbits);
+
+/* Heterogeneous gate batch: a LIST of independent gates -- different kinds, different sizes, different buffers -- as ONE
+ * bootstrap launch (circuit-level fusion; the reference's circuit example is operators_integer.py:64-95,
+ * where each gate is its own chain of launches).  Every gate costs the same 500 dependent blind-rotation steps however
+ * few bits it has, and a launch of up to one bit per CU takes as long as one bit: four independent 64-bit gates finish in
+ * the time of one.  The library (1) writes the linear pre-combination (0, c0) + pa a + pb b of every gate (MUX: its two,
+ * gates.py:639-650) into the rows of one scratch array, (2) bootstraps all rows in one launch of the kernel family the
+ * TOTAL row count selects, (3) adds the two extracted samples of MUX rows (+ (0, mu), gates.py:657-661) and (4) runs one
+ * keyswitch whose finalize step writes every gate's slice to its own result view.  Results are word-for-word those of
+ * the per-gate entry points (int32 wraparound sums are order independent).
+ *   kind NUFHE_JOB_BINARY: result = KS(BS_mu((0, c0) + pa * a + pb * b)); `c` is ignored.
+ *   kind NUFHE_JOB_MUX:    result = a ? b : c; c0 / pa / pb are ignored (the reference's constants are used), mu must be 2^29.
+ * nbits may differ per job (0 allowed).  Jobs must not write a result that another job of the SAME batch reads.  Not
+ * capturable into a hipGraph (the job tables are uploaded from the host per call). */
+#define NUFHE_JOB_BINARY 0
+#define NUFHE_JOB_MUX 1
+typedef struct {
+    int32_t kind;
+    int32_t c0, pa, pb;
+    long nbits;
+    nufhe_lwe result, a, b, c;
+} nufhe_gate_job;
+int nufhe_gate_batch(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_gate_job *jobs, int n_jobs, int32_t mu);
 
 /* Client side.  out[i * out_stride] = base[i * base_stride] + sign * <a[i], key>
  * with int32 wraparound, sign = +1 or -1:
@@ -267,6 +298,14 @@ int nufhe_ctx_set_team8(nufhe_ctx *ctx, int enable);
  * kernel below (it is ahead up to there); 0: never; 2: always.  Both are exact integer sums mod 2^32:
  * identical results. */
 int nufhe_ctx_set_keyswitch_mfma(nufhe_ctx *ctx, int mode);
+
+/* Scratch pinning for captured graphs.  The library's scratch buffers (extracted samples, keyswitch accumulators) grow on
+ * demand; a hipGraph captured from gate calls holds raw pointers into them.  While the pin count is positive a buffer
+ * that has to grow is kept alive (retired) instead of freed, so earlier captures stay valid; the retired buffers are
+ * released when the count returns to zero.  delta = +1 before capturing, -1 when the graph is destroyed
+ * (nufhe_amd/graph.py does both).  A buffer that would have to grow DURING a capture is an error (NUFHE_EINVAL): run the
+ * circuit once eagerly first. */
+int nufhe_ctx_pin_scratch(nufhe_ctx *ctx, int delta);
 
 /* ---- measurement: time of the last fused gate / bootstrap kernels, from HIP events on the
  * context's stream (milliseconds; blind-rotate kernel and keyswitch kernels separately) ---- */

@@ -29,6 +29,24 @@ class NufheLwe(ctypes.Structure):
     ]
 
 
+class NufheGateJob(ctypes.Structure):
+    """nufhe_gate_job of include/nufhe_hip.h (one gate of a nufhe_gate_batch call)"""
+    _fields_ = [
+        ("kind", ctypes.c_int32),
+        ("c0", ctypes.c_int32),
+        ("pa", ctypes.c_int32),
+        ("pb", ctypes.c_int32),
+        ("nbits", ctypes.c_long),
+        ("result", NufheLwe),
+        ("a", NufheLwe),
+        ("b", NufheLwe),
+        ("c", NufheLwe),
+    ]
+
+
+JOB_BINARY = 0
+JOB_MUX = 1
+
 _vp = ctypes.c_void_p
 _i32 = ctypes.c_int32
 _int = ctypes.c_int
@@ -72,6 +90,8 @@ PROTOTYPES = {
     "nufhe_keyswitch": [_vp, _vp, NufheLwe, NufheLwe, _long],
     "nufhe_gate_binary": [_vp, _vp, NufheLwe, NufheLwe, NufheLwe, _i32, _i32, _i32, _i32, _long],
     "nufhe_gate_mux": [_vp, _vp, NufheLwe, NufheLwe, NufheLwe, NufheLwe, _long],
+    "nufhe_gate_batch": [_vp, _vp, ctypes.POINTER(NufheGateJob), _int, _i32],
+    "nufhe_ctx_pin_scratch": [_vp, _int],
     "nufhe_lwe_phase": [_vp, _vp, _long, _vp, _long, _vp, _long, _vp, _i32, _long, _int],
     "nufhe_t32_to_phase": [_vp, _vp, _vp, _long, ctypes.c_uint32],
     "nufhe_shift_torus_polynomial": [_vp, _vp, _vp, _vp, _long, _long, _long, _int, _int, _int],
@@ -97,7 +117,7 @@ PROTOTYPES = {
 }
 
 # NUFHE_ABI_VERSION of the include/nufhe_hip.h these prototypes were written against
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 

@@ -161,6 +161,27 @@ class VirtualMachine:
         gate_func(self.thread, self.cloud_key, dest, *args, perf_params=self.perf_params)
         return dest
 
+    def gate_batch(self, jobs):
+        """
+        Runs a list of INDEPENDENT gates as one bootstrap launch (:func:`nufhe_amd.gates.gate_batch`):
+        ``jobs`` = [('gate_nand', a, b), ('gate_mux', s, x, y), ('gate_xor', a, b, dest), ...] -- the gate's name, its
+        ciphertext arguments and, optionally, a destination as the last element.  Returns the list of results, in
+        order.  Small independent gates (up to about one bit per compute unit in total) finish in the time of one.
+        """
+        prepared, results = [], []
+        for job in jobs:
+            name, args = job[0], list(job[1:])
+            arity = 3 if name == 'gate_mux' else 2
+            if len(args) not in (arity, arity + 1):
+                raise ValueError("%s takes %d ciphertexts (+ an optional destination)" % (name, arity))
+            dest = args.pop() if len(args) == arity + 1 else None
+            if dest is None:
+                dest = self.empty_ciphertext(result_shape(*[get_shape(arg) for arg in args]))
+            prepared.append((name, dest) + tuple(args))
+            results.append(dest)
+        gates.gate_batch(self.thread, self.cloud_key, prepared, perf_params=self.perf_params)
+        return results
+
     def __getattr__(self, name):
         if name.startswith('gate_'):
             return lambda *args, **kwds: self._gate(name, *args, **kwds)

@@ -59,11 +59,22 @@ struct nufhe_ctx {
     cplx *d_ftw1 = nullptr;
     cplx *d_ftw2 = nullptr;
     Scratch ext_a, ext_b, ks_acc, ks_digits;
+    Scratch batch_a, batch_b;  // nufhe_gate_batch: the combined LWE(n) inputs of all rotations of a batch
+    // Scratch that a captured hipGraph points into must not be freed while the graph lives: while scratch_pins > 0 a buffer
+    // that has to grow is RETIRED (kept until the last pin is released) instead of freed (nufhe_ctx_pin_scratch)
+    int scratch_pins = 0;
+    std::vector<void *> retired;
+    // job tables of nufhe_gate_batch: a ring of slots, each a pinned host staging buffer, its device copy and the event
+    // behind the upload (a slot's staging buffer is rewritten only after its previous upload has executed)
+    struct TableSlot { void *h = nullptr; void *d = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; bool used = false; };
+    TableSlot tables[4];
+    unsigned table_next = 0;
     long team_max_bits = -1;   // batches up to this size use the 4-waves-per-bit kernel; -1 = default (launch_bootstrap)
     long pair_max_bits = -1;   // above that and up to this size: the 2-waves-per-bit kernel; -1 = 4 x CUs
     int ks_mfma = 1;           // keyswitch on the matrix cores (k_keyswitch_mfma): 0 never, 1 batches > 2 x CUs bits, 2 always
     bool profile = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // [0..2]: begin / after bootstrap / end of the LAST profiled gate
+    hipEvent_t ev_dst = nullptr;                               // nufhe_gather: "everything queued on this stream so far"
     bool ev_valid = false;
     // history of the profiled gates since the last nufhe_profile_history: PROFILE_RING event triples, so that a timed loop
     // never has to synchronise on an event in order to keep its kernel timings (created on first use)
@@ -95,8 +106,16 @@ int ensure(nufhe_ctx *ctx, Scratch &s, size_t bytes)
     if (s.bytes >= bytes) return NUFHE_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     if (s.ptr) {
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        HIP_TRY(hipFree(s.ptr));
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+            return fail(NUFHE_EINVAL, "a scratch buffer would have to grow (%zu -> %zu bytes) during stream capture: run the "
+                        "circuit once eagerly at this size before capturing it", s.bytes, bytes);
+        if (ctx->scratch_pins > 0) {
+            ctx->retired.push_back(s.ptr);          // a captured graph may still point into it
+        } else {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            HIP_TRY(hipFree(s.ptr));
+        }
         s.ptr = nullptr;
         s.bytes = 0;
     }
@@ -148,16 +167,42 @@ int check_key(nufhe_ctx *ctx, nufhe_cloudkey *key, bool need_bk, bool need_ks)
 }
 
 // the three events of the gate about to be profiled: a fresh slot of the history ring (ev[0..2] alias the last one)
-int profile_slot(nufhe_ctx *ctx)
+// (the slot is only COUNTED by profile_commit, after its end event has been recorded: a gate that fails half way leaves
+// the history as it was)
+int profile_slot(nufhe_ctx *ctx, hipEvent_t pe[3])
 {
     if (ctx->ring.empty()) {
-        ctx->ring.resize(3 * PROFILE_RING, nullptr);
-        for (auto &e : ctx->ring) HIP_TRY(hipEventCreate(&e));
+        std::vector<hipEvent_t> fresh(3 * PROFILE_RING, nullptr);
+        for (auto &e : fresh) {
+            hipError_t err = hipEventCreate(&e);
+            if (err != hipSuccess) {
+                for (hipEvent_t made : fresh)
+                    if (made) hipEventDestroy(made);
+                return fail(NUFHE_EHIP, "hipEventCreate (profile ring): %s", hipGetErrorString(err));
+            }
+        }
+        ctx->ring.swap(fresh);
     }
     const long slot = ctx->ring_count % PROFILE_RING;
-    ctx->ring_count++;
-    for (int k = 0; k < 3; k++) ctx->ev[k] = ctx->ring[3 * slot + k];
+    for (int k = 0; k < 3; k++) pe[k] = ctx->ring[3 * slot + k];
     return NUFHE_OK;
+}
+
+void profile_commit(nufhe_ctx *ctx, hipEvent_t pe[3])
+{
+    for (int k = 0; k < 3; k++) ctx->ev[k] = pe[k];      // ev[0..2]: the last gate whose three events were all recorded
+    ctx->ring_count++;
+    ctx->ev_valid = true;
+}
+
+// profiling is skipped while the stream is being captured into a graph: event pairs recorded inside a capture have no
+// elapsed time
+bool profiling_now(nufhe_ctx *ctx)
+{
+    if (!ctx->profile) return false;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &cap) != hipSuccess) { (void)hipGetLastError(); return true; }
+    return cap == hipStreamCaptureStatusNone;
 }
 
 int pick_j_per_block(long nbits, int input_size, int num_cus)
@@ -174,7 +219,7 @@ int pick_j_per_block(long nbits, int input_size, int num_cus)
 // keyswitch of LWE(1024) src1 (+ src2) (+ constant on b) into `result`
 int run_keyswitch(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result, const i32 *s1a, long s1as,
                   const i32 *s1b, long s1bs, const i32 *s2a, long s2as, const i32 *s2b, long s2bs, i32 c0,
-                  long nbits)
+                  long nbits, const BatchOut *batch_outs = nullptr, int n_batch_outs = 0)
 {
     int rc = ensure(ctx, ctx->ks_acc, (size_t)nbits * key->n * sizeof(u32));
     if (rc) return rc;
@@ -197,6 +242,8 @@ int run_keyswitch(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result, 
         P.digits_t = (unsigned short *)ctx->ks_digits.ptr;
     }
     KsFinal F;
+    F.batch_outs = batch_outs;
+    F.n_batch_outs = n_batch_outs;
     F.acc = P.acc;
     F.ks_b = key->d_ks_b; F.ks_cv = key->d_ks_cv;
     F.src1_a = s1a; F.src2_a = s2a; F.src1_b = s1b; F.src2_b = s2b;
@@ -285,6 +332,7 @@ int nufhe_ctx_create(int device, void *stream, int own_stream, nufhe_ctx **out)
     if (e == hipSuccess) e = hipMemcpy(ctx->d_ftw2, g2.data(), FFT_TW2_ELEMS * sizeof(cplx), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = kernels_init_device(&ctx->num_cus);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev[3]);      // nufhe_gather; ev[0..2] alias slots of the profile ring
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_dst, hipEventDisableTiming);
     if (e != hipSuccess) {
         nufhe_ctx_destroy(ctx);
         return fail(NUFHE_EHIP, "context setup: %s", hipGetErrorString(e));
@@ -309,7 +357,16 @@ int nufhe_ctx_destroy(nufhe_ctx *ctx)
     if (ctx->ext_b.ptr) hipFree(ctx->ext_b.ptr);
     if (ctx->ks_acc.ptr) hipFree(ctx->ks_acc.ptr);
     if (ctx->ks_digits.ptr) hipFree(ctx->ks_digits.ptr);
+    if (ctx->batch_a.ptr) hipFree(ctx->batch_a.ptr);
+    if (ctx->batch_b.ptr) hipFree(ctx->batch_b.ptr);
+    for (void *p : ctx->retired) hipFree(p);
+    for (auto &t : ctx->tables) {
+        if (t.h) hipHostFree(t.h);
+        if (t.d) hipFree(t.d);
+        if (t.done) hipEventDestroy(t.done);
+    }
     if (ctx->ev[3]) hipEventDestroy(ctx->ev[3]);
+    if (ctx->ev_dst) hipEventDestroy(ctx->ev_dst);
     for (hipEvent_t e : ctx->ring)
         if (e) hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -385,22 +442,37 @@ int nufhe_gather(nufhe_ctx *dst, void *d_dst, const size_t *dst_offsets, nufhe_c
         if (!srcs[i]) return fail(NUFHE_EINVAL, "null source context %d", i);
         if (bytes[i] && (!d_srcs[i] || !d_dst)) return fail(NUFHE_EINVAL, "null buffer of slice %d", i);
     }
-    for (int i = 0; i < count; i++) {
+    int caller_device = -1;
+    HIP_TRY(hipGetDevice(&caller_device));
+    // Ordering contract, both ways.  (1) The copies wait for everything ALREADY QUEUED on dst's stream: d_dst may be a
+    // recycled block whose last user -- a kernel still in flight on dst's stream -- must finish before a source stream
+    // writes into it.  (2) dst's stream waits for every copy, so whatever is queued on dst afterwards sees the slices.
+    HIP_TRY(hipSetDevice(dst->device));
+    HIP_TRY(hipEventRecord(dst->ev_dst, dst->stream));
+    int rc = NUFHE_OK;
+    for (int i = 0; i < count && rc == NUFHE_OK; i++) {
         if (!bytes[i]) continue;
         nufhe_ctx *src = srcs[i];
-        HIP_TRY(hipSetDevice(src->device));
-        if (src->device == dst->device)
-            HIP_TRY(hipMemcpyAsync((char *)d_dst + dst_offsets[i], d_srcs[i], bytes[i], hipMemcpyDeviceToDevice, src->stream));
-        else
-            HIP_TRY(hipMemcpyPeerAsync((char *)d_dst + dst_offsets[i], dst->device, d_srcs[i], src->device, bytes[i],
-                                       src->stream));
-        if (src == dst || src->stream == dst->stream) continue;      // same queue: already ordered
-        HIP_TRY(hipEventRecord(src->ev[3], src->stream));
-        HIP_TRY(hipSetDevice(dst->device));
-        HIP_TRY(hipStreamWaitEvent(dst->stream, src->ev[3], 0));
+        const bool same_queue = src == dst || src->stream == dst->stream;
+        hipError_t e = hipSetDevice(src->device);
+        if (e == hipSuccess && !same_queue) e = hipStreamWaitEvent(src->stream, dst->ev_dst, 0);
+        if (e == hipSuccess) {
+            if (src->device == dst->device)
+                e = hipMemcpyAsync((char *)d_dst + dst_offsets[i], d_srcs[i], bytes[i], hipMemcpyDeviceToDevice, src->stream);
+            else
+                e = hipMemcpyPeerAsync((char *)d_dst + dst_offsets[i], dst->device, d_srcs[i], src->device, bytes[i],
+                                       src->stream);
+        }
+        if (e == hipSuccess && !same_queue) {
+            e = hipEventRecord(src->ev[3], src->stream);
+            if (e == hipSuccess) e = hipSetDevice(dst->device);
+            if (e == hipSuccess) e = hipStreamWaitEvent(dst->stream, src->ev[3], 0);
+        }
+        if (e != hipSuccess) rc = fail(NUFHE_EHIP, "nufhe_gather, slice %d: %s", i, hipGetErrorString(e));
     }
-    HIP_TRY(hipSetDevice(dst->device));
-    return NUFHE_OK;
+    // the calling thread's current device is left as it was found
+    if (caller_device >= 0) (void)hipSetDevice(caller_device);
+    return rc;
 }
 
 // ---- cloud key ---------------------------------------------------------------------------
@@ -580,10 +652,29 @@ int nufhe_ks_upload(nufhe_cloudkey *key, const int32_t *h_ks_a, const int32_t *h
 // bootstrapping key in the wave layout | ks_a3 | ks_b | ks_cv, each part starting at a multiple of 256 bytes
 static size_t image_part(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
 
+// the image starts with a 256-byte header that names what it holds; import refuses anything else
+#define IMAGE_HEADER_BYTES 256
+struct ImageHeader {
+    char magic[8];            // "NUFHEIMG"
+    int32_t abi, n, transform, mask_size;
+    uint64_t total_bytes;
+};
+static_assert(sizeof(ImageHeader) <= IMAGE_HEADER_BYTES, "image header");
+
+static ImageHeader image_header(const nufhe_cloudkey *key, size_t total)
+{
+    ImageHeader h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, "NUFHEIMG", 8);
+    h.abi = NUFHE_ABI_VERSION; h.n = key->n; h.transform = key->transform; h.mask_size = key->mask_size;
+    h.total_bytes = total;
+    return h;
+}
+
 static void image_layout(const nufhe_cloudkey *key, size_t off[5])
 {
     const size_t rows = (size_t)key->ext_size() * NUFHE_KS_T;
-    off[0] = 0;
+    off[0] = IMAGE_HEADER_BYTES;
     off[1] = off[0] + image_part((size_t)key->bk_polys() * BK_POLY_ELEMS * sizeof(u64));
     off[2] = off[1] + image_part(rows * 3 * key->n * sizeof(int32_t));
     off[3] = off[2] + image_part(rows * 4 * sizeof(int32_t));
@@ -614,6 +705,12 @@ int nufhe_cloudkey_export_image(nufhe_cloudkey *key, void *d_image)
                            rows * 4 * sizeof(int32_t), rows * 4 * sizeof(float)};
     for (int i = 0; i < 4; i++)
         HIP_TRY(hipMemcpyAsync(dst + off[i], src[i], len[i], hipMemcpyDeviceToDevice, ctx->stream));
+    unsigned char head[IMAGE_HEADER_BYTES];
+    memset(head, 0, sizeof(head));
+    const ImageHeader h = image_header(key, off[4]);
+    memcpy(head, &h, sizeof(h));
+    HIP_TRY(hipMemcpyAsync(dst, head, sizeof(head), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));      // `head` is a stack buffer
     return NUFHE_OK;
 }
 
@@ -623,9 +720,23 @@ int nufhe_cloudkey_import_image(nufhe_cloudkey *key, const void *d_image)
     nufhe_ctx *ctx = key->ctx;
     int rc = check_ctx(ctx);
     if (rc) return rc;
-    if ((rc = alloc_bk(key)) || (rc = alloc_ks(key))) return rc;
     size_t off[5];
     image_layout(key, off);
+    {
+        // an image made for another transform / mask size / LWE size / library build has the same or a plausible size:
+        // the header is what tells them apart
+        ImageHeader got;
+        HIP_TRY(hipMemcpyAsync(&got, d_image, sizeof(got), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        const ImageHeader want = image_header(key, off[4]);
+        if (memcmp(got.magic, want.magic, 8) != 0) return fail(NUFHE_EINVAL, "not a cloud-key image (no NUFHEIMG header)");
+        if (got.abi != want.abi)
+            return fail(NUFHE_EINVAL, "cloud-key image of ABI version %d, this library is %d", (int)got.abi, (int)want.abi);
+        if (got.n != want.n || got.transform != want.transform || got.mask_size != want.mask_size || got.total_bytes != want.total_bytes)
+            return fail(NUFHE_EINVAL, "cloud-key image holds (n %d, transform %d, mask size %d), the key was created with (%d, %d, %d)",
+                        (int)got.n, (int)got.transform, (int)got.mask_size, key->n, key->transform, key->mask_size);
+    }
+    if ((rc = alloc_bk(key)) || (rc = alloc_ks(key))) return rc;
     const char *src = (const char *)d_image;
     void *dst[4] = {key->d_bk, key->d_ks_a3, key->d_ks_b, key->d_ks_cv};
     const size_t rows = (size_t)key->ext_size() * NUFHE_KS_T;
@@ -720,17 +831,9 @@ int nufhe_lwe_trivial_const(nufhe_ctx *ctx, nufhe_lwe res, int32_t mu, long nbit
     return NUFHE_OK;
 }
 
-// shared by bootstrap / gate_binary / gate_mux: jobs -> (optional keyswitch) -> result
-static int run_gate(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result, const BrJob *jobs, int njobs,
-                    i32 mu, long nbits, bool keyswitch, i32 ks_c0)
+// key, tables and kernel-family preparation common to every fused bootstrap launch of `total` rotations
+static void prepare_launch(nufhe_ctx *ctx, nufhe_cloudkey *key, BrLaunch &P, long total, i32 mu)
 {
-    if (nbits < 0) return fail(NUFHE_EINVAL, "negative batch size");
-    if (nbits == 0) return NUFHE_OK;
-    const long total = nbits * njobs;
-    BrLaunch P;
-    memset(&P, 0, sizeof(P));
-    for (int j = 0; j < njobs; j++) P.job[j] = jobs[j];
-    P.bits_per_job = nbits;
     P.nbits_total = total;
     P.bk = key->d_bk;
     P.bk_half = nullptr;
@@ -758,7 +861,22 @@ static int run_gate(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result
     const bool fft = key->transform == NUFHE_TRANSFORM_FFT;
     P.tw_a = fft ? (const void *)ctx->d_ftw1 : (const void *)ctx->d_tw1x;
     P.tw_b = fft ? (const void *)ctx->d_ftw2 : (const void *)ctx->d_tw1i;
-    P.clock_probe = ctx->profile ? ctx->d_clock : nullptr;
+}
+
+// shared by bootstrap / gate_binary / gate_mux: jobs -> (optional keyswitch) -> result
+static int run_gate(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result, const BrJob *jobs, int njobs,
+                    i32 mu, long nbits, bool keyswitch, i32 ks_c0)
+{
+    if (nbits < 0) return fail(NUFHE_EINVAL, "negative batch size");
+    if (nbits == 0) return NUFHE_OK;
+    const long total = nbits * njobs;
+    BrLaunch P;
+    memset(&P, 0, sizeof(P));
+    for (int j = 0; j < njobs; j++) P.job[j] = jobs[j];
+    P.bits_per_job = nbits;
+    prepare_launch(ctx, key, P, total, mu);
+    const bool prof = profiling_now(ctx);
+    P.clock_probe = prof ? ctx->d_clock : nullptr;
     if (keyswitch) {
         const int ext = key->ext_size();
         int rc = ensure(ctx, ctx->ext_a, (size_t)total * ext * sizeof(i32));
@@ -771,15 +889,16 @@ static int run_gate(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result
         P.out_a = result.a; P.out_a_stride = result.a_stride;
         P.out_b = result.b; P.out_b_stride = result.b_stride;
     }
-    if (ctx->profile) {
-        int rcp = profile_slot(ctx);
+    hipEvent_t pe[3] = {nullptr, nullptr, nullptr};
+    if (prof) {
+        int rcp = profile_slot(ctx, pe);
         if (rcp) return rcp;
         HIP_TRY(hipMemsetAsync(ctx->d_clock, 0, CLOCK_PROBE_WORDS * sizeof(unsigned long long), ctx->stream));
-        HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+        HIP_TRY(hipEventRecord(pe[0], ctx->stream));
     }
     HIP_TRY(launch_bootstrap(P, key->transform, key->mask_size, ctx->team_max_bits, ctx->pair_max_bits, ctx->num_cus,
                              ctx->stream));
-    if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+    if (prof) HIP_TRY(hipEventRecord(pe[1], ctx->stream));
     if (keyswitch) {
         const i32 *ea = (const i32 *)ctx->ext_a.ptr, *eb = (const i32 *)ctx->ext_b.ptr;
         const int ext = key->ext_size();
@@ -787,10 +906,32 @@ static int run_gate(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result
                                njobs == 2 ? eb + nbits : nullptr, 1, ks_c0, nbits);
         if (rc) return rc;
     }
-    if (ctx->profile) {
-        HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
-        ctx->ev_valid = true;
+    if (prof) {
+        HIP_TRY(hipEventRecord(pe[2], ctx->stream));
+        profile_commit(ctx, pe);
     }
+    return NUFHE_OK;
+}
+
+// job tables of a heterogeneous batch: next slot of the ring, staging buffer free to be rewritten
+static int table_slot(nufhe_ctx *ctx, size_t bytes, nufhe_ctx::TableSlot **out)
+{
+    nufhe_ctx::TableSlot &t = ctx->tables[ctx->table_next++ % 4];
+    if (!t.done) HIP_TRY(hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
+    if (t.used) HIP_TRY(hipEventSynchronize(t.done));     // its previous upload has executed (4 batches ago)
+    if (t.bytes < bytes) {
+        if (t.used) HIP_TRY(hipStreamSynchronize(ctx->stream));     // kernels of that batch may still read the device copy
+        if (t.h) HIP_TRY(hipHostFree(t.h));
+        if (t.d) HIP_TRY(hipFree(t.d));
+        t.h = t.d = nullptr;
+        t.bytes = 0;
+        const size_t cap = bytes < 4096 ? 4096 : bytes * 2;
+        HIP_TRY(hipHostMalloc(&t.h, cap, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&t.d, cap));
+        t.bytes = cap;
+    }
+    t.used = true;
+    *out = &t;
     return NUFHE_OK;
 }
 
@@ -818,17 +959,19 @@ int nufhe_keyswitch(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe
         (rc = check_lwe(result, key->n, "keyswitch result", true, nbits, true)))
         return rc;
     if (nbits == 0) return NUFHE_OK;
-    if (ctx->profile) {
-        int rcp = profile_slot(ctx);
+    const bool prof = profiling_now(ctx);
+    hipEvent_t pe[3] = {nullptr, nullptr, nullptr};
+    if (prof) {
+        int rcp = profile_slot(ctx, pe);
         if (rcp) return rcp;
-        HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-        HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+        HIP_TRY(hipEventRecord(pe[0], ctx->stream));
+        HIP_TRY(hipEventRecord(pe[1], ctx->stream));
     }
     rc = run_keyswitch(ctx, key, result, src.a, src.a_stride, src.b, src.b_stride, nullptr, 0, nullptr, 0, 0, nbits);
     if (rc) return rc;
-    if (ctx->profile) {
-        HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
-        ctx->ev_valid = true;
+    if (prof) {
+        HIP_TRY(hipEventRecord(pe[2], ctx->stream));
+        profile_commit(ctx, pe);
     }
     return NUFHE_OK;
 }
@@ -863,6 +1006,140 @@ int nufhe_gate_mux(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe_
     jobs[0].s0 = source(a, 1);  jobs[0].s1 = source(b, 1);  jobs[0].c0 = -MU;   // (0,-1/8) + a + b, gates.py:639-641
     jobs[1].s0 = source(a, -1); jobs[1].s1 = source(c, 1);  jobs[1].c0 = -MU;   // (0,-1/8) - a + c, gates.py:648-650
     return run_gate(ctx, key, result, jobs, 2, MU, nbits, true, MU);             // (0,1/8) + u1 + u2 -> KS, :657-664
+}
+
+int nufhe_gate_batch(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_gate_job *jobs, int n_jobs, int32_t mu)
+{
+    int rc = check_key(ctx, key, true, true);
+    if (rc) return rc;
+    if (n_jobs < 0 || (n_jobs > 0 && !jobs)) return fail(NUFHE_EINVAL, "null job list");
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return fail(NUFHE_EINVAL, "nufhe_gate_batch uploads its job tables from the host and cannot be captured into a graph");
+    long out_bits = 0, mux_bits = 0;
+    int live = 0;
+    for (int j = 0; j < n_jobs; j++) {
+        const nufhe_gate_job &g = jobs[j];
+        char what[64];
+        if (g.kind != NUFHE_JOB_BINARY && g.kind != NUFHE_JOB_MUX) return fail(NUFHE_EINVAL, "job %d: unknown kind %d", j, (int)g.kind);
+        if (g.nbits < 0) return fail(NUFHE_EINVAL, "job %d: negative batch size", j);
+        snprintf(what, sizeof(what), "job %d result", j);
+        if ((rc = check_lwe(g.result, key->n, what, true, g.nbits, true))) return rc;
+        snprintf(what, sizeof(what), "job %d operand a", j);
+        if ((rc = check_lwe(g.a, key->n, what, false, g.nbits))) return rc;
+        snprintf(what, sizeof(what), "job %d operand b", j);
+        if ((rc = check_lwe(g.b, key->n, what, false, g.nbits))) return rc;
+        if (g.kind == NUFHE_JOB_MUX) {
+            snprintf(what, sizeof(what), "job %d operand c", j);
+            if ((rc = check_lwe(g.c, key->n, what, false, g.nbits))) return rc;
+            mux_bits += g.nbits;
+        }
+        out_bits += g.nbits;
+        live += g.nbits > 0;
+    }
+    if (out_bits == 0) return NUFHE_OK;
+    const long rows = out_bits + mux_bits;
+    // tables: first rotations of all gates in job order (row = output bit), then the second rotations of the MUX gates
+    std::vector<BatchRot> rots;
+    std::vector<BatchOut> outs;
+    rots.reserve(2 * (size_t)live);
+    outs.reserve(live);
+    auto rot = [](const nufhe_lwe &x, i32 p0, const nufhe_lwe &y, i32 p1, i32 c0, long start, long nbits) {
+        BatchRot r;
+        memset(&r, 0, sizeof(r));
+        r.a0 = x.a; r.b0 = x.b; r.a0_stride = x.a_stride; r.b0_stride = x.b_stride; r.p0 = p0;
+        r.a1 = y.a; r.b1 = y.b; r.a1_stride = y.a_stride; r.b1_stride = y.b_stride; r.p1 = p1;
+        r.c0 = c0; r.start = start; r.nbits = nbits;
+        return r;
+    };
+    const i32 MU8 = (i32)(1u << 29);
+    long pos = 0, pos2 = out_bits;
+    for (int j = 0; j < n_jobs; j++) {
+        const nufhe_gate_job &g = jobs[j];
+        if (g.nbits == 0) continue;
+        BatchOut o;
+        memset(&o, 0, sizeof(o));
+        o.a = g.result.a; o.b = g.result.b; o.cv = g.result.cv;
+        o.a_stride = g.result.a_stride; o.b_stride = g.result.b_stride;
+        o.start = pos; o.nbits = g.nbits; o.second = -1;
+        if (g.kind == NUFHE_JOB_MUX) {
+            rots.push_back(rot(g.a, 1, g.b, 1, -MU8, pos, g.nbits));          // (0,-1/8) + a + b, gates.py:639-641
+            o.second = pos2;
+            pos2 += g.nbits;
+        } else {
+            rots.push_back(rot(g.a, g.pa, g.b, g.pb, g.c0, pos, g.nbits));
+        }
+        outs.push_back(o);
+        pos += g.nbits;
+    }
+    for (int j = 0; j < n_jobs; j++) {
+        const nufhe_gate_job &g = jobs[j];
+        if (g.nbits == 0 || g.kind != NUFHE_JOB_MUX) continue;
+        const long start = rots.empty() ? 0 : rots.back().start + rots.back().nbits;
+        rots.push_back(rot(g.a, -1, g.c, 1, -MU8, start, g.nbits));           // (0,-1/8) - a + c, gates.py:648-650
+    }
+    const size_t rot_bytes = rots.size() * sizeof(BatchRot), out_bytes = outs.size() * sizeof(BatchOut);
+    nufhe_ctx::TableSlot *slot = nullptr;
+    if ((rc = table_slot(ctx, rot_bytes + out_bytes, &slot))) return rc;
+    memcpy(slot->h, rots.data(), rot_bytes);
+    memcpy((char *)slot->h + rot_bytes, outs.data(), out_bytes);
+    HIP_TRY(hipMemcpyAsync(slot->d, slot->h, rot_bytes + out_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipEventRecord(slot->done, ctx->stream));
+    const BatchRot *d_rots = (const BatchRot *)slot->d;
+    const BatchOut *d_outs = (const BatchOut *)((const char *)slot->d + rot_bytes);
+
+    const int ext = key->ext_size();
+    if ((rc = ensure(ctx, ctx->batch_a, (size_t)rows * key->n * sizeof(i32))) || (rc = ensure(ctx, ctx->batch_b, (size_t)rows * sizeof(i32))) ||
+        (rc = ensure(ctx, ctx->ext_a, (size_t)rows * ext * sizeof(i32))) || (rc = ensure(ctx, ctx->ext_b, (size_t)rows * sizeof(i32))))
+        return rc;
+    HIP_TRY(launch_batch_combine((i32 *)ctx->batch_a.ptr, (i32 *)ctx->batch_b.ptr, d_rots, (int)rots.size(), rows, key->n,
+                                 ctx->stream));
+    BrLaunch P;
+    memset(&P, 0, sizeof(P));
+    P.job[0].s0 = BrSource{(const i32 *)ctx->batch_a.ptr, (const i32 *)ctx->batch_b.ptr, (long)key->n, 1, 1};
+    P.job[0].c0 = 0;
+    P.bits_per_job = rows;
+    prepare_launch(ctx, key, P, rows, mu);
+    const bool prof = profiling_now(ctx);
+    P.clock_probe = prof ? ctx->d_clock : nullptr;
+    P.out_a = (i32 *)ctx->ext_a.ptr; P.out_a_stride = ext;
+    P.out_b = (i32 *)ctx->ext_b.ptr; P.out_b_stride = 1;
+    hipEvent_t pe[3] = {nullptr, nullptr, nullptr};
+    if (prof) {
+        if ((rc = profile_slot(ctx, pe))) return rc;
+        HIP_TRY(hipMemsetAsync(ctx->d_clock, 0, CLOCK_PROBE_WORDS * sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(hipEventRecord(pe[0], ctx->stream));
+    }
+    HIP_TRY(launch_bootstrap(P, key->transform, key->mask_size, ctx->team_max_bits, ctx->pair_max_bits, ctx->num_cus,
+                             ctx->stream));
+    if (prof) HIP_TRY(hipEventRecord(pe[1], ctx->stream));
+    if (mux_bits > 0)
+        HIP_TRY(launch_batch_mux_fold((i32 *)ctx->ext_a.ptr, (i32 *)ctx->ext_b.ptr, d_outs, (int)outs.size(), out_bits, ext, MU8,
+                                      ctx->stream));
+    nufhe_lwe none;
+    memset(&none, 0, sizeof(none));
+    rc = run_keyswitch(ctx, key, none, (const i32 *)ctx->ext_a.ptr, ext, (const i32 *)ctx->ext_b.ptr, 1, nullptr, 0, nullptr, 0, 0,
+                       out_bits, d_outs, (int)outs.size());
+    if (rc) return rc;
+    if (prof) {
+        HIP_TRY(hipEventRecord(pe[2], ctx->stream));
+        profile_commit(ctx, pe);
+    }
+    return NUFHE_OK;
+}
+
+int nufhe_ctx_pin_scratch(nufhe_ctx *ctx, int delta)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (ctx->scratch_pins + delta < 0) return fail(NUFHE_EINVAL, "scratch pin count would become negative");
+    ctx->scratch_pins += delta;
+    if (ctx->scratch_pins == 0 && !ctx->retired.empty()) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (void *p : ctx->retired) hipFree(p);
+        ctx->retired.clear();
+    }
+    return NUFHE_OK;
 }
 
 int nufhe_lwe_phase(nufhe_ctx *ctx, int32_t *d_out, long out_stride, const int32_t *d_a, long a_stride,

@@ -57,7 +57,29 @@ struct KsLaunch {
     unsigned short *digits_t;
 };
 
+// ---- heterogeneous gate batch (nufhe_gate_batch): device tables, ascending `start` --------------------------------
+// One blind rotation per row of a combined LWE(n) scratch: rows [start, start + nbits) of group g hold
+// (0, c0) + p0 * src0[bit] + p1 * src1[bit] (int32 wraparound), bit = row - start.
+struct BatchRot {
+    const i32 *a0, *b0, *a1, *b1;
+    long a0_stride, b0_stride, a1_stride, b1_stride;
+    long start, nbits;
+    i32 p0, p1, c0, pad_;
+};
+// One result slice per gate of the batch: output bits [start, start + nbits) go to its own view; `second` >= 0 (MUX):
+// the rows of the second rotation's extracted samples, added to the first rotation's (with +mu on b) before the keyswitch.
+struct BatchOut {
+    i32 *a, *b;
+    float *cv;
+    long a_stride, b_stride;
+    long start, nbits;
+    long second;
+};
+
 struct KsFinal {
+    // heterogeneous batch: results go to the views of `batch_outs` (n_batch_outs entries) instead of out_a / out_b / out_cv
+    const BatchOut *batch_outs;
+    int n_batch_outs;
     const u32 *acc;
     const i32 *ks_b;      // [1024][8][4]
     const float *ks_cv;   // [1024][8][4]
@@ -124,6 +146,9 @@ hipError_t launch_bk_from_coeffs(u64 *out, const i32 *in, long polys, const u64 
 static inline size_t ks_planes_bytes(int input_size) { return (size_t)4 * input_size * 2 * KSM_COLS * 16; }
 hipError_t launch_ks_planes(signed char *planes, const i32 *ks_a3, int input_size, int n, hipStream_t stream);
 hipError_t launch_keyswitch(const KsLaunch &P, const KsFinal &F, hipStream_t stream);
+hipError_t launch_batch_combine(i32 *out_a, i32 *out_b, const BatchRot *rots, int n_rots, long rows, int n, hipStream_t stream);
+hipError_t launch_batch_mux_fold(i32 *ext_a, i32 *ext_b, const BatchOut *outs, int n_outs, long out_bits, int ext, i32 mu,
+                                 hipStream_t stream);
 hipError_t launch_lwe_linear(const LweView &res, const LweView &src, i32 p, int add_result, long nbits, int size,
                              hipStream_t stream);
 hipError_t launch_lwe_trivial_const(const LweView &res, i32 mu, long nbits, int size, hipStream_t stream);

@@ -973,6 +973,19 @@ __global__ __launch_bounds__(KS_BLOCK_THREADS) void k_keyswitch_a(KsLaunch P)
     }
 }
 
+// entry of an ascending-`start` table that holds row `r` (the last one whose start <= r; empty entries are skipped
+// because their successor has the same start)
+template <typename T>
+__device__ __forceinline__ int batch_find(const T *tab, int n, long r)
+{
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].start <= r) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
 // finalize: copy the accumulated mask into the result view, and compute b and the variance.
 // The float32 variance must be summed in the reference's sequential (j, k) order to be
 // bit-identical (lwe_cpu.py:80-92): the block gathers the selected terms into LDS in parallel
@@ -984,8 +997,16 @@ __global__ __launch_bounds__(256) void k_keyswitch_finalize(KsFinal P)
     const long bit = blockIdx.x;
     if (threadIdx.x == 0) { b_sum = 0; nz_sum = 0; }
     __syncthreads();
+    i32 *out_a = P.out_a + bit * P.out_a_stride, *out_b = P.out_b + bit * P.out_b_stride;
+    float *out_cv = P.out_cv ? P.out_cv + bit * P.out_b_stride : nullptr;
+    if (P.batch_outs) {
+        const BatchOut &o = P.batch_outs[batch_find(P.batch_outs, P.n_batch_outs, bit)];
+        out_a = o.a + (bit - o.start) * o.a_stride;
+        out_b = o.b + (bit - o.start) * o.b_stride;
+        out_cv = o.cv ? o.cv + (bit - o.start) * o.b_stride : nullptr;
+    }
     for (int c = threadIdx.x; c < P.n; c += blockDim.x)
-        P.out_a[bit * P.out_a_stride + c] = (i32)P.acc[bit * P.n + c];
+        out_a[c] = (i32)P.acc[bit * P.n + c];
     const bool by_count = P.cv_table != nullptr;     // uniform-variance key: count instead of adding
     u32 bpart = 0, nz = 0;
     float cv = 0.0f;
@@ -1006,7 +1027,7 @@ __global__ __launch_bounds__(256) void k_keyswitch_finalize(KsFinal P)
         }
         if (!by_count) {
             __syncthreads();
-            if (threadIdx.x == 0 && P.out_cv)
+            if (threadIdx.x == 0 && out_cv)
                 for (int i = 0; i < 8192; i++) cv += cv_terms[i];
             __syncthreads();
         }
@@ -1017,8 +1038,8 @@ __global__ __launch_bounds__(256) void k_keyswitch_finalize(KsFinal P)
     if (threadIdx.x == 0) {
         u32 b = (u32)P.c0 + (u32)P.src1_b[bit * P.src1_bstride];
         if (P.src2_b) b += (u32)P.src2_b[bit * P.src2_bstride];
-        P.out_b[bit * P.out_b_stride] = (i32)(b - b_sum);
-        if (P.out_cv) P.out_cv[bit * P.out_b_stride] = by_count ? P.cv_table[nz_sum] : cv;
+        *out_b = (i32)(b - b_sum);
+        if (out_cv) *out_cv = by_count ? P.cv_table[nz_sum] : cv;
     }
 }
 
@@ -1046,6 +1067,42 @@ __global__ void k_lwe_linear(LweView res, LweView src, i32 p, int add_result, lo
             *c = (add_result ? *c : 0.0f) + (float)((long)p * p) * sv;
         }
     }
+}
+
+// Heterogeneous gate batch, step 1: the linear pre-combination of every gate of the batch (gates.py:104-110 and
+// siblings: (0, c) + pa a + pb b, int32 wraparound) into the rows of ONE LWE(n) array, so that a single bootstrap launch
+// covers independent gates of different kinds.  One work-group per row.
+__global__ __launch_bounds__(256) void k_batch_combine(i32 *__restrict__ out_a, i32 *__restrict__ out_b,
+                                                       const BatchRot *__restrict__ rots, int n_rots, int n)
+{
+    const long row = blockIdx.x;
+    const BatchRot &g = rots[batch_find(rots, n_rots, row)];
+    const long bit = row - g.start;
+    const i32 *a0 = g.a0 + bit * g.a0_stride;
+    const i32 *a1 = g.p1 ? g.a1 + bit * g.a1_stride : nullptr;
+    for (int c = threadIdx.x; c < n; c += blockDim.x) {
+        u32 v = (u32)g.p0 * (u32)a0[c];
+        if (a1) v += (u32)g.p1 * (u32)a1[c];
+        out_a[row * n + c] = (i32)v;
+    }
+    if (threadIdx.x == 0) {
+        u32 v = (u32)g.c0 + (u32)g.p0 * (u32)g.b0[bit * g.b0_stride];
+        if (a1) v += (u32)g.p1 * (u32)g.b1[bit * g.b1_stride];
+        out_b[row] = (i32)v;
+    }
+}
+
+// step 3 (MUX gates of a batch only): (0, mu) + u1 + u2 under the extracted key (gates.py:657-661), in place in u1's rows
+__global__ __launch_bounds__(256) void k_batch_mux_fold(i32 *__restrict__ ext_a, i32 *__restrict__ ext_b,
+                                                        const BatchOut *__restrict__ outs, int n_outs, int ext, i32 mu)
+{
+    const long bit = blockIdx.x;
+    const BatchOut &o = outs[batch_find(outs, n_outs, bit)];
+    if (o.second < 0) return;
+    const long row2 = o.second + (bit - o.start);
+    for (int c = threadIdx.x; c < ext; c += blockDim.x)
+        ext_a[bit * ext + c] = (i32)((u32)ext_a[bit * ext + c] + (u32)ext_a[row2 * ext + c]);
+    if (threadIdx.x == 0) ext_b[bit] = (i32)((u32)ext_b[bit] + (u32)ext_b[row2] + (u32)mu);
 }
 
 // LweNoiselessTrivialConstant, lwe_cpu.py:136-143
@@ -1775,6 +1832,21 @@ hipError_t launch_keyswitch(const KsLaunch &P, const KsFinal &F, hipStream_t str
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_keyswitch_finalize, dim3((unsigned)P.nbits), dim3(256), 0, stream, F);
+    return hipGetLastError();
+}
+
+hipError_t launch_batch_combine(i32 *out_a, i32 *out_b, const BatchRot *rots, int n_rots, long rows, int n, hipStream_t stream)
+{
+    if (rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_batch_combine, dim3((unsigned)rows), dim3(256), 0, stream, out_a, out_b, rots, n_rots, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_batch_mux_fold(i32 *ext_a, i32 *ext_b, const BatchOut *outs, int n_outs, long out_bits, int ext, i32 mu,
+                                 hipStream_t stream)
+{
+    if (out_bits == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_batch_mux_fold, dim3((unsigned)out_bits), dim3(256), 0, stream, ext_a, ext_b, outs, n_outs, ext, mu);
     return hipGetLastError();
 }
 

@@ -225,3 +225,64 @@ def gate_mux(thr, cloud_key, result, a, b, c, perf_params=None):
     _lib.call("nufhe_gate_mux", thr.handle, cloud_key._native.handle, res.desc, fa.desc, fb.desc, fc.desc,
               res.nbits)
     res.writeback()
+
+
+# (c, pa, pb) of every bootstrapped binary gate: result = KS(BS((0, c) + pa a + pb b)) (the functions above)
+BINARY_GATES = {
+    'gate_nand': (phase_to_t32(1, 8), -1, -1),
+    'gate_or': (phase_to_t32(1, 8), 1, 1),
+    'gate_and': (phase_to_t32(-1, 8), 1, 1),
+    'gate_xor': (phase_to_t32(1, 4), 2, 2),
+    'gate_xnor': (phase_to_t32(-1, 4), -2, -2),
+    'gate_nor': (phase_to_t32(-1, 8), -1, -1),
+    'gate_andny': (phase_to_t32(-1, 8), -1, 1),
+    'gate_andyn': (phase_to_t32(-1, 8), 1, -1),
+    'gate_orny': (phase_to_t32(1, 8), -1, 1),
+    'gate_oryn': (phase_to_t32(1, 8), 1, -1),
+}
+
+
+def gate_batch(thr, cloud_key, jobs, perf_params=None):
+    """
+    A list of INDEPENDENT bootstrapped gates -- different kinds, shapes and buffers -- as one bootstrap launch
+    (``nufhe_gate_batch``; SURVEY 8f row 4, no reference counterpart beyond the gate-by-gate circuit of
+    nufhe/operators_integer.py:64-95).  ``jobs`` = [(name, result, a, b) | ('gate_mux', result, a, b, c), ...] with the
+    gate functions' own names and argument order.  A gate of up to one bit per CU takes as long as one bit (500
+    dependent blind-rotation steps), so N small independent gates batched this way take the time of ONE instead of N.
+    Results are word-for-word those of the individual gate calls.  No job may read another job's result buffer.
+    With ``single_kernel_bootstrap == False`` the gates simply run one after the other (the reference's mode).
+    """
+    import ctypes
+    jobs = list(jobs)
+    for job in jobs:
+        name = job[0]
+        if name != 'gate_mux' and name not in BINARY_GATES:
+            raise ValueError("gate_batch: %r is not a bootstrapped gate (gate_not / gate_copy / gate_constant need no batch)" % (name,))
+        if len(job) != (5 if name == 'gate_mux' else 4):
+            raise ValueError("gate_batch: %s takes %d ciphertext arguments" % (name, 4 if name == 'gate_mux' else 3))
+    if not single_kernel(perf_params):
+        for job in jobs:
+            globals()[job[0]](thr, cloud_key, *job[1:], perf_params=perf_params)
+        return
+    thr.check_stream()
+    descs = (_lib.NufheGateJob * max(1, len(jobs)))()
+    flats = []
+    for i, job in enumerate(jobs):
+        name, result, args = job[0], job[1], job[2:]
+        check_shape(result, *args)
+        _check_sizes(cloud_key, result, *args)
+        res = _Flat(result, result.shape, output=True)
+        ops = [_Flat(x, result.shape) for x in args]
+        flats.append((res, ops))                      # the temporaries of strided views must outlive the call
+        d = descs[i]
+        d.nbits = res.nbits
+        d.result, d.a, d.b = res.desc, ops[0].desc, ops[1].desc
+        if name == 'gate_mux':
+            d.kind = _lib.JOB_MUX
+            d.c = ops[2].desc
+        else:
+            d.kind = _lib.JOB_BINARY
+            d.c0, d.pa, d.pb = [int(v) for v in BINARY_GATES[name]]
+    _lib.call("nufhe_gate_batch", thr.handle, cloud_key._native.handle, descs, len(jobs), int(MU))
+    for res, _ in flats:
+        res.writeback()

@@ -24,9 +24,17 @@ the 3-5 kernels of every gate disappear; the device work (500 dependent blind-ro
 measured (profiles/r04_graph_capture.json): uint_min on 4 x 16 bits 85.4 ms eager, 85.3 ms replayed; a 16-gate NAND chain
 on 4 bits 75.4 / 75.6 ms.  The gates are so long (4.7 ms each) that the stream never runs dry in eager mode either; the
 graph is for hosts that must not spend a core on issuing gates, not a latency win.
+
+The captured graph holds raw pointers into the library's scratch buffers (extracted samples, keyswitch accumulators),
+which grow on demand.  A GateGraph therefore PINS the context's scratch from its first capture until ``close()`` (or
+garbage collection): a later, larger eager gate on the same DeviceThread allocates a new buffer and the old one stays
+alive for the graph (``nufhe_ctx_pin_scratch``) -- replaying an old graph after larger gates have run is safe.
+``VirtualMachine.gate_batch`` cannot be captured (its job tables are uploaded from the host per call).
 """
 
 import torch
+
+from . import _lib
 
 
 class GateGraph:
@@ -35,6 +43,7 @@ class GateGraph:
         self.thread = thread
         self.graph = None
         self.outputs = None
+        self._pinned = False
         if thread._torch_stream.cuda_stream == 0:
             raise ValueError(
                 "the default stream cannot be captured: create the DeviceThread / Context inside "
@@ -47,6 +56,9 @@ class GateGraph:
         every ``replay``; the ciphertexts the circuit
         read are its INPUT BUFFERS -- refresh them in place (``ct[...] = other``)."""
         stream = self.thread._torch_stream
+        if not self._pinned:
+            _lib.call("nufhe_ctx_pin_scratch", self.thread.handle, 1)
+            self._pinned = True
         with torch.cuda.stream(stream):
             for _ in range(max(1, int(warmup))):
                 circuit()
@@ -63,3 +75,18 @@ class GateGraph:
         with torch.cuda.stream(self.thread._torch_stream):
             self.graph.replay()
         return self.outputs
+
+    def close(self):
+        """Drops the graph and releases its pin on the context's scratch buffers."""
+        self.graph = None
+        if self._pinned:
+            self._pinned = False
+            handle = getattr(self.thread, 'handle', None)
+            if handle is not None and handle.value is not None:
+                _lib.call("nufhe_ctx_pin_scratch", handle, -1)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

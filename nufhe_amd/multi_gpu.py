@@ -23,8 +23,8 @@ import torch
 def launch_ranks(script: str, argv, nproc: int, backend: str = "nccl"):
     """
     Starts ``nproc`` ranks of ``script`` on THIS node (one process per GPU) and returns the exit status:
-    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node nproc --master-addr 127.0.0.1
-    --master-port <free port> script argv...``.  This is what lets ``python bench.py --gpus N`` and
+    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node nproc --rdzv-backend=c10d
+    --rdzv-endpoint=127.0.0.1:0 --local-addr 127.0.0.1 script argv...`` (the store picks its own free port).  This is what lets ``python bench.py --gpus N`` and
     ``python examples/multi_gpu.py --gpus N`` be complete commands, like the reference's example that
     starts its own per-GPU workers (examples/multi_gpu.py:86-114).  A process that already has ``RANK``
     in its environment must not call this (it IS a rank).
@@ -33,7 +33,6 @@ def launch_ranks(script: str, argv, nproc: int, backend: str = "nccl"):
     an error here, before anything is started.  ``gloo`` is the test route (ranks may share a GPU).
     """
     import os
-    import socket
     import subprocess
     import sys
     if "RANK" in os.environ:
@@ -43,11 +42,12 @@ def launch_ranks(script: str, argv, nproc: int, backend: str = "nccl"):
     if backend == "nccl" and torch.cuda.device_count() < nproc:
         raise RuntimeError("%d ranks over RCCL need %d GPUs, this node shows %d (set NUFHE_BENCH_BACKEND=gloo "
                            "for the shared-GPU test route)" % (nproc, nproc, torch.cuda.device_count()))
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    # the rendezvous store binds port 0 itself (c10d backend): no window between "find a free port" and "use it" in which
+    # a concurrent launch on this node could take it; 127.0.0.1 throughout (the container's hostname may not resolve)
+    import uuid
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+           "--rdzv-backend=c10d", "--rdzv-endpoint=127.0.0.1:0", "--rdzv-id", uuid.uuid4().hex,
+           "--local-addr", "127.0.0.1", script] + list(argv)
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // nproc)))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs between the ranks of one node
@@ -107,7 +107,9 @@ def gather_threads(dst_thr, parts):
     lead = [int(numpy_prod(ct.shape)) for _, ct in parts]
     total = sum(lead)
     n = params.size
-    with torch.cuda.device(dst_thr.device):
+    # allocated under the DESTINATION's stream: a recycled block's previous user is then work on that stream, which the
+    # copies of nufhe_gather are ordered behind (its ordering contract, include/nufhe_hip.h)
+    with torch.cuda.device(dst_thr.device), torch.cuda.stream(dst_thr._torch_stream):
         a = torch.empty((total, n), dtype=torch.int32, device=dst_thr.device)
         b = torch.empty((total,), dtype=torch.int32, device=dst_thr.device)
         cv = torch.empty((total,), dtype=torch.float32, device=dst_thr.device)

@@ -1,0 +1,299 @@
+"""
+Heterogeneous gate batch (nufhe_gate_batch / VirtualMachine.gate_batch; SURVEY 8f row 4, circuit-level fusion -- the
+reference's circuit is a gate-by-gate chain, nufhe/operators_integer.py:64-95): a list of independent gates of different
+kinds and sizes as ONE bootstrap launch.  Every job's result words (a, b, variances) are compared with the CPU oracle on
+the same inputs and with the individual gate calls; plus the round-4 advisor items that live next to it in api.hip:
+scratch pinning for captured graphs, the key-image header, the ordering of nufhe_gather.
+"""
+import ctypes
+import os
+import time
+
+import numpy
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def env(orc, oracle_keys):
+    import gpu_helpers as H
+    from nufhe_amd.device import DeviceThread
+    import nufhe_amd
+    thr = DeviceThread(0)
+    lwe_key, tlwe_key, ck = oracle_keys
+    cloud_key = H.cloud_key_from_arrays(thr, ck)
+    secret_key = H.secret_key_from_array(thr, lwe_key)
+    ctx = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(456), thread=thr)
+    vm = ctx.make_virtual_machine(cloud_key)
+    return dict(H=H, thr=thr, ctx=ctx, vm=vm, ck=ck, lwe_key=lwe_key, cloud_key=cloud_key, secret_key=secret_key)
+
+
+TRUTH = {
+    'gate_nand': lambda a, b: ~(a & b), 'gate_or': lambda a, b: a | b, 'gate_and': lambda a, b: a & b,
+    'gate_xor': lambda a, b: a ^ b, 'gate_xnor': lambda a, b: ~(a ^ b), 'gate_nor': lambda a, b: ~(a | b),
+    'gate_andny': lambda a, b: ~a & b, 'gate_andyn': lambda a, b: a & ~b, 'gate_orny': lambda a, b: ~a | b,
+    'gate_oryn': lambda a, b: a | ~b,
+}
+
+
+def _make(env, orc, rng, n):
+    m = rng.uniform_bool((n,)).astype(bool)
+    c = orc.encrypt(rng, env['lwe_key'], m)
+    return m, c, env['H'].ciphertext_from_arrays(env['thr'], c)
+
+
+def _oracle(orc, ck, name, cs):
+    if name == 'gate_mux':
+        return orc.gate_mux(ck, cs[0], cs[1], cs[2])
+    return orc.gate(name, ck, cs[0], cs[1])
+
+
+def _check_job(env, orc, name, result, inputs, upto=None):
+    H = env['H']
+    ra, rb, rcv = H.ct_arrays(result)
+    ms = [m for m, _, _ in inputs]
+    n = ra.shape[0] if upto is None else min(upto, ra.shape[0])
+    exp = _oracle(orc, env['ck'], name, [tuple(x[:n] for x in c) for _, c, _ in inputs])
+    assert (ra[:n] == exp[0]).all() and (rb[:n] == exp[1]).all() and (rcv[:n] == exp[2]).all(), name
+    truth = numpy.where(ms[0], ms[1], ms[2]) if name == 'gate_mux' else TRUTH[name](ms[0], ms[1])
+    assert (env['ctx'].decrypt(env['secret_key'], result) == truth).all(), name
+
+
+def test_batch_of_mixed_gates_every_word_vs_oracle(env, orc):
+    """binary | MUX | binary with odd sizes (one bit, a prime, zero), a MUX between two binary jobs"""
+    rng = orc.DeterministicRNG(2025)
+    spec = [('gate_nand', 5), ('gate_mux', 7), ('gate_xor', 1), ('gate_and', 0), ('gate_mux', 3), ('gate_oryn', 13)]
+    jobs, keep = [], []
+    for name, n in spec:
+        ins = [_make(env, orc, rng, n) for _ in range(3 if name == 'gate_mux' else 2)]
+        keep.append((name, ins))
+        jobs.append((name,) + tuple(d for _, _, d in ins))
+    results = env['vm'].gate_batch(jobs)
+    assert len(results) == len(spec)
+    for (name, ins), res in zip(keep, results):
+        assert res.shape == (ins[0][0].shape[0],)
+        if res.shape[0]:
+            _check_job(env, orc, name, res, ins)
+        # the individual call writes the same words
+        single = getattr(env['vm'], name)(*[d for _, _, d in ins])
+        assert single == res
+
+
+def test_batch_all_ten_binary_gates_and_destinations(env, orc):
+    """one launch holding every binary gate kind; results into caller-provided destinations, one of them a strided view"""
+    rng = orc.DeterministicRNG(7)
+    vm = env['vm']
+    a = _make(env, orc, rng, 6); b = _make(env, orc, rng, 6)
+    names = sorted(TRUTH)
+    big = vm.empty_ciphertext((len(names), 12))
+    jobs = [(name, a[2], b[2], big[i, ::2]) for i, name in enumerate(names)]
+    results = vm.gate_batch(jobs)
+    for i, name in enumerate(names):
+        _check_job(env, orc, name, big[i, ::2].copy(), [a, b])
+        assert results[i] == big[i, ::2]
+
+
+@pytest.mark.parametrize('sizes', [(64, 64, 64, 64), (300, 300), (1500, 700, 200)])
+def test_batch_crosses_the_kernel_families(env, orc, sizes):
+    """total row counts that select the 8-wave team kernel (<= CUs), the pair kernel and the wave kernel + matrix-core
+    keyswitch: first 16 bits of every job against the oracle, everything against the individual gate calls"""
+    rng = orc.DeterministicRNG(sum(sizes))
+    vm = env['vm']
+    names = ['gate_nand', 'gate_mux', 'gate_xnor', 'gate_andny']
+    jobs, keep = [], []
+    for name, n in zip(names, sizes):
+        ins = [_make(env, orc, rng, n) for _ in range(3 if name == 'gate_mux' else 2)]
+        keep.append((name, ins))
+        jobs.append((name,) + tuple(d for _, _, d in ins))
+    results = vm.gate_batch(jobs)
+    for (name, ins), res in zip(keep, results):
+        _check_job(env, orc, name, res, ins, upto=16)
+        assert getattr(vm, name)(*[d for _, _, d in ins]) == res
+
+
+def test_batch_broadcast_operand_and_stepwise_mode(env, orc):
+    """a one-bit operand broadcast over a job; and the reference's multi-kernel mode runs the same list gate by gate"""
+    import nufhe_amd
+    rng = orc.DeterministicRNG(11)
+    vm = env['vm']
+    one = _make(env, orc, rng, 1); many = _make(env, orc, rng, 9); other = _make(env, orc, rng, 4)
+    r0, r1 = vm.gate_batch([('gate_and', one[2], many[2]), ('gate_nor', other[2], other[2])])
+    assert r0.shape == (9,) and r1.shape == (4,)
+    assert r0 == vm.gate_and(one[2], many[2]) and r1 == vm.gate_nor(other[2], other[2])
+    pp = nufhe_amd.PerformanceParameters(env['cloud_key'].params, single_kernel_bootstrap=False)
+    vm2 = env['ctx'].make_virtual_machine(env['cloud_key'], perf_params=pp)
+    s0, s1 = vm2.gate_batch([('gate_and', one[2], many[2]), ('gate_nor', other[2], other[2])])
+    assert s0 == r0 and s1 == r1
+
+
+def test_batch_refusals(env, orc):
+    rng = orc.DeterministicRNG(3)
+    vm = env['vm']
+    a = _make(env, orc, rng, 4); b = _make(env, orc, rng, 5)
+    with pytest.raises(ValueError):
+        vm.gate_batch([('gate_nand', a[2], b[2])])             # shapes do not broadcast
+    with pytest.raises(ValueError):
+        vm.gate_batch([('gate_not', a[2], a[2])])              # not a bootstrapped gate
+    with pytest.raises(ValueError):
+        vm.gate_batch([('gate_mux', a[2], a[2])])              # arity
+    assert vm.gate_batch([]) == []
+    # raw C boundary: unknown kind, wrong operand size
+    from nufhe_amd import _lib
+    from nufhe_amd.lwe import _Flat
+    res = vm.empty_ciphertext((4,))
+    job = (_lib.NufheGateJob * 1)()
+    job[0].kind = 7; job[0].nbits = 4
+    job[0].result = _Flat(res, (4,), output=True).desc; job[0].a = _Flat(a[2], (4,)).desc; job[0].b = _Flat(a[2], (4,)).desc
+    with pytest.raises(ValueError, match='unknown kind'):
+        _lib.call("nufhe_gate_batch", env['thr'].handle, env['cloud_key']._native.handle, job, 1, 1 << 29)
+    job[0].kind = 0
+    job[0].a.size = 499
+    with pytest.raises(ValueError, match='LWE size'):
+        _lib.call("nufhe_gate_batch", env['thr'].handle, env['cloud_key']._native.handle, job, 1, 1 << 29)
+
+
+def test_batch_of_small_gates_takes_the_time_of_one(env, orc):
+    """the point of the entry point: four independent 64-bit gates of different kinds in about the time of one (each is
+    a 500-step dependent chain at one bit per CU); measured here, asserted loosely (< 1.6 x one gate, vs ~4 x)"""
+    rng = orc.DeterministicRNG(4)
+    vm, thr = env['vm'], env['thr']
+    names = ['gate_nand', 'gate_or', 'gate_xor', 'gate_andyn']
+    ins = [[_make(env, orc, rng, 64) for _ in range(2)] for _ in names]
+    dests = [vm.empty_ciphertext((64,)) for _ in names]
+    jobs = [(n, i[0][2], i[1][2], d) for n, i, d in zip(names, ins, dests)]
+
+    def timed(fn, reps=5):
+        fn(); thr.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        thr.synchronize()
+        return (time.perf_counter() - t0) / reps
+    t_one = timed(lambda: vm.gate_nand(ins[0][0][2], ins[0][1][2], dest=dests[0]))
+    t_seq = timed(lambda: [getattr(vm, n)(i[0][2], i[1][2], dest=d) for n, i, d in zip(names, ins, dests)])
+    t_batch = timed(lambda: vm.gate_batch(jobs))
+    print("one 64-bit gate %.2f ms, four in sequence %.2f ms, four as one batch %.2f ms" % (
+        1e3 * t_one, 1e3 * t_seq, 1e3 * t_batch))
+    assert t_batch < 1.6 * t_one and t_batch < 0.5 * t_seq
+    for n, i, d in zip(names, ins, dests):
+        _check_job(env, orc, n, d, i, upto=8)
+
+
+def test_graph_survives_larger_eager_gates(orc):
+    """round-4 advisor: a captured graph points into the context's grow-only scratch; a LARGER eager gate afterwards used
+    to free it.  With the scratch pinned by the GateGraph the old buffers stay alive: capture at 3 bits, run 600 and 2100
+    bits eagerly (both reallocate), replay the 3-bit graph -> still the eager result."""
+    import torch
+    import nufhe_amd as nufhe
+    from nufhe_amd.device import DeviceThread
+    stream = torch.cuda.Stream()
+    rs = numpy.random.RandomState(5)
+    with torch.cuda.stream(stream):
+        thr = DeviceThread(0)
+        ctx = nufhe.Context(rng=nufhe.DeterministicRNG(42), thread=thr)
+        secret, cloud = ctx.make_key_pair()
+        vm = ctx.make_virtual_machine(cloud)
+        ms = [rs.randint(0, 2, 3).astype(bool) for _ in range(3)]
+        cs = [ctx.encrypt(secret, m) for m in ms]
+
+        def circuit():
+            return vm.gate_mux(vm.gate_nand(cs[0], cs[1]), cs[2], cs[0])
+        g = nufhe.GateGraph(thr)
+        out = g.capture(circuit)
+        g.replay()
+        expect = circuit()
+        assert out == expect
+        for B in (600, 2100):
+            big = [ctx.encrypt(secret, rs.randint(0, 2, B).astype(bool)) for _ in range(3)]
+            vm.gate_mux(big[0], big[1], big[2])
+        thr.synchronize()
+        out.a.zero_(); out.b.zero_()
+        g.replay()
+        assert out == expect
+        g.close()
+        # growing DURING a capture is refused, not silently wrong
+        huge = [ctx.encrypt(secret, rs.randint(0, 2, 5000).astype(bool)) for _ in range(2)]
+        with pytest.raises(Exception):
+            _capture_without_warmup(thr, lambda: vm.gate_nand(huge[0], huge[1]))
+        thr.synchronize()
+        assert vm.gate_nand(cs[0], cs[1]) == vm.gate_nand(cs[0], cs[1])      # the context still works
+
+
+def _capture_without_warmup(thr, circuit):
+    import torch
+    from nufhe_amd import _lib
+    stream = thr._torch_stream
+    _lib.call("nufhe_ctx_pin_scratch", thr.handle, 1)
+    try:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(stream):
+            with torch.cuda.graph(graph, stream=stream):
+                circuit()
+    finally:
+        _lib.call("nufhe_ctx_pin_scratch", thr.handle, -1)
+
+
+def test_key_image_header_refuses_a_foreign_image(env):
+    """round-4 advisor: NTT and FFT key images have the same size; the header tells them apart at the C boundary"""
+    import torch
+    import nufhe_amd
+    from nufhe_amd import _lib
+    from nufhe_amd.api_low_level import NuFHEParameters
+    from nufhe_amd.bootstrap import NativeCloudKey
+    from nufhe_amd.device import ptr
+    thr = env['thr']
+    params, image = env['cloud_key'].device_image()
+    assert bytes(image[:8].cpu().numpy().tobytes()) == b'NUFHEIMG'
+    fft = NativeCloudKey(thr, params.in_out_params.size, 'FFT', 1)
+    assert fft.image_bytes() == image.numel()
+    with pytest.raises(ValueError, match='cloud-key image holds'):
+        fft.import_image(image)
+    k2 = NativeCloudKey(thr, params.in_out_params.size, 'NTT', 2)
+    with pytest.raises(ValueError):
+        k2.import_image(image)
+    junk = torch.zeros_like(image)
+    ntt = NativeCloudKey(thr, params.in_out_params.size, 'NTT', 1)
+    with pytest.raises(ValueError, match='not a cloud-key image'):
+        ntt.import_image(junk)
+    stale = image.clone()
+    stale[8:12] = torch.tensor([3, 0, 0, 0], dtype=torch.uint8, device=stale.device)      # another ABI version
+    with pytest.raises(ValueError, match='ABI version 3'):
+        ntt.import_image(stale)
+    ntt.import_image(image)                                                                # the real one loads
+    for k in (fft, k2, ntt):
+        k.destroy()
+
+
+def test_gather_waits_for_work_queued_on_the_destination(env, orc):
+    """round-4 advisor: nufhe_gather's copies run on the SOURCE streams; they must wait for what is already queued on
+    the destination's stream (the destination block may be recycled while its last user is still in flight).  A long
+    kernel chain that WRITES the destination buffer is queued on dst's stream, then the gather: the gathered bytes must
+    survive."""
+    import torch
+    import nufhe_amd
+    from nufhe_amd import _lib
+    from nufhe_amd.device import DeviceThread
+    s_dst, s_src = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(s_dst):
+        dst_thr = DeviceThread(0)
+    with torch.cuda.stream(s_src):
+        src_thr = DeviceThread(0)
+        src = torch.arange(1 << 20, dtype=torch.int32, device='cuda')
+    src_thr.synchronize()
+    with torch.cuda.stream(s_dst):
+        dst = torch.empty(1 << 20, dtype=torch.int32, device='cuda')
+        big = torch.ones(1 << 26, dtype=torch.float32, device='cuda')
+        for _ in range(40):
+            big.mul_(1.0000001)                       # tens of milliseconds of queued work on dst's stream ...
+        dst.fill_(-1)                                 # ... whose last kernel writes the destination buffer
+    offs = (ctypes.c_size_t * 1)(0)
+    srcs = (ctypes.c_void_p * 1)(src_thr.handle.value)
+    ptrs = (ctypes.c_void_p * 1)(src.data_ptr())
+    sizes = (ctypes.c_size_t * 1)(4 << 20)
+    _lib.check(_lib.lib().nufhe_gather(dst_thr.handle, ctypes.c_void_p(dst.data_ptr()), offs, srcs, ptrs, sizes, 1))
+    with torch.cuda.stream(s_dst):
+        got = dst.clone()
+    dst_thr.synchronize()
+    assert (got == src).all()
+    assert torch.cuda.current_device() == 0

@@ -610,6 +610,48 @@ def test_bench_gpus_2_starts_its_own_ranks():
     assert d['parity']['variances_differing'] == 0
     assert abs(d['value'] - 2 * 256 * 1000.0 / d['ms_per_step']) < 1e-6 * d['value']
     assert d['config']['workload'].endswith('(BASELINE config 4)')
+    _check_multi_rank_line(d, 2)
+
+
+def _check_multi_rank_line(d, world):
+    """what an N > 1 line must carry to be judged like the N = 1 line: cpu_baseline (timed in this run), roofline with the
+    per-rank kernel times / clocks, parity over every rank"""
+    cb = d['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['unit'] == 'gates/s' and cb['value'] > 0 and cb['cores'] >= world
+    assert cb['ranks'] == world and 'sample' in cb and cb['reference_python']['measured_in_this_run'] is False
+    roof = d['roofline']
+    assert roof['kernel_ms'] > 0 and 0 < roof['frac'] and 'streaming_model' in roof
+    pr = roof['per_rank']
+    assert len(pr['kernel_ms']) == world and len(pr['clock_ghz_in_kernel']) == world
+    assert 0 < pr['kernel_ms_min'] <= roof['kernel_ms'] <= pr['kernel_ms_max']
+    assert all(c > 1.0 for c in pr['clock_ghz_in_kernel'])
+    assert d['gather']['verified'] is True and d['gather_ms'] > 0
+
+
+def test_bench_gpus_8_rehearsal_on_one_gpu():
+    """The driver's 8-GPU command, rehearsed: `python bench.py --gpus 8` (literal form, no launcher) with eight ranks
+    sharing this box's one GPU over the gloo test route.  The line must be complete -- n_gpus 8, parity from all 8
+    ranks with 0 differing words, cpu_baseline, roofline incl. per-rank kernel times -- and arrive in bounded time, so
+    that the first run on 8 physical GPUs (RCCL instead of gloo, nothing else changes) is not lost to a formality."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NUFHE_BENCH_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '3', '--warmup', '1',
+           '--bits', '256', '--no-extra']
+    t0 = time.time()
+    d = _bench_line(subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root))
+    wall = time.time() - t0
+    assert d['n_gpus'] == 8 and d['correct'] and d['scaling'] == 'weak' and d['steps'] == 3
+    assert d['parity']['ranks_reporting'] == 8 and d['parity']['differing'] == 0
+    assert d['parity']['words'] == 8 * 256 * 501 and d['parity']['variances_differing'] == 0
+    assert len(d['per_rank_ms_per_step']) == 8
+    assert abs(d['value'] - 8 * 256 * 1000.0 / d['ms_per_step']) < 1e-6 * d['value']
+    _check_multi_rank_line(d, 8)
+    assert wall < 300, wall
 
 
 def test_bench_refuses_more_rccl_ranks_than_gpus():
@@ -647,6 +689,21 @@ def test_multi_gpu_example_gpus_2_starts_its_own_ranks(via_host):
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
     assert 'multi-GPU gate_nand OK: 45 bits over 2 GPU(s), gathered to rank 0 over gloo' in proc.stdout
     assert ('key via host pickle' if via_host else 'key as one device broadcast') in proc.stdout
+
+
+def test_multi_gpu_example_gpus_8_rehearsal():
+    """`python examples/multi_gpu.py --gpus 8 --bits 2048`: the reference example's shape (examples/multi_gpu.py:86-114) at
+    the node's rank count, eight ranks sharing this GPU over gloo, key replicated by one broadcast of its image"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in (
+        'NUFHE_BENCH_BACKEND', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    cmd = [sys.executable, os.path.join(root, 'examples', 'multi_gpu.py'), '--gpus', '8', '--bits', '2048',
+           '--backend', 'gloo']
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
+    assert 'multi-GPU gate_nand OK: 2048 bits over 8 GPU(s), gathered to rank 0 over gloo' in proc.stdout
 
 
 def test_cloud_key_device_image_round_trip(env, orc):
