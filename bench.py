@@ -628,9 +628,13 @@ def main():
             checks["clock_ok"] = bool(live_clock >= 2.2 or args.transform == "FFT" and live_clock >= 2.0)
         roof["self_check"] = checks
         if per_rank_kernel is not None:
-            km, cg = per_rank_kernel["kernel_ms"], per_rank_kernel["clock_ghz_in_kernel"]
+            km = per_rank_kernel["kernel_ms"]
+            # (the in-kernel clock exists for the wave-per-bit kernels only: batches of more than 4 x CUs bits per GPU)
+            cg = per_rank_kernel["clock_ghz_in_kernel"] = [c if c > 0 else None for c in per_rank_kernel["clock_ghz_in_kernel"]]
+            have = [c for c in cg if c is not None]
             per_rank_kernel.update({
-                "kernel_ms_min": min(km), "kernel_ms_max": max(km), "clock_ghz_min": min(cg), "clock_ghz_max": max(cg),
+                "kernel_ms_min": min(km), "kernel_ms_max": max(km),
+                "clock_ghz_min": min(have) if have else None, "clock_ghz_max": max(have) if have else None,
                 "streaming_frac_min": a_kernel / (max(km) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "streaming_frac_max": a_kernel / (min(km) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "note": "one entry per rank, rank order; `roofline` above is rank 0's kernel; the slowest rank sets `value`"})

@@ -135,7 +135,7 @@ def lwe_desc(a, b, cv, size):
     """Builds the C descriptor of an LWE sample batch from (a [B, size], b [B], cv [B]) device
     tensors that are 2D/1D views with a contiguous last axis (stride-0 batch axes broadcast)."""
     assert a.dim() == 2 and b.dim() == 1
-    if a.shape[1] != size or (a.shape[1] > 1 and a.stride(1) != 1):
+    if a.shape[1] != size or (a.shape[0] > 0 and a.shape[1] > 1 and a.stride(1) != 1):     # (an empty batch has no layout)
         raise ValueError("LWE mask array must have a contiguous last axis of length %d" % size)
     if cv is not None:
         assert cv.dim() == 1 and (cv.stride(0) == b.stride(0) or cv.shape[0] <= 1)

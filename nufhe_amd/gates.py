@@ -267,10 +267,15 @@ def gate_batch(thr, cloud_key, jobs, perf_params=None):
     thr.check_stream()
     descs = (_lib.NufheGateJob * max(1, len(jobs)))()
     flats = []
-    for i, job in enumerate(jobs):
+    count = 0
+    for job in jobs:
         name, result, args = job[0], job[1], job[2:]
         check_shape(result, *args)
         _check_sizes(cloud_key, result, *args)
+        if int(numpy.prod(result.shape)) == 0:
+            continue                                  # an empty gate: nothing to run (the C entry point allows it, too)
+        i = count
+        count += 1
         res = _Flat(result, result.shape, output=True)
         ops = [_Flat(x, result.shape) for x in args]
         flats.append((res, ops))                      # the temporaries of strided views must outlive the call
@@ -283,6 +288,6 @@ def gate_batch(thr, cloud_key, jobs, perf_params=None):
         else:
             d.kind = _lib.JOB_BINARY
             d.c0, d.pa, d.pb = [int(v) for v in BINARY_GATES[name]]
-    _lib.call("nufhe_gate_batch", thr.handle, cloud_key._native.handle, descs, len(jobs), int(MU))
+    _lib.call("nufhe_gate_batch", thr.handle, cloud_key._native.handle, descs, count, int(MU))
     for res, _ in flats:
         res.writeback()

@@ -280,7 +280,7 @@ def test_gather_waits_for_work_queued_on_the_destination(env, orc):
     with torch.cuda.stream(s_src):
         src_thr = DeviceThread(0)
         src = torch.arange(1 << 20, dtype=torch.int32, device='cuda')
-    src_thr.synchronize()
+        src_thr.synchronize()
     with torch.cuda.stream(s_dst):
         dst = torch.empty(1 << 20, dtype=torch.int32, device='cuda')
         big = torch.ones(1 << 26, dtype=torch.float32, device='cuda')
@@ -294,6 +294,6 @@ def test_gather_waits_for_work_queued_on_the_destination(env, orc):
     _lib.check(_lib.lib().nufhe_gather(dst_thr.handle, ctypes.c_void_p(dst.data_ptr()), offs, srcs, ptrs, sizes, 1))
     with torch.cuda.stream(s_dst):
         got = dst.clone()
-    dst_thr.synchronize()
+        dst_thr.synchronize()
     assert (got == src).all()
     assert torch.cuda.current_device() == 0

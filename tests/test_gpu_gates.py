@@ -624,7 +624,8 @@ def _check_multi_rank_line(d, world):
     pr = roof['per_rank']
     assert len(pr['kernel_ms']) == world and len(pr['clock_ghz_in_kernel']) == world
     assert 0 < pr['kernel_ms_min'] <= roof['kernel_ms'] <= pr['kernel_ms_max']
-    assert all(c > 1.0 for c in pr['clock_ghz_in_kernel'])
+    # (256 bits per rank run the small-batch kernels, which carry no clock probe: None there, > 1 GHz where measured)
+    assert all(c is None or c > 1.0 for c in pr['clock_ghz_in_kernel'])
     assert d['gather']['verified'] is True and d['gather_ms'] > 0
 
 
