@@ -51,11 +51,13 @@ def _profile_json(name):
 def pmc_traffic(transform, gate, bits):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes
     (profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command,
-    corrected as MI355X_MICROARCH.md prescribes); None for configurations that were not measured."""
-    entry = (_profile_json("pmc_traffic.json") or {}).get(transform)
-    if entry is None or gate != "nand" or bits != 4096:
-        return None
-    return entry["hbm_bytes_per_launch"]
+    corrected as MI355X_MICROARCH.md prescribes: NAND at 4096 bits from tools/profile.sh, MUX at 4096 and NAND at 2048
+    bits from tools/pmc_traffic_configs.sh); None for configurations that were not measured."""
+    table = _profile_json("pmc_traffic.json") or {}
+    entry = (table.get("configs") or {}).get("%s/%s/%d" % (transform, gate, bits))      # tools/pmc_traffic_configs.sh
+    if entry is None and gate == "nand" and bits == 4096:
+        entry = table.get(transform)                                                     # tools/profile.sh
+    return None if entry is None else entry["hbm_bytes_per_launch"]
 
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X vector fp64: 256 CUs x 128 flop/clk x 2.4 GHz (v_fma_f64 measured

@@ -42,7 +42,8 @@ typedef struct nufhe_ctx nufhe_ctx;            /* one GPU + one stream; replaces
 typedef struct nufhe_cloudkey nufhe_cloudkey;  /* device copies of BootstrapKey + LweKeyswitchKey */
 
 /* Bumped whenever a struct passed by value or an entry point's signature changes (3: nufhe_lwe gained `size`;
- * 4: output-stride checks, key images; 5: key images carry a header, nufhe_gate_batch, nufhe_ctx_pin_scratch).  A
+ * 4: output-stride checks, key images; 5: key images carry a header, nufhe_gate_batch, nufhe_ctx_pin_scratch,
+ * nufhe_ctx_get_tuning / _set_tuning).  A
  * binding compares nufhe_abi_version() with the macro of the header it was written against before the first real
  * call (nufhe_amd/_lib.py does). */
 #define NUFHE_ABI_VERSION 5
@@ -184,8 +185,10 @@ int nufhe_gate_mux(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe_
  * the per-gate entry points (int32 wraparound sums are order independent).
  *   kind NUFHE_JOB_BINARY: result = KS(BS_mu((0, c0) + pa * a + pb * b)); `c` is ignored.
  *   kind NUFHE_JOB_MUX:    result = a ? b : c; c0 / pa / pb are ignored (the reference's constants are used), mu must be 2^29.
- * nbits may differ per job (0 allowed).  Jobs must not write a result that another job of the SAME batch reads.  Not
- * capturable into a hipGraph (the job tables are uploaded from the host per call). */
+ * nbits may differ per job (0 allowed).  Every operand of every job is read (step 1) before any result is written
+ * (step 4): a job may name its own or another job's result buffer as an operand and sees the values from BEFORE the
+ * call (carry = MUX(same, carry, a) in place is fine); two jobs must not write the same buffer.  Not capturable into a
+ * hipGraph (the job tables are uploaded from the host per call). */
 #define NUFHE_JOB_BINARY 0
 #define NUFHE_JOB_MUX 1
 typedef struct {
@@ -292,9 +295,30 @@ int nufhe_ctx_set_pair_max_bits(nufhe_ctx *ctx, long bits);
  * is kept a second time in the half-ring layout (made on first use).  0 switches back to the 4-wave team kernel (default
  * 1).  Identical results either way. */
 int nufhe_ctx_set_team8(nufhe_ctx *ctx, int enable);
+/* Where the switch points come from.  Every batch-size switch above is a figure in ciphertext bits that the library
+ * derives from the DEVICE when the context is created: a table of measured switch points keyed by (gcnArchName, CU
+ * count) -- MI355X / gfx950 / 256 CUs today -- and, for a part without an entry, the measured part's bits-per-CU ratios
+ * scaled by its CU count (`measured` = 0).  nufhe_ctx_get_tuning reads the context's set; nufhe_ctx_set_tuning replaces
+ * it (NULL: back to the table).  The per-switch calls above stay what they were: overrides on top of this set
+ * (negative = no override).  No switch changes a result: the kernel families are bit-identical (NTT) / identical on
+ * every tested input (FFT); tests/test_gpu_gates.py::test_every_switch_point_plus_minus_one_bit. */
+typedef struct {
+    long team_max_bits;        /* NTT: up to here the 8- / 4- / 3-wavefronts-per-bit kernels */
+    long team_max_bits_fft;    /* FFT: the 4- / 3-wavefront kernels up to here */
+    long pair_max_bits_ntt;    /* NTT, k = 1: up to here 2 wavefronts per bit; 0 = off */
+    long pair_max_bits_fft;    /* FFT, k = 1: up to here 2 wavefronts per bit; 0 = off */
+    long ks_mfma_min_bits;     /* keyswitch on the matrix cores for batches ABOVE this size (mode 1) */
+    int32_t ring_k2;           /* k = 2: the 3-wavefront kernel without a partial-sum buffer above the team limit */
+    int32_t k2_roomy_ratio_pct;/* NTT k = 2 wave kernels: duration of a 6 x CUs round over a 4 x CUs round, percent */
+    int32_t measured;          /* out: 1 = (arch_name, num_cus) has a table entry */
+    int32_t num_cus;           /* out */
+    char arch_name[64];        /* out: gcnArchName */
+} nufhe_tuning;
+int nufhe_ctx_get_tuning(nufhe_ctx *ctx, nufhe_tuning *tuning);
+int nufhe_ctx_set_tuning(nufhe_ctx *ctx, const nufhe_tuning *tuning);
 /* Keyswitch kernel.  The matrix-core kernel writes the digit selection as a one-hot int8 matrix product against the
  * key split into four signed byte planes (v_mfma_i32_16x16x64_i8); the LDS-window kernel gathers key rows by digit.
- * mode 1 (default): matrix cores for batches of more than 2 x CUs bits (0.30 vs 1.15 ms at 4096 bits), the LDS-window
+ * mode 1 (default): matrix cores for batches of more than tuning.ks_mfma_min_bits (2 x CUs) bits (0.30 vs 1.15 ms at 4096 bits), the LDS-window
  * kernel below (it is ahead up to there); 0: never; 2: always.  Both are exact integer sums mod 2^32:
  * identical results. */
 int nufhe_ctx_set_keyswitch_mfma(nufhe_ctx *ctx, int mode);

@@ -44,6 +44,22 @@ class NufheGateJob(ctypes.Structure):
     ]
 
 
+class NufheTuning(ctypes.Structure):
+    """nufhe_tuning of include/nufhe_hip.h (batch-size switch points of one context)"""
+    _fields_ = [
+        ("team_max_bits", ctypes.c_long),
+        ("team_max_bits_fft", ctypes.c_long),
+        ("pair_max_bits_ntt", ctypes.c_long),
+        ("pair_max_bits_fft", ctypes.c_long),
+        ("ks_mfma_min_bits", ctypes.c_long),
+        ("ring_k2", ctypes.c_int32),
+        ("k2_roomy_ratio_pct", ctypes.c_int32),
+        ("measured", ctypes.c_int32),
+        ("num_cus", ctypes.c_int32),
+        ("arch_name", ctypes.c_char * 64),
+    ]
+
+
 JOB_BINARY = 0
 JOB_MUX = 1
 
@@ -92,6 +108,8 @@ PROTOTYPES = {
     "nufhe_gate_mux": [_vp, _vp, NufheLwe, NufheLwe, NufheLwe, NufheLwe, _long],
     "nufhe_gate_batch": [_vp, _vp, ctypes.POINTER(NufheGateJob), _int, _i32],
     "nufhe_ctx_pin_scratch": [_vp, _int],
+    "nufhe_ctx_get_tuning": [_vp, ctypes.POINTER(NufheTuning)],
+    "nufhe_ctx_set_tuning": [_vp, ctypes.POINTER(NufheTuning)],
     "nufhe_lwe_phase": [_vp, _vp, _long, _vp, _long, _vp, _long, _vp, _i32, _long, _int],
     "nufhe_t32_to_phase": [_vp, _vp, _vp, _long, ctypes.c_uint32],
     "nufhe_shift_torus_polynomial": [_vp, _vp, _vp, _vp, _long, _long, _long, _int, _int, _int],

@@ -48,6 +48,8 @@ struct Scratch {
 struct nufhe_ctx {
     int device = 0;
     int num_cus = 256;         // of this context's device
+    char arch_name[64] = {0};  // gcnArchName of this context's device
+    BrTuning tuning;           // batch-size switches derived from (arch_name, num_cus) at creation (kernels.h)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     u64 *d_tw1f = nullptr;
@@ -69,9 +71,9 @@ struct nufhe_ctx {
     struct TableSlot { void *h = nullptr; void *d = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; bool used = false; };
     TableSlot tables[4];
     unsigned table_next = 0;
-    long team_max_bits = -1;   // batches up to this size use the 4-waves-per-bit kernel; -1 = default (launch_bootstrap)
-    long pair_max_bits = -1;   // above that and up to this size: the 2-waves-per-bit kernel; -1 = 4 x CUs
-    int ks_mfma = 1;           // keyswitch on the matrix cores (k_keyswitch_mfma): 0 never, 1 batches > 2 x CUs bits, 2 always
+    long team_max_bits = -1;   // nufhe_ctx_set_team_max_bits override of tuning.team_max_bits; -1 = none
+    long pair_max_bits = -1;   // nufhe_ctx_set_pair_max_bits override of the pair / ring switches; -1 = none
+    int ks_mfma = 1;           // keyswitch on the matrix cores (k_keyswitch_mfma): 0 never, 1 batches > tuning.ks_mfma_min_bits, 2 always
     bool profile = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // [0..2]: begin / after bootstrap / end of the LAST profiled gate
     hipEvent_t ev_dst = nullptr;                               // nufhe_gather: "everything queued on this stream so far"
@@ -234,7 +236,7 @@ int run_keyswitch(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result, 
     P.j_per_block = pick_j_per_block(nbits, P.input_size, ctx->num_cus);
     // the matrix-core kernel walks the whole key per 64-bit tile (0.23 ms at any size up to 1024 bits, 0.30 ms at 4096);
     // the LDS-window kernel is ahead up to 2 x CUs bits (0.08 ms for one bit, 0.23 ms at 512, 0.34 ms at 768)
-    P.ks_planes = (ctx->ks_mfma == 2 || (ctx->ks_mfma == 1 && nbits > 2L * ctx->num_cus)) ? key->d_ks_planes : nullptr;
+    P.ks_planes = (ctx->ks_mfma == 2 || (ctx->ks_mfma == 1 && nbits > ctx->tuning.ks_mfma_min_bits)) ? key->d_ks_planes : nullptr;
     P.digits_t = nullptr;
     if (P.ks_planes) {
         rc = ensure(ctx, ctx->ks_digits, (size_t)P.input_size * ((nbits + 63) & ~63L) * sizeof(unsigned short));
@@ -330,7 +332,8 @@ int nufhe_ctx_create(int device, void *stream, int own_stream, nufhe_ctx **out)
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_ftw2, FFT_TW2_ELEMS * sizeof(cplx));
     if (e == hipSuccess) e = hipMemcpy(ctx->d_ftw1, g1.data(), FFT_TW1_ELEMS * sizeof(cplx), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ctx->d_ftw2, g2.data(), FFT_TW2_ELEMS * sizeof(cplx), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = kernels_init_device(&ctx->num_cus);
+    if (e == hipSuccess) e = kernels_init_device(&ctx->num_cus, ctx->arch_name, sizeof(ctx->arch_name));
+    if (e == hipSuccess) ctx->tuning = br_tuning_for(ctx->arch_name, ctx->num_cus);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev[3]);      // nufhe_gather; ev[0..2] alias slots of the profile ring
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_dst, hipEventDisableTiming);
     if (e != hipSuccess) {
@@ -831,6 +834,22 @@ int nufhe_lwe_trivial_const(nufhe_ctx *ctx, nufhe_lwe res, int32_t mu, long nbit
     return NUFHE_OK;
 }
 
+// the context's tuning with the legacy per-switch overrides applied (nufhe_ctx_set_team_max_bits: an explicit value
+// counts half for the FFT kernels; nufhe_ctx_set_pair_max_bits: the NTT k = 1 limit itself, for FFT / k = 2 an on-off switch)
+static BrTuning effective_tuning(const nufhe_ctx *ctx)
+{
+    BrTuning T = ctx->tuning;
+    if (ctx->team_max_bits >= 0) {
+        T.team_max_bits = ctx->team_max_bits;
+        T.team_max_bits_fft = ctx->team_max_bits / 2;
+    }
+    if (ctx->pair_max_bits >= 0) {
+        T.pair_max_bits_ntt = ctx->pair_max_bits;
+        if (ctx->pair_max_bits == 0) { T.pair_max_bits_fft = 0; T.ring_k2 = 0; }
+    }
+    return T;
+}
+
 // key, tables and kernel-family preparation common to every fused bootstrap launch of `total` rotations
 static void prepare_launch(nufhe_ctx *ctx, nufhe_cloudkey *key, BrLaunch &P, long total, i32 mu)
 {
@@ -841,7 +860,7 @@ static void prepare_launch(nufhe_ctx *ctx, nufhe_cloudkey *key, BrLaunch &P, lon
     {
         // smallest batches of the NTT / k = 1 path run the half-ring team kernel: it reads the key in its own layout (a
         // permutation of the same field elements), converted once per key on first use
-        const long team_limit = ctx->team_max_bits < 0 ? (long)ctx->num_cus : ctx->team_max_bits;
+        const long team_limit = effective_tuning(ctx).team_max_bits;
         if (ctx->team8 && key->transform == NUFHE_TRANSFORM_NTT && key->mask_size == 1 && total <= team_limit) {
             // (one-time, per key: 33 MB and one conversion launch.)  A failure here is not an error of the gate: the
             // launch falls back to the 4-wave team kernel, which reads the ordinary layout (P.bk_half stays NULL).
@@ -896,8 +915,7 @@ static int run_gate(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result
         HIP_TRY(hipMemsetAsync(ctx->d_clock, 0, CLOCK_PROBE_WORDS * sizeof(unsigned long long), ctx->stream));
         HIP_TRY(hipEventRecord(pe[0], ctx->stream));
     }
-    HIP_TRY(launch_bootstrap(P, key->transform, key->mask_size, ctx->team_max_bits, ctx->pair_max_bits, ctx->num_cus,
-                             ctx->stream));
+    HIP_TRY(launch_bootstrap(P, key->transform, key->mask_size, effective_tuning(ctx), ctx->stream));
     if (prof) HIP_TRY(hipEventRecord(pe[1], ctx->stream));
     if (keyswitch) {
         const i32 *ea = (const i32 *)ctx->ext_a.ptr, *eb = (const i32 *)ctx->ext_b.ptr;
@@ -1110,8 +1128,7 @@ int nufhe_gate_batch(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_gate_job *
         HIP_TRY(hipMemsetAsync(ctx->d_clock, 0, CLOCK_PROBE_WORDS * sizeof(unsigned long long), ctx->stream));
         HIP_TRY(hipEventRecord(pe[0], ctx->stream));
     }
-    HIP_TRY(launch_bootstrap(P, key->transform, key->mask_size, ctx->team_max_bits, ctx->pair_max_bits, ctx->num_cus,
-                             ctx->stream));
+    HIP_TRY(launch_bootstrap(P, key->transform, key->mask_size, effective_tuning(ctx), ctx->stream));
     if (prof) HIP_TRY(hipEventRecord(pe[1], ctx->stream));
     if (mux_bits > 0)
         HIP_TRY(launch_batch_mux_fold((i32 *)ctx->ext_a.ptr, (i32 *)ctx->ext_b.ptr, d_outs, (int)outs.size(), out_bits, ext, MU8,
@@ -1354,6 +1371,39 @@ int nufhe_ctx_set_pair_max_bits(nufhe_ctx *ctx, long bits)
     int rc = check_ctx(ctx);
     if (rc) return rc;
     ctx->pair_max_bits = bits;
+    return NUFHE_OK;
+}
+
+int nufhe_ctx_get_tuning(nufhe_ctx *ctx, nufhe_tuning *out)
+{
+    if (!ctx || !out) return fail(NUFHE_EINVAL, "null argument");
+    const BrTuning &T = ctx->tuning;
+    memset(out, 0, sizeof(*out));
+    out->team_max_bits = T.team_max_bits; out->team_max_bits_fft = T.team_max_bits_fft;
+    out->pair_max_bits_ntt = T.pair_max_bits_ntt; out->pair_max_bits_fft = T.pair_max_bits_fft;
+    out->ks_mfma_min_bits = T.ks_mfma_min_bits;
+    out->ring_k2 = T.ring_k2; out->k2_roomy_ratio_pct = T.k2_roomy_ratio_pct;
+    out->measured = T.measured; out->num_cus = T.num_cus;
+    snprintf(out->arch_name, sizeof(out->arch_name), "%s", ctx->arch_name);
+    return NUFHE_OK;
+}
+
+int nufhe_ctx_set_tuning(nufhe_ctx *ctx, const nufhe_tuning *in)
+{
+    if (!ctx) return fail(NUFHE_EINVAL, "null context");
+    if (!in) {                                   // NULL: back to what the device table says
+        ctx->tuning = br_tuning_for(ctx->arch_name, ctx->num_cus);
+        return NUFHE_OK;
+    }
+    if (in->team_max_bits < 0 || in->team_max_bits_fft < 0 || in->pair_max_bits_ntt < 0 || in->pair_max_bits_fft < 0 ||
+        in->ks_mfma_min_bits < 0 || in->k2_roomy_ratio_pct <= 0)
+        return fail(NUFHE_EINVAL, "negative switch point");
+    BrTuning &T = ctx->tuning;
+    T.team_max_bits = in->team_max_bits; T.team_max_bits_fft = in->team_max_bits_fft;
+    T.pair_max_bits_ntt = in->pair_max_bits_ntt; T.pair_max_bits_fft = in->pair_max_bits_fft;
+    T.ks_mfma_min_bits = in->ks_mfma_min_bits;
+    T.ring_k2 = in->ring_k2 != 0; T.k2_roomy_ratio_pct = in->k2_roomy_ratio_pct;
+    T.measured = 0;                              // (num_cus and arch_name are the device's, not the caller's)
     return NUFHE_OK;
 }
 

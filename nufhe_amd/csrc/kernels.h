@@ -105,10 +105,26 @@ struct LweView {
     long a_stride, b_stride;
 };
 
-hipError_t kernels_init_device(int *num_cus);
+// Batch-size switches of launch_bootstrap / the keyswitch, in ciphertext bits (rotations of one launch).  They come from
+// the DEVICE, not from the box the kernels were tuned on: br_tuning_for() looks the part up in a table of measured
+// switch points keyed by (gcnArchName, CU count) and, for a part that was never measured, scales the ratios of the
+// measured one by its CU count (`measured` = 0 then).  The context holds one (nufhe_ctx_get_tuning / _set_tuning).
+struct BrTuning {
+    long team_max_bits;        // NTT: batches up to here run 8 (k = 1, half rings) / 4 / 3 (k = 2) waves per bit
+    long team_max_bits_fft;    // FFT: the 4 / 3-wave kernels up to here (k = 1: only when the pair kernel is off)
+    long pair_max_bits_ntt;    // NTT k = 1: above the team limit and up to here 2 waves per bit; 0 = off
+    long pair_max_bits_fft;    // FFT k = 1: up to here 2 waves per bit; 0 = off
+    int ring_k2;               // k = 2: 3 waves per bit without a partial-sum buffer above the team limit; 0 = wave kernels
+    int k2_roomy_ratio_pct;    // NTT k = 2 wave kernels: time of a 6 x CUs round over a 4 x CUs round, in percent
+    long ks_mfma_min_bits;     // keyswitch on the matrix cores for batches ABOVE this many bits
+    int measured;              // 1: this (architecture, CU count) has an entry in the table
+    int num_cus;
+};
+BrTuning br_tuning_for(const char *arch_name, int num_cus);
+
+hipError_t kernels_init_device(int *num_cus, char *arch_name, size_t arch_len);
 // transform: 0 = NTT, 1 = FFT
-hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, long team_max_bits, long pair_max_bits, int num_cus,
-                            hipStream_t stream);
+hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, const BrTuning &T, hipStream_t stream);
 hipError_t launch_ff_op(u64 *out, const u64 *a, const u64 *b, const u64 *c, const u64 *d, const u64 *e, int op,
                         int shift, long count, hipStream_t stream);
 hipError_t launch_ks_make(i32 *ks_b, float *ks_cv, const i32 *noises_a, const i32 *noises_b, const i32 *in_key,

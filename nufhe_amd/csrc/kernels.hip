@@ -2,6 +2,7 @@
 // Device-side bodies live in ff.h / ntt1024.h / blind_rotate.h / keyswitch.h; this file adds the
 // __global__ wrappers (LDS carving, wave -> bit mapping) and the launch geometry.
 #include <hip/hip_runtime.h>
+#include <string.h>
 
 #define BR_KEY_BUFFER_LOADS 1   /* key words through buffer loads (blind_rotate.h, br_key_stream): every row pointer in this unit is wave-uniform */
 #include "blind_rotate.h"
@@ -1303,13 +1304,19 @@ static const size_t kFftLds = FTABLE_LDS_BYTES + (size_t)FFT_WAVES_PER_BLOCK * W
 // per-device one-time setup: the fused kernels use up to ~156 KiB of dynamic LDS (> the 64 KiB default cap)
 // *num_cus receives the CU count of the CURRENT device (kept per context: contexts on devices of
 // different sizes may coexist in one process)
-hipError_t kernels_init_device(int *num_cus)
+hipError_t kernels_init_device(int *num_cus, char *arch_name, size_t arch_len)
 {
-    int dev = 0, cus = 0;
-    *num_cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-        *num_cus = cus;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    hipError_t pe = hipGetDevice(&dev);
+    if (pe == hipSuccess) pe = hipGetDeviceProperties(&prop, dev);
+    if (pe != hipSuccess) return pe;
+    if (prop.multiProcessorCount <= 0) return hipErrorInvalidDevice;
+    *num_cus = prop.multiProcessorCount;
+    if (arch_name && arch_len) {
+        strncpy(arch_name, prop.gcnArchName, arch_len - 1);
+        arch_name[arch_len - 1] = 0;
+    }
     hipError_t e = hipFuncSetAttribute((const void *)k_bootstrap<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(1));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(2));
@@ -1392,17 +1399,50 @@ static BrLaunch br_sub_launch(const BrLaunch &P, long g0, long g1)
     return Q;
 }
 
-hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, long team_max_bits, long pair_max_bits,
-                            int num_cus, hipStream_t stream)
+// Measured switch points (MI355X, 256 CUs: profiles/r0*_latency_*.json, r04f_small_batch_kernel_stats.csv,
+// r02q_k2_timing.txt): team kernels up to 1 x CUs bits (one bit per CU at a time), NTT pair kernel up to 4 x CUs, FFT
+// pair kernel up to 3 x CUs, matrix-core keyswitch above 2 x CUs, k = 2 round-time ratio 1.56.  They are all "bits per
+// CU" figures, so a part with another CU count starts from the same ratios; a part that is measured gets its own row.
+struct TuningRow { const char *arch; int cus; double team, pair_ntt, pair_fft, ks_mfma; int k2_ratio_pct; };
+static const TuningRow kTuningTable[] = {
+    {"gfx950", 256, 1.0, (double)BRP_MAX_PAIRS, (double)BRFP_MAX_PAIRS, 2.0, 156},
+};
+
+BrTuning br_tuning_for(const char *arch_name, int num_cus)
+{
+    const TuningRow *row = &kTuningTable[0];      // unknown part: the ratios of the measured one
+    int measured = 0;
+    for (const TuningRow &r : kTuningTable) {
+        // gcnArchName carries feature suffixes ("gfx950:sramecc+:xnack-")
+        const size_t n = strlen(r.arch);
+        if (arch_name && strncmp(arch_name, r.arch, n) == 0 && (arch_name[n] == 0 || arch_name[n] == ':') && r.cus == num_cus) {
+            row = &r;
+            measured = 1;
+        }
+    }
+    BrTuning T;
+    T.num_cus = num_cus;
+    T.team_max_bits = (long)(row->team * num_cus);
+    T.team_max_bits_fft = (long)(row->team * num_cus);
+    T.pair_max_bits_ntt = (long)(row->pair_ntt * num_cus);
+    T.pair_max_bits_fft = (long)(row->pair_fft * num_cus);
+    T.ring_k2 = 1;
+    T.k2_roomy_ratio_pct = row->k2_ratio_pct;
+    T.ks_mfma_min_bits = (long)(row->ks_mfma * num_cus);
+    T.measured = measured;
+    return T;
+}
+
+hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, const BrTuning &T, hipStream_t stream)
 {
     if (P.nbits_total == 0) return hipSuccess;
-    // defaults of the batch-size switches (negative = default): NTT: team kernel up to 1 x CUs bits, then the pair
-    // (k = 1, up to 4 x CUs) / ring (k = 2, any size) kernel; FFT k = 1: pair kernel up to 3 x CUs (team kernel up to
-    // 1 x CUs when the pair switch is 0), k = 2: team kernel up to 1 x CUs, then the ring kernel (an explicit team value
-    // counts half for the FFT kernels, see nufhe_hip.h)
-    if (pair_max_bits < 0) pair_max_bits = (long)BRP_MAX_PAIRS * num_cus;
-    if (team_max_bits < 0)
-        team_max_bits = (transform == 0) ? (long)num_cus : 2L * num_cus;
+    // the switches (BrTuning, kernels.h): NTT: team kernel up to team_max_bits, then the pair (k = 1) / ring (k = 2, any
+    // size) kernel; FFT k = 1: pair kernel up to pair_max_bits_fft (team kernel up to team_max_bits_fft when the pair
+    // switch is 0), k = 2: team kernel, then the ring kernel
+    const int num_cus = T.num_cus;
+    const long team_max_bits = transform == 0 ? T.team_max_bits : 2 * T.team_max_bits_fft;    // (FFT: halved again below)
+    const long pair_max_bits = transform == 0 ? (mask_size == 1 ? T.pair_max_bits_ntt : (long)T.ring_k2)
+                                              : (mask_size == 1 ? T.pair_max_bits_fft : (long)T.ring_k2);
     if (transform == 0 && mask_size == 1 && P.nbits_total <= team_max_bits && P.bk_half != nullptr) {
         // smallest batches: 8 waves per bit (two per digit transform, half rings), one bit per CU at a time
         hipError_t e8 = launch_team8(P, stream);
@@ -1429,8 +1469,7 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, lon
                                stream, H);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return e;
-            return launch_bootstrap(br_sub_launch(P, head, P.nbits_total), transform, mask_size, team_max_bits,
-                                    pair_max_bits, num_cus, stream);
+            return launch_bootstrap(br_sub_launch(P, head, P.nbits_total), transform, mask_size, T, stream);
         }
         const int w = br_pick_waves(P.nbits_total, BR_WAVES_K(1), num_cus);
         hipLaunchKernelGGL(k_bootstrap<1>, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), br_lds_bytes(1, w), stream, P);
@@ -1449,14 +1488,14 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, lon
         // rounds of 6 x CUs bits at 2 waves per SIMD (42 ms, spills) or rounds of 4 x CUs bits at 1 wave per SIMD
         // (27 ms, no spills): measured ratio 1.56
         const long r6 = (P.nbits_total + 6L * num_cus - 1) / (6L * num_cus), r4 = (P.nbits_total + 4L * num_cus - 1) / (4L * num_cus);
-        if (100 * r4 < 156 * r6) {
+        if (100 * r4 < (long)T.k2_roomy_ratio_pct * r6) {
             const int w = br_pick_waves(P.nbits_total, BR_K2_ROOMY_WAVES, num_cus);
             hipLaunchKernelGGL(k_bootstrap_k2_roomy, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), br_lds_bytes(2, w), stream, P);
         } else {
             const int w = br_pick_waves(P.nbits_total, BR_WAVES_K(2), num_cus);
             hipLaunchKernelGGL(k_bootstrap<2>, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), br_lds_bytes(2, w), stream, P);
         }
-    } else if (transform == 1 && mask_size == 1 && pair_max_bits > 0 && P.nbits_total <= (long)BRFP_MAX_PAIRS * num_cus) {
+    } else if (transform == 1 && mask_size == 1 && pair_max_bits > 0 && P.nbits_total <= pair_max_bits) {
         // small and medium batches, FFT: 2 waves per bit, 1 to 3 pairs per work-group (ahead of the 4-wave team kernel at
         // every size: 2.9 vs 3.0 ms up to 1 x CUs bits, 3.1 ms up to 2 x CUs, 3.7 ms up to 3 x CUs); any non-zero pair
         // limit enables it

@@ -94,6 +94,17 @@ class DeviceThread:
     def synchronize(self):
         _lib.call("nufhe_ctx_synchronize", self.handle)
 
+    def tuning(self):
+        """The batch-size switch points of this context as a dict (``nufhe_ctx_get_tuning``): derived from the device
+        (architecture name + CU count) when the context was created; ``measured`` says whether that part has an entry
+        in the library's table of measured switch points."""
+        import ctypes
+        t = _lib.NufheTuning()
+        _lib.check(_lib.lib().nufhe_ctx_get_tuning(self.handle, ctypes.byref(t)))
+        out = {name: getattr(t, name) for name, _ in t._fields_}
+        out['arch_name'] = out['arch_name'].decode()
+        return out
+
     def release(self):
         if not self._released and self.handle:
             for key in list(self._cloud_keys):    # ~100 MB of device memory each: free them with the context

@@ -249,7 +249,8 @@ def gate_batch(thr, cloud_key, jobs, perf_params=None):
     nufhe/operators_integer.py:64-95).  ``jobs`` = [(name, result, a, b) | ('gate_mux', result, a, b, c), ...] with the
     gate functions' own names and argument order.  A gate of up to one bit per CU takes as long as one bit (500
     dependent blind-rotation steps), so N small independent gates batched this way take the time of ONE instead of N.
-    Results are word-for-word those of the individual gate calls.  No job may read another job's result buffer.
+    Results are word-for-word those of the individual gate calls.  All operands are read before any result is written:
+    a job may update one of its operands in place (``carry = MUX(same, carry, a)``); two jobs must not share a result.
     With ``single_kernel_bootstrap == False`` the gates simply run one after the other (the reference's mode).
     """
     import ctypes

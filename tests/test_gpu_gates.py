@@ -247,6 +247,56 @@ def test_small_batch_team_kernel_equals_wave_kernel(env, orc):
         _lib.call("nufhe_ctx_set_team8", thr.handle, 1)
 
 
+def test_every_switch_point_plus_minus_one_bit(env, orc):
+    """The kernel-family switch points come from the device (nufhe_ctx_get_tuning: a table keyed by architecture name +
+    CU count); at every one of them, and one bit either side, the gate's words equal the oracle's (first and last 6 bits)
+    -- NAND and, where the MUX's doubled rotation count crosses the boundary instead, MUX.  Then the same with every
+    switch point moved (nufhe_ctx_set_tuning): results do not depend on where the switches sit."""
+    import ctypes
+    from nufhe_amd import _lib
+    H = env['H']; thr = env['thr']; vm = env['vm']; ck = env['ck']; lwe_key = env['lwe_key']
+    t = thr.tuning()
+    assert t['measured'] == 1 and t['arch_name'].startswith('gfx950') and t['num_cus'] > 0
+    cus = t['num_cus']
+    assert t['team_max_bits'] == cus and t['pair_max_bits_ntt'] == 4 * cus and t['ks_mfma_min_bits'] == 2 * cus
+    points = sorted({t['team_max_bits'], t['pair_max_bits_ntt'], t['ks_mfma_min_bits'], 8 * cus, 8 * cus + t['team_max_bits']})
+    top = max(points) + 1
+    rng = orc.DeterministicRNG(31)
+    ms = [rng.uniform_bool((top,)).astype(bool) for _ in range(3)]
+    cs = [orc.encrypt(rng, lwe_key, m) for m in ms]
+    ds = [H.ciphertext_from_arrays(thr, c) for c in cs]
+
+    def ends(c, size):
+        idx = numpy.r_[0:6, size - 6:size]
+        return tuple(x[idx] for x in c)
+
+    def check(sizes, mux_sizes):
+        for size in sizes:
+            got = H.ct_arrays(vm.gate_nand(ds[0][:size], ds[1][:size]))
+            exp = orc.gate('gate_nand', ck, ends(cs[0], size), ends(cs[1], size))
+            for g, e in zip(ends(got, size), exp):
+                assert (g == e).all(), ('nand', size)
+        for size in mux_sizes:
+            got = H.ct_arrays(vm.gate_mux(ds[0][:size], ds[1][:size], ds[2][:size]))
+            exp = orc.gate_mux(ck, ends(cs[0], size), ends(cs[1], size), ends(cs[2], size))
+            for g, e in zip(ends(got, size), exp):
+                assert (g == e).all(), ('mux', size)
+
+    sizes = sorted({p + d for p in points for d in (-1, 0, 1)})
+    mux_sizes = sorted({p // 2 + d for p in (t['team_max_bits'], t['pair_max_bits_ntt']) for d in (0, 1)})
+    check(sizes, mux_sizes)
+    moved = _lib.NufheTuning()
+    _lib.check(_lib.lib().nufhe_ctx_get_tuning(thr.handle, ctypes.byref(moved)))
+    moved.team_max_bits = 37; moved.pair_max_bits_ntt = 201; moved.ks_mfma_min_bits = 100
+    try:
+        _lib.check(_lib.lib().nufhe_ctx_set_tuning(thr.handle, ctypes.byref(moved)))
+        assert thr.tuning()['measured'] == 0 and thr.tuning()['team_max_bits'] == 37
+        check([36, 37, 38, 100, 101, 200, 201, 202], [18, 19, 100, 101])
+    finally:
+        _lib.check(_lib.lib().nufhe_ctx_set_tuning(thr.handle, None))
+    assert thr.tuning() == t
+
+
 def test_replacing_the_key_drops_the_half_ring_copy(env, orc):
     """The 8-waves-per-bit kernel reads a second, lazily converted copy of the bootstrapping key; uploading other key
     material into the same handle must invalidate it.  A small gate (makes the copy), a different key uploaded, the same

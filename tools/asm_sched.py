@@ -29,6 +29,13 @@ Safety rules of the rescheduler:
     states are filled with `s_nop`.
 
 Use:  python tools/asm_sched.py in.s out.s [--kernel SYMBOL ...] [--min-run N] [--window W] [--stats] [--prio-toggle N]
+
+STATUS (round 5): QUARANTINED.  The reordering mode produces WRONG CODE on the current kernel (0 of 384,768 gate words
+right after the round-4 register-range fix exposed more dependences than the list scheduler honours; NOTES.md, round 4
+follow-up) and nobody has debugged its dependence graph since.  What is used is the PARSER (`Inst`, `regs_of`,
+`split_operands`: tools/isa_mix.py, tools/isa_lines.py count issue classes with it).  The command line therefore refuses
+to rewrite assembly unless --i-know-it-is-broken is given (tests/test_cabi_and_host.py::test_asm_sched_is_quarantined);
+--prio-toggle (no reordering, inserts s_setprio only) is not affected.
 """
 import argparse
 import collections
@@ -479,7 +486,12 @@ def main():
     ap.add_argument('--stats', action='store_true')
     ap.add_argument('--prio-toggle', type=int, default=0, help='only insert alternating s_setprio every N instructions')
     ap.add_argument('--prio-levels', default='1,0')
+    ap.add_argument('--i-know-it-is-broken', action='store_true',
+                    help='run the reordering mode although it is known to produce wrong code (see the module docstring)')
     args = ap.parse_args()
+    if not args.prio_toggle and not args.i_know_it_is_broken:
+        sys.exit("asm_sched.py: the reordering mode is quarantined (wrong code on the current kernels, see the module "
+                 "docstring); pass --i-know-it-is-broken to run it anyway.  The parser classes stay importable.")
     kernels = set(args.kernel) or {'_Z11k_bootstrapILi1EEv8BrLaunch'}
     lines = open(args.src).read().split('\n')
     if args.prio_toggle:
