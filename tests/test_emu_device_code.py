@@ -242,6 +242,7 @@ def test_bootstrap_wave_body_mask_size_2(orc):
     MU = 2**29
     a0 = rs.randint(-2**31, 2**31, size=n, dtype=numpy.int32)
     a1 = rs.randint(-2**31, 2**31, size=n, dtype=numpy.int32)
+    a0[2] = 0; a1[2] = 0                                           # bara = 0 -> a step every wave of a team must skip alike
     b0 = rs.randint(-2**31, 2**31, size=1, dtype=numpy.int32)
     b1 = rs.randint(-2**31, 2**31, size=1, dtype=numpy.int32)
     ta = (a0 + a1).astype(numpy.int32); tb = (numpy.int32(-MU) + b0 + b1).astype(numpy.int32)
@@ -252,6 +253,8 @@ def test_bootstrap_wave_body_mask_size_2(orc):
     # the 3-wave team variant (small batches): same bits
     ga, gb = emu.bootstrap_bit(bki, n, (a0, b0), 1, (a1, b1), 1, -MU, MU, mask_size=2, ring=True)
     assert (ga == ea[0]).all() and gb == eb[0]        # the 3-wave ring variant (no partial-sum buffer)
+    ga, gb = emu.bootstrap_bit(bki, n, (a0, b0), 1, (a1, b1), 1, -MU, MU, mask_size=2, quad=True)
+    assert (ga == ea[0]).all() and gb == eb[0]        # the 4-wave quad variant (hand-over counters, no barrier)
     ga, gb = emu.bootstrap_bit(bki, n, (a0, b0), 1, (a1, b1), 1, -MU, MU, mask_size=2, team=True)
     assert (ga == ea[0]).all() and gb == eb[0]
 
