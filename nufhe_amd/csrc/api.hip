@@ -1402,7 +1402,7 @@ int nufhe_ctx_set_tuning(nufhe_ctx *ctx, const nufhe_tuning *in)
     T.team_max_bits = in->team_max_bits; T.team_max_bits_fft = in->team_max_bits_fft;
     T.pair_max_bits_ntt = in->pair_max_bits_ntt; T.pair_max_bits_fft = in->pair_max_bits_fft;
     T.ks_mfma_min_bits = in->ks_mfma_min_bits;
-    T.ring_k2 = in->ring_k2 < 0 ? 0 : (in->ring_k2 > 2 ? 2 : in->ring_k2); T.k2_roomy_ratio_pct = in->k2_roomy_ratio_pct;
+    T.ring_k2 = in->ring_k2 != 0; T.k2_roomy_ratio_pct = in->k2_roomy_ratio_pct;
     T.measured = 0;                              // (num_cus and arch_name are the device's, not the caller's)
     return NUFHE_OK;
 }

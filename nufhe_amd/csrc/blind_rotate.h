@@ -1084,202 +1084,3 @@ FF_FN void brr_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSou
     if (tid == 0) *out_b = lds.acc[K * 1024];
 }
 
-// ------------------------------------------------------------------------------------------
-// Quad variant, K = 2: K + 2 = FOUR wavefronts per bit -- K + 1 "forward" waves and ONE "inverse" wave -- two teams per
-// work-group, so that every SIMD of the CU holds exactly two waves (the ring team above puts 6 waves on 4 SIMDs: the
-// two waves that have a SIMD to themselves wait half of every step for the four that share one).
-//   forward wave f  owns input polynomial f: (X^a - 1) ACC_f, its two digit transforms, and for every output mo the
-//                   canonical partial sum  x0 (*) BK[f][0][mo] + x1 (*) BK[f][1][mo], published through LDS
-//   inverse wave    for mo = 0..K: adds the K + 1 partial sums of output mo, transforms back, updates ACC_mo
-// There is no barrier in the loop, only hand-over counters in LDS (all monotonic, one writer each; s = number of the
-// executed step, 1-based -- steps with a = 0 are skipped by every wave alike):
-//   ready[f][mo] = s   forward wave f has published its partial sum of output mo of step s
-//   taken[mo]    = s   the inverse wave has read all partial sums of output mo of step s (their buffers are free)
-//   done[mo]     = s   ACC_mo holds the result of step s
-// Forward wave f starts step s + 1 as soon as done[f] = s -- while the inverse wave is still busy with the later
-// outputs of step s.  Each forward wave has TWO hand-over buffers: `pbuf` (outputs 0 and 2) and its own exchange
-// buffer (output 1: free between its transforms of step s and those of step s + 1, which wait for taken[1] = s).
-// Canonical partial sums and exact field additions: bit-identical to every other kernel family.
-// ------------------------------------------------------------------------------------------
-#define BRQ_FLAG_WORDS 20      /* per team: ready[3][3], taken[3], done[3], arrive[4], spare */
-struct BrQuadLds {
-    u64 *xbuf;                 // this wave's exchange buffer (NTT_XBUF_ELEMS u64)
-    u64 *pbuf;                 // forward waves: second hand-over buffer (1024 u64); inverse wave: unused
-    const u64 *part_pbuf;      // inverse wave: pbuf of forward wave 0 (wave f: + f * 1024 elements) ...
-    const u64 *part_xbuf;      // ... and its exchange buffer (wave f: + f * NTT_XBUF_ELEMS)
-    i32 *acc;                  // [3][1024], shared by the team
-    uint16_t *bara;            // [BR_MAX_LWE], shared
-    const u64 *tw1x;
-    const u64 *tw1i;
-    u32 *flags;                // BRQ_FLAG_WORDS words of this team, zeroed before the team starts
-    BrPace pace;
-};
-
-// hand-over counters: one wave publishes (after its LDS writes), another waits.  Device: LDS words through
-// address-space-3 volatile accesses (ds_write_b32 / ds_read_b32; the LDS unit executes one wave's instructions in
-// order, so the counter lands behind the data it announces); emulator: lane 0 decides for its wave between two fibre
-// switches, so that all lanes of the waiting wave leave the loop at the same sync point.
-FF_FN void brq_publish(u32 *flag, u32 value, int lane)
-{
-    WAVE_SYNC();
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef __attribute__((address_space(3))) volatile u32 lds_vu32;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    *(lds_vu32 *)flag = value;
-    (void)lane;
-#else
-    if (lane == 0) *flag = value;
-#endif
-}
-
-#if defined(NUFHE_EMU)
-extern u32 g_emu_wave_decision[8];
-int emu_wave_index();
-#endif
-
-FF_FN void brq_wait(const u32 *flag, u32 value, int lane)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef __attribute__((address_space(3))) volatile u32 lds_vu32;
-    (void)lane;
-    while ((i32)((u32)WAVE_UNIFORM((int)*(const lds_vu32 *)flag) - value) < 0) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#elif defined(NUFHE_EMU)
-    const int wv = emu_wave_index();
-    for (;;) {
-        if (lane == 0) g_emu_wave_decision[wv] = (i32)(*flag - value) >= 0;
-        WAVE_SYNC();
-        const bool ok = g_emu_wave_decision[wv] != 0;
-        WAVE_SYNC();
-        if (ok) break;
-    }
-#else
-    (void)flag; (void)value; (void)lane;
-#endif
-}
-
-// one step of forward wave F (input polynomial F) -- s = number of this executed step (1-based)
-template <int K>
-FF_FN void brq_forward_step(u32 a, const u64 *row, const BrQuadLds &lds, const NttLane &L, int f, u32 s)
-{
-    static_assert(K == 2, "the hand-over schedule is written for three outputs");
-    const int lane = L.lane;
-    u32 *ready = lds.flags + 3 * f, *taken = lds.flags + 9, *done = lds.flags + 12;
-    brq_wait(done + f, s - 1, lane);           // ACC_f of the previous step
-    u64 x0[16], x1[16];
-    {
-        u32 T[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const u32 j = (u32)(lane + 64 * r);
-            const u32 t = (j - a) & 2047u;
-            const u32 v = (u32)lds.acc[f * 1024 + (t & 1023u)];
-            T[r] = ((t & 1024u) ? 0u - v : v) - (u32)lds.acc[f * 1024 + j];     // (X^a - 1) ACC_f
-        }
-        brq_wait(taken + 1, s - 1, lane);      // the exchange buffer still holds the partial sum of output 1 of step s - 1
-        i32 dg[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) dg[r] = br_digit<0>(T[r]);
-        ntt_forward_small_l4(x0, dg, lds.xbuf, lds.tw1x, L);
-#pragma unroll
-        for (int r = 0; r < 16; r++) dg[r] = br_digit<1>(T[r]);
-        ntt_forward_small_l4(x1, dg, lds.xbuf, lds.tw1x, L);
-    }
-    const u64 *rw = row + (long)f * 2 * (K + 1) * BK_POLY_ELEMS;      // polynomial (f, d, mo): ((f * 2 + d) * (K + 1) + mo)
-    auto partial_to = [&](u64 *buf, int mo) {
-        u64 ps[16];
-        br_mac2_one(ps, x0, x1, rw + (long)mo * BK_POLY_ELEMS, rw + (long)(K + 1 + mo) * BK_POLY_ELEMS, lane);
-#pragma unroll
-        for (int r = 0; r < 16; r++) buf[r * 64 + lane] = ps[r];
-    };
-    brq_wait(taken + 2, s - 1, lane);          // pbuf: output 2 of step s - 1 has been read
-    partial_to(lds.pbuf, 0);
-    brq_publish(ready + 0, s, lane);
-    WAVE_SYNC();                               // every lane is done with the exchange buffer
-    partial_to(lds.xbuf, 1);
-    brq_publish(ready + 1, s, lane);
-    brq_wait(taken + 0, s, lane);              // pbuf: output 0 of this step has been read
-    partial_to(lds.pbuf, 2);
-    brq_publish(ready + 2, s, lane);
-}
-
-// one step of the inverse wave
-template <int K>
-FF_FN void brq_inverse_step(const BrQuadLds &lds, const NttLane &L, u32 s)
-{
-    const int lane = L.lane;
-    u32 *taken = lds.flags + 9, *done = lds.flags + 12;
-#pragma unroll 1
-    for (int mo = 0; mo <= K; mo++) {
-        const int which = mo == 1 ? 1 : 0;     // outputs 0 and 2 come through pbuf, output 1 through the exchange buffer
-        u64 sum[16];
-#pragma unroll 1
-        for (int f = 0; f <= K; f++) {
-            brq_wait(lds.flags + 3 * f + mo, s, lane);
-            const u64 *src = which ? lds.part_xbuf + f * NTT_XBUF_ELEMS : lds.part_pbuf + f * 1024;
-            if (f == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) sum[r] = src[r * 64 + lane];
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; r++) sum[r] = ff_add(sum[r], src[r * 64 + lane]);
-            }
-        }
-        brq_publish(taken + mo, s, lane);
-        u32 c[16];
-        ntt_inverse_l4_i32(c, sum, lds.xbuf, lds.tw1i, L);
-#pragma unroll
-        for (int r = 0; r < 16; r++) lds.acc[mo * 1024 + lane + 64 * r] += (i32)(r == 0 ? c[r] : 0u - c[r]);
-        brq_publish(done + mo, s, lane);
-    }
-}
-
-// Whole bootstrap body of wave `role` (0..K: forward wave of that input polynomial, K + 1: inverse wave) of a quad team
-// for one bit; `tid` = 64 * (index of the wave in its team) + lane; out_a has K * 1024 entries.
-template <int K>
-FF_FN void brq_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSource &s1, i32 c0, long bit,
-                         const u64 *bk, int n, i32 mu, const BrQuadLds &lds, const NttLane &L, int role, int tid)
-{
-    constexpr int THREADS = 64 * (K + 2);
-    const int lane = L.lane;
-    u32 *arrive = lds.flags + 15;
-    for (int i = tid; i < n; i += THREADS) {
-        u32 v = 0;
-        if (s0.p) v += (u32)s0.p * (u32)s0.a[bit * s0.a_stride + i];
-        if (s1.p) v += (u32)s1.p * (u32)s1.a[bit * s1.a_stride + i];
-        lds.bara[i] = (uint16_t)br_modswitch(v);
-    }
-    u32 vb = (u32)c0;
-    if (s0.p) vb += (u32)s0.p * (u32)s0.b[bit * s0.b_stride];
-    if (s1.p) vb += (u32)s1.p * (u32)s1.b[bit * s1.b_stride];
-    const u32 barb = br_modswitch(vb);
-    // ACC = (0, ..., 0, X^(2N - barb) * mu)  (bootstrap.py:176-182)
-    for (int j = tid; j < 1024; j += THREADS) {
-        const u32 t = ((u32)j + barb) & 2047u;
-#pragma unroll
-        for (int m = 0; m < K; m++) lds.acc[m * 1024 + j] = 0;
-        lds.acc[K * 1024 + j] = (t < 1024u) ? mu : (i32)(0u - (u32)mu);
-    }
-    // team barrier: the prologue of all four waves is in LDS
-    brq_publish(arrive + (tid >> 6), 1u, lane);
-    for (int o = 0; o < K + 2; o++) brq_wait(arrive + o, 1u, lane);
-    u32 s = 0;
-    for (int i = 0; i < n; i++) {
-        br_pace(lds.pace, (u32)i);
-        const u32 a = WAVE_UNIFORM((u32)lds.bara[i]);
-        if (a == 0) continue;
-        s++;
-        if (role <= K) brq_forward_step<K>(a, bk + (long)i * BK_ROW_ELEMS_K(K), lds, L, role, s);
-        else brq_inverse_step<K>(lds, L, s);
-    }
-    br_pace_done(lds.pace);
-    // everything the inverse wave wrote is visible: ACC holds the result of the last executed step
-    for (int mo = 0; mo <= K; mo++) brq_wait(lds.flags + 12 + mo, s, lane);
-    // sample extraction (tlwe_cpu.py:55-58)
-    for (int j = tid; j < K * 1024; j += THREADS) {
-        const int m = j >> 10, jj = j & 1023;
-        const u32 v = (u32)lds.acc[j];
-        out_a[m * 1024 + ((1024 - jj) & 1023)] = (i32)(jj == 0 ? v : 0u - v);
-    }
-    if (tid == 0) *out_b = lds.acc[K * 1024];
-}

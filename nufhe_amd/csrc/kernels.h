@@ -114,8 +114,7 @@ struct BrTuning {
     long team_max_bits_fft;    // FFT: the 4 / 3-wave kernels up to here (k = 1: only when the pair kernel is off)
     long pair_max_bits_ntt;    // NTT k = 1: above the team limit and up to here 2 waves per bit; 0 = off
     long pair_max_bits_fft;    // FFT k = 1: up to here 2 waves per bit; 0 = off
-    int ring_k2;               // k = 2 above the team limit: 2 = 4 waves per bit (NTT; quad kernel), 1 = 3 waves per bit (ring
-                               // kernel; the FFT path's multi-wave kernel for any non-zero value), 0 = one wave per bit
+    int ring_k2;               // k = 2: 3 waves per bit without a partial-sum buffer above the team limit; 0 = wave kernels
     int k2_roomy_ratio_pct;    // NTT k = 2 wave kernels: time of a 6 x CUs round over a 4 x CUs round, in percent
     long ks_mfma_min_bits;     // keyswitch on the matrix cores for batches ABOVE this many bits
     int measured;              // 1: this (architecture, CU count) has an entry in the table

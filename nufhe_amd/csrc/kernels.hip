@@ -256,47 +256,6 @@ __global__ __launch_bounds__(192 * BRR_MAX_TEAMS, 2) void k_bootstrap_ring_k2(Br
                      P.job[job].c0, bit, (const u64 *)P.bk, P.n, P.mu, lds, L, w, team_sync);
 }
 
-// k = 2, throughput kernel: FOUR waves per bit (three forward waves + one inverse wave, blind_rotate.h brq_*), two teams
-// per work-group = two waves on every SIMD.  LDS: tables | pacing words | hand-over counters | per team: ACC 12 KiB,
-// bara 1 KiB, 4 exchange buffers, 3 hand-over buffers of 8 KiB.  The roles are dealt so that the two inverse waves of a
-// work-group sit on different SIMDs (waves w and w + 4 share one): team 0 wave j has role j, team 1 wave j role (j + 2) & 3.
-#define QUAD_PBUF_BYTES (1024 * 8)
-#define QUAD_LDS_BYTES (3 * 1024 * 4 + WAVE_BARA_BYTES + 4 * WAVE_XBUF_BYTES + 3 * QUAD_PBUF_BYTES)
-#define QUAD_FLAG_BYTES 256
-#define BRQ_MAX_TEAMS 2
-static_assert(TABLE_LDS_BYTES + BR_PACE_BYTES + QUAD_FLAG_BYTES + BRQ_MAX_TEAMS * QUAD_LDS_BYTES <= 160 * 1024, "LDS budget of the quad kernel");
-static_assert(BRQ_MAX_TEAMS * BRQ_FLAG_WORDS * 4 <= QUAD_FLAG_BYTES, "hand-over counters");
-__global__ __launch_bounds__(256 * BRQ_MAX_TEAMS, 2) void k_bootstrap_quad_k2(BrLaunch P)
-{
-    if (threadIdx.x < QUAD_FLAG_BYTES / 4) ((u32 *)(g_smem + TABLE_LDS_BYTES + BR_PACE_BYTES))[threadIdx.x] = 0;
-    load_tables((const u64 *)P.tw_a, (const u64 *)P.tw_b);          // (ends with the work-group barrier)
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int team = wave >> 2, j = wave & 3;
-    const int role = (j + 2 * team) & 3;                             // 0..2: forward wave of that polynomial, 3: inverse wave
-    const long gbit = (long)blockIdx.x * (blockDim.x >> 8) + team;   // teams per group chosen at launch
-    const BrPace pace = carve_pace(g_smem + TABLE_LDS_BYTES, wave, gbit < P.nbits_total);
-    if (gbit >= P.nbits_total) return;                               // (all four waves of the team)
-    const int job = gbit >= P.bits_per_job ? 1 : 0;
-    const long bit = gbit - (job ? P.bits_per_job : 0);
-    unsigned char *base = g_smem + TABLE_LDS_BYTES + BR_PACE_BYTES + QUAD_FLAG_BYTES + team * QUAD_LDS_BYTES;
-    unsigned char *xbufs = base + 3 * 1024 * 4 + WAVE_BARA_BYTES;               // [role 0..3]
-    unsigned char *pbufs = xbufs + 4 * WAVE_XBUF_BYTES;                          // [role 0..2]
-    BrQuadLds lds;
-    lds.acc = (i32 *)base;
-    lds.bara = (uint16_t *)(base + 3 * 1024 * 4);
-    lds.xbuf = (u64 *)(xbufs + role * WAVE_XBUF_BYTES);
-    lds.pbuf = (u64 *)(pbufs + (role < 3 ? role : 0) * QUAD_PBUF_BYTES);
-    lds.part_pbuf = (const u64 *)pbufs;
-    lds.part_xbuf = (const u64 *)xbufs;
-    lds.tw1x = (const u64 *)g_smem;
-    lds.tw1i = (const u64 *)g_smem + 1024;
-    lds.flags = (u32 *)(g_smem + TABLE_LDS_BYTES + BR_PACE_BYTES) + team * BRQ_FLAG_WORDS;
-    lds.pace = pace;
-    const NttLane L = ntt_lane_init(lane);
-    brq_bootstrap<2>(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, P.job[job].s0, P.job[job].s1,
-                     P.job[job].c0, bit, (const u64 *)P.bk, P.n, P.mu, lds, L, role, 64 * j + lane);
-}
-
 template <int K>
 __global__ __launch_bounds__(64 * BR_WAVES_K(K), K == 1 ? 2 : 1) void k_blind_rotate_accum(
     i32 *__restrict__ accum, const u64 *__restrict__ bk, const i32 *__restrict__ bara, long bara_stride,
@@ -1365,9 +1324,6 @@ hipError_t kernels_init_device(int *num_cus, char *arch_name, size_t arch_len)
     e = hipFuncSetAttribute((const void *)k_bootstrap_ring_k2, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(TABLE_LDS_BYTES + BR_PACE_BYTES + BRR_MAX_TEAMS * RING2_LDS_BYTES));
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void *)k_bootstrap_quad_k2, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(TABLE_LDS_BYTES + BR_PACE_BYTES + QUAD_FLAG_BYTES + BRQ_MAX_TEAMS * QUAD_LDS_BYTES));
-    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap_k2_roomy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)br_lds_bytes(2, BR_K2_ROOMY_WAVES));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_keyswitch_a, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KS_LDS_BYTES);
@@ -1521,12 +1477,6 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, con
         // small batch, k = 2: 3 waves per bit (one team per CU at a time)
         hipError_t e3 = launch_team_k2(P, stream);
         if (e3 != hipSuccess) return e3;
-    } else if (transform == 0 && mask_size == 2 && T.ring_k2 == 2) {
-        // k = 2 beyond the team kernel: 4 waves per bit (3 forward + 1 inverse), 2 teams per work-group, two waves on
-        // every SIMD: rounds of 2 x CUs bits
-        const long teams = P.nbits_total > num_cus ? BRQ_MAX_TEAMS : 1;
-        hipLaunchKernelGGL(k_bootstrap_quad_k2, dim3(blocks_for(P.nbits_total, (int)teams)), dim3(256 * (unsigned)teams),
-                           TABLE_LDS_BYTES + BR_PACE_BYTES + QUAD_FLAG_BYTES + (size_t)teams * QUAD_LDS_BYTES, stream, P);
     } else if (transform == 0 && mask_size == 2 && pair_max_bits > 0) {
         // k = 2 beyond the team kernel: 3 waves per bit without the partial-sum buffer, 2 teams per work-group: rounds of
         // 2 x CUs bits in 12.3 ms (the wave kernels below: 4 x CUs in 27 ms / 6 x CUs in 43 ms); any non-zero pair limit

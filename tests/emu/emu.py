@@ -101,8 +101,7 @@ def bk_to_half(bk_internal):
     return out
 
 
-def bootstrap_bit(bk_internal, n, src0, p0, src1, p1, c0, mu, mask_size=1, team=False, pair=False, ring=False, team8=False,
-                  quad=False):
+def bootstrap_bit(bk_internal, n, src0, p0, src1, p1, c0, mu, mask_size=1, team=False, pair=False, ring=False, team8=False):
     """src = (a [n], b scalar array [1]); returns (ext_a [1024 * mask_size], ext_b).
     team=True runs the 4-wave (k = 2: 3-wave) team variant of the body, pair=True the 2-wave variant (k = 1)."""
     a0 = numpy.ascontiguousarray(src0[0], numpy.int32); b0 = numpy.ascontiguousarray(src0[1], numpy.int32).reshape(1)
@@ -115,8 +114,6 @@ def bootstrap_bit(bk_internal, n, src0, p0, src1, p1, c0, mu, mask_size=1, team=
         fn = lib().emu_bootstrap_bit_pair
     if ring:
         fn = lib().emu_bootstrap_bit_ring_k2          # mask_size 2 only
-    if quad:
-        fn = lib().emu_bootstrap_bit_quad_k2          # mask_size 2 only: 3 forward waves + 1 inverse wave
     if team8:
         fn = lib().emu_bootstrap_bit_team8            # bk_internal must be in the half-ring layout (bk_to_half)
     fn(_p(out_a, c_i32p), _p(out_b, c_i32p), _p(bk_internal, c_u64p), ctypes.c_int(n),

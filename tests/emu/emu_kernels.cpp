@@ -293,39 +293,6 @@ extern "C" void emu_bootstrap_bit_ring_k2(i32 *out_a, i32 *out_b, const u64 *bk_
     });
 }
 
-// the 4-wave quad variant for tlwe_mask_size = 2 (blind_rotate.h, brq_*): three forward waves + one inverse wave, no
-// barrier in the loop, only hand-over counters (brq_publish / brq_wait; the emulator's wait is a per-wave decision by
-// lane 0 between two fibre switches, so that the lanes of a wave stay in lock step)
-u32 g_emu_wave_decision[8];
-int emu_wave_index() { return emu_lane() / 64; }
-extern "C" void emu_bootstrap_bit_quad_k2(i32 *out_a, i32 *out_b, const u64 *bk_internal, int n,
-                                          const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,
-                                          i32 c0, i32 mu)
-{
-    tables();
-    std::vector<u64> xbuf(4 * NTT_XBUF_ELEMS), pbuf(3 * 1024);
-    std::vector<i32> accbuf(3 * 1024);
-    std::vector<uint16_t> bara(BR_MAX_LWE);
-    std::vector<u32> flags(BRQ_FLAG_WORDS, 0);
-    BrSource s0{a0, b0, 0, 0, p0}, s1{a1, b1, 0, 0, p1};
-    emu_run_team(4, [&](int w, int lane) {
-        const int role = (w + 1) & 3;          // any dealing of the roles over the waves must work
-        BrQuadLds lds;
-        lds.xbuf = xbuf.data() + role * NTT_XBUF_ELEMS;
-        lds.pbuf = pbuf.data() + (role < 3 ? role : 0) * 1024;
-        lds.part_pbuf = pbuf.data();
-        lds.part_xbuf = xbuf.data();
-        lds.acc = accbuf.data();
-        lds.bara = bara.data();
-        lds.tw1x = g_tw1x;
-        lds.tw1i = g_tw1i;
-        lds.flags = flags.data();
-        lds.pace = BrPace{nullptr, nullptr};
-        NttLane L = ntt_lane_init(lane);
-        brq_bootstrap<2>(out_a, out_b, s0, s1, c0, 0, bk_internal, n, mu, lds, L, role, 64 * w + lane);
-    });
-}
-
 extern "C" void emu_bootstrap_bit(i32 *out_a, i32 *out_b, const u64 *bk_internal, int n,
                                   const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,
                                   i32 c0, i32 mu)

@@ -253,8 +253,6 @@ def test_bootstrap_wave_body_mask_size_2(orc):
     # the 3-wave team variant (small batches): same bits
     ga, gb = emu.bootstrap_bit(bki, n, (a0, b0), 1, (a1, b1), 1, -MU, MU, mask_size=2, ring=True)
     assert (ga == ea[0]).all() and gb == eb[0]        # the 3-wave ring variant (no partial-sum buffer)
-    ga, gb = emu.bootstrap_bit(bki, n, (a0, b0), 1, (a1, b1), 1, -MU, MU, mask_size=2, quad=True)
-    assert (ga == ea[0]).all() and gb == eb[0]        # the 4-wave quad variant (hand-over counters, no barrier)
     ga, gb = emu.bootstrap_bit(bki, n, (a0, b0), 1, (a1, b1), 1, -MU, MU, mask_size=2, team=True)
     assert (ga == ea[0]).all() and gb == eb[0]
 
