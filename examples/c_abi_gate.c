@@ -7,7 +7,8 @@
  *   gcc -std=c99 -O2 -I include examples/c_abi_gate.c -L nufhe_amd -lnufhe_hip -Wl,-rpath,$PWD/nufhe_amd -o c_abi_gate
  *   ./c_abi_gate in.bin out.bin
  *
- * in.bin  : int32 n, int32 nbits, int32 transform (0 NTT / 1 FFT), int32 gate (0 NAND, 1 MUX)
+ * in.bin  : int32 n, int32 nbits, int32 transform (0 NTT / 1 FFT), int32 gate (0 NAND, 1 MUX, 2 = ONE nufhe_gate_batch call:
+ *           NAND on the first half of the bits and MUX on the second half, two jobs of different kinds in one launch)
  *           bootstrapping key, reference format: 8 bytes x [n][2][2][2][1024]   (uint64 NTT / complex128 [..][512] FFT)
  *           keyswitch key, reference format: int32 a[1024][8][4][n], int32 b[1024][8][4], float cv[1024][8][4]
  *           three ciphertext batches: int32 a[nbits][n], int32 b[nbits]  (the third is only read by MUX)
@@ -90,8 +91,27 @@ int main(int argc, char **argv)
     const int32_t MU = (int32_t)1 << 29;
     if (gate == 0)
         CHECK(nufhe_gate_binary(ctx, key, ct[3], ct[0], ct[1], MU, -1, -1, MU, nbits));     /* NAND, gates.py:81-121 */
-    else
+    else if (gate == 1)
         CHECK(nufhe_gate_mux(ctx, key, ct[3], ct[0], ct[1], ct[2], nbits));                  /* a ? b : c, gates.py:600-664 */
+    else {
+        /* two independent gates of different kinds as one launch: views of the same buffers, shifted to each job's bits */
+        const long half = nbits / 2;
+        nufhe_gate_job jobs[2];
+        nufhe_lwe v[4];
+        for (int i = 0; i < 4; i++) {
+            v[i] = ct[i];
+            v[i].a += half * n; v[i].b += half; v[i].cv += half;
+        }
+        jobs[0].kind = NUFHE_JOB_BINARY; jobs[0].c0 = MU; jobs[0].pa = -1; jobs[0].pb = -1; jobs[0].nbits = half;
+        jobs[0].result = ct[3]; jobs[0].a = ct[0]; jobs[0].b = ct[1]; jobs[0].c = ct[2];
+        jobs[1].kind = NUFHE_JOB_MUX; jobs[1].c0 = 0; jobs[1].pa = 0; jobs[1].pb = 0; jobs[1].nbits = nbits - half;
+        jobs[1].result = v[3]; jobs[1].a = v[0]; jobs[1].b = v[1]; jobs[1].c = v[2];
+        CHECK(nufhe_gate_batch(ctx, key, jobs, 2, MU));
+        nufhe_tuning t;
+        CHECK(nufhe_ctx_get_tuning(ctx, &t));
+        printf("switch points of %s (%d CUs, measured %d): team %ld, pair %ld, matrix-core keyswitch above %ld bits\n",
+               t.arch_name, (int)t.num_cus, (int)t.measured, t.team_max_bits, t.pair_max_bits_ntt, t.ks_mfma_min_bits);
+    }
     /* a second, chained gate on the device results: NOT(result) = lwe_negate, then back (exercises nufhe_lwe_linear) */
     CHECK(nufhe_lwe_linear(ctx, ct[0], ct[3], -1, 0, nbits, n));
     CHECK(nufhe_lwe_linear(ctx, ct[3], ct[0], -1, 0, nbits, n));
@@ -125,7 +145,8 @@ int main(int argc, char **argv)
     }
     CHECK(nufhe_cloudkey_destroy(key));
     CHECK(nufhe_ctx_destroy(ctx));
-    printf("c_abi_gate OK: %s on %ld bits through %s (refused the malformed call: %s)\n", gate ? "MUX" : "NAND", nbits,
+    printf("c_abi_gate OK: %s on %ld bits through %s (refused the malformed call: %s)\n",
+           gate == 0 ? "NAND" : gate == 1 ? "MUX" : "NAND | MUX batch", nbits,
            nufhe_version(), nufhe_last_error());
     return 0;
 }

@@ -280,3 +280,76 @@ def test_asm_sched_is_quarantined(tmp_path):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.Inst('v_add_u32_e32 v0, v1, v2', 0).plain and not mod.Inst('v_mad_u64_u32 v[0:1], vcc, v2, v3, v[4:5]', 0).plain
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    """The structs that cross the boundary by value / by pointer (nufhe_lwe, nufhe_gate_job, nufhe_tuning) have the same
+    size and field offsets in the ctypes binding as in include/nufhe_hip.h compiled by a plain C compiler."""
+    import ctypes
+    import subprocess
+    from nufhe_amd import _lib
+    structs = {'nufhe_lwe': (_lib.NufheLwe, ['a', 'b', 'cv', 'a_stride', 'b_stride', 'size']),
+               'nufhe_gate_job': (_lib.NufheGateJob, ['kind', 'c0', 'pa', 'pb', 'nbits', 'result', 'a', 'b', 'c']),
+               'nufhe_tuning': (_lib.NufheTuning, ['team_max_bits', 'team_max_bits_fft', 'pair_max_bits_ntt', 'pair_max_bits_fft',
+                                                   'ks_mfma_min_bits', 'ring_k2', 'k2_roomy_ratio_pct', 'measured', 'num_cus',
+                                                   'arch_name'])}
+    lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "nufhe_hip.h"', 'int main(void) {']
+    for name, (_, fields) in structs.items():
+        lines.append('printf("%s %%zu", sizeof(%s));' % (name, name))
+        for f in fields:
+            lines.append('printf(" %%zu", offsetof(%s, %s));' % (name, f))
+        lines.append('printf("\\n");')
+    lines += ['printf("abi %d\\n", NUFHE_ABI_VERSION);', 'return 0; }']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-std=c99', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).split('\n')
+    for line in out:
+        parts = line.split()
+        if not parts:
+            continue
+        if parts[0] == 'abi':
+            assert int(parts[1]) == _lib.ABI_VERSION
+            continue
+        cls, fields = structs[parts[0]]
+        assert int(parts[1]) == ctypes.sizeof(cls), parts[0]
+        for f, off in zip(fields, parts[2:]):
+            assert getattr(cls, f).offset == int(off), (parts[0], f)
+
+
+def test_gate_batch_refuses_malformed_job_lists_before_touching_the_device():
+    """nufhe_amd.gates.gate_batch checks names and arity of every job first (no device object is needed to be told that
+    gate_not is not a bootstrapped gate)."""
+    from nufhe_amd import gates
+    assert set(gates.BINARY_GATES) == {'gate_nand', 'gate_or', 'gate_and', 'gate_xor', 'gate_xnor', 'gate_nor',
+                                       'gate_andny', 'gate_andyn', 'gate_orny', 'gate_oryn'}
+    for name, (c, pa, pb) in gates.BINARY_GATES.items():
+        assert abs(pa) == abs(pb) and abs(pa) in (1, 2) and c in (2**29, -2**29, 2**30, -2**30), name
+    with pytest.raises(ValueError, match='not a bootstrapped gate'):
+        gates.gate_batch(None, None, [('gate_not', 1, 2, 3)])
+    with pytest.raises(ValueError, match='takes 4 ciphertext arguments'):
+        gates.gate_batch(None, None, [('gate_mux', 1, 2, 3)])
+    with pytest.raises(ValueError, match='takes 3 ciphertext arguments'):
+        gates.gate_batch(None, None, [('gate_nand', 1, 2)])
+
+
+def test_bench_traffic_lookup_covers_every_baseline_configuration():
+    """roofline.traffic must not be null on a BASELINE configuration: NAND 4096 (configs 2, 4, 5), MUX 4096 (config 3) and
+    the 2048-bit lines all have counter passes in profiles/pmc_traffic.json"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    argv = sys.argv
+    sys.argv = ['bench.py']
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    for tr in ('NTT', 'FFT'):
+        for gate, bits in (('nand', 4096), ('mux', 4096), ('nand', 2048)):
+            t = bench.pmc_traffic(tr, gate, bits)
+            assert t is not None and 1e8 < t < 3e9, (tr, gate, bits)
+        # a MUX launch moves twice the key traffic of a NAND launch
+        assert 1.8 < bench.pmc_traffic(tr, 'mux', 4096) / bench.pmc_traffic(tr, 'nand', 4096) < 2.2
+    assert bench.pmc_traffic('NTT', 'nand', 77) is None

@@ -33,7 +33,7 @@ def test_c_host_program_builds_without_a_gpu(c_host):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('gate,transform,nbits', [(0, 0, 37), (1, 0, 5), (0, 1, 300), (0, 0, 0)])
+@pytest.mark.parametrize('gate,transform,nbits', [(0, 0, 37), (1, 0, 5), (0, 1, 300), (0, 0, 0), (2, 0, 41), (2, 1, 7)])
 def test_c_host_gates_equal_the_oracle(c_host, orc, oracle_keys, tmp_path, gate, transform, nbits):
     lwe_key, tlwe_key, ck = oracle_keys
     n = 500
@@ -61,7 +61,15 @@ def test_c_host_gates_equal_the_oracle(c_host, orc, oracle_keys, tmp_path, gate,
     raw = numpy.fromfile(tmp_path / 'out.bin', numpy.int32)
     a = raw[:nbits * n].reshape(nbits, n); b = raw[nbits * n:nbits * n + nbits]
     cv = raw[nbits * n + nbits:].view(numpy.float32)
-    exp = orc.gate_mux(ck, cs[0], cs[1], cs[2]) if gate else orc.gate('gate_nand', ck, cs[0], cs[1])
+    if gate == 2:
+        # one nufhe_gate_batch call: NAND on the first half of the bits, MUX on the rest
+        h = nbits // 2
+        lo = orc.gate('gate_nand', ck, tuple(x[:h] for x in cs[0]), tuple(x[:h] for x in cs[1]))
+        hi = orc.gate_mux(ck, *[tuple(x[h:] for x in c) for c in cs])
+        exp = tuple(numpy.concatenate([l, u]) for l, u in zip(lo, hi))
+        assert 'switch points of gfx950' in proc.stdout
+    else:
+        exp = orc.gate_mux(ck, cs[0], cs[1], cs[2]) if gate == 1 else orc.gate('gate_nand', ck, cs[0], cs[1])
     da = (a.astype(numpy.int64) - exp[0].astype(numpy.int64) + 2**31) % 2**32 - 2**31
     db = (b.astype(numpy.int64) - exp[1].astype(numpy.int64) + 2**31) % 2**32 - 2**31
     tol = 0 if transform == 0 else 16
