@@ -242,6 +242,34 @@ def fft_env(thr, H, orc, oracle_keys):
     return dict(ctx=ctx, vm=ctx.make_virtual_machine(cloud_key), sk=secret_key, ck=ck, lwe_key=lwe_key, params=params)
 
 
+def test_fft_heterogeneous_gate_batch(fft_env, thr, H, orc):
+    """nufhe_gate_batch on the FFT path: AND | MUX | XNOR of different sizes in one launch write exactly the words of the
+    individual FFT gate calls (same kernels, same per-bit arithmetic) and stay within the FFT tolerance of the exact
+    (NTT) oracle; sizes chosen so that the total crosses from the pair kernel's range into the wave kernel's."""
+    import torch
+    vm = fft_env['vm']; ck = fft_env['ck']; lwe_key = fft_env['lwe_key']; params = fft_env['params']
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    rng = orc.DeterministicRNG(515)
+
+    def make(n):
+        m = rng.uniform_bool((n,)).astype(bool)
+        c = orc.encrypt(rng, lwe_key, m)
+        return m, c, H.ciphertext_from_arrays(thr, c, params)
+    for sizes in ((7, 3, 12), (2 * cus, cus, cus + 5)):
+        x = [make(sizes[0]) for _ in range(2)]; y = [make(sizes[1]) for _ in range(3)]; z = [make(sizes[2]) for _ in range(2)]
+        rx, ry, rz = vm.gate_batch([('gate_and', x[0][2], x[1][2]), ('gate_mux', y[0][2], y[1][2], y[2][2]),
+                                    ('gate_xnor', z[0][2], z[1][2])])
+        assert rx == vm.gate_and(x[0][2], x[1][2]) and ry == vm.gate_mux(y[0][2], y[1][2], y[2][2])
+        assert rz == vm.gate_xnor(z[0][2], z[1][2])
+        n = min(16, sizes[1])
+        exp = orc.gate_mux(ck, *[tuple(v[:n] for v in q[1]) for q in y])
+        ra, rb, rcv = H.ct_arrays(ry)
+        da = (ra[:n].astype(numpy.int64) - exp[0].astype(numpy.int64) + 2**31) % 2**32 - 2**31
+        assert abs(da).max() <= 16 and (rcv[:n] == exp[2]).all()
+        assert (fft_env['ctx'].decrypt(fft_env['sk'], ry) == numpy.where(y[0][0], y[1][0], y[2][0])).all()
+        assert (fft_env['ctx'].decrypt(fft_env['sk'], rz) == ~(z[0][0] ^ z[1][0])).all()
+
+
 def test_config5_fft_gates_vs_exact_path(fft_env, thr, H, orc):
     """NAND and MUX with the FFT transform vs the exact (NTT) oracle: tolerance contract + record."""
     vm = fft_env['vm']; ctx = fft_env['ctx']; sk = fft_env['sk']; ck = fft_env['ck']; lwe_key = fft_env['lwe_key']

@@ -165,6 +165,27 @@ def test_gpu_k2_gates_vs_oracle_ragged(k2_env, thr, H, orc):
 
 
 @pytest.mark.gpu
+def test_gpu_k2_heterogeneous_gate_batch(k2_env, thr, H, orc):
+    """nufhe_gate_batch with tlwe_mask_size = 2 (extracted samples of 2048 coefficients through the MUX fold and the
+    keyswitch): XOR | MUX | NAND of different sizes in one launch, every word vs the k = 2 oracle."""
+    vm = k2_env['vm']; ck = k2_env['ck']; lwe_key = k2_env['lwe_key']; params = k2_env['params']
+    rng = orc.DeterministicRNG(8910)
+
+    def make(n):
+        m = rng.uniform_bool((n,)).astype(bool)
+        c = orc.encrypt(rng, lwe_key, m, k2_env['oparams'])
+        return m, c, H.ciphertext_from_arrays(thr, c, params)
+    x = [make(9) for _ in range(2)]; y = [make(4) for _ in range(3)]; z = [make(21) for _ in range(2)]
+    rx, ry, rz = vm.gate_batch([('gate_xor', x[0][2], x[1][2]), ('gate_mux', y[0][2], y[1][2], y[2][2]),
+                                ('gate_nand', z[0][2], z[1][2])])
+    for got, exp in ((rx, orc.gate('gate_xor', ck, x[0][1], x[1][1])), (ry, orc.gate_mux(ck, y[0][1], y[1][1], y[2][1])),
+                     (rz, orc.gate('gate_nand', ck, z[0][1], z[1][1]))):
+        ra, rb, rcv = H.ct_arrays(got)
+        assert (ra == exp[0]).all() and (rb == exp[1]).all() and (rcv == exp[2]).all()
+    assert (k2_env['ctx'].decrypt(k2_env['sk'], ry) == numpy.where(y[0][0], y[1][0], y[2][0])).all()
+
+
+@pytest.mark.gpu
 def test_gpu_k2_large_batch_kernels(k2_env, thr, H, orc):
     """k = 2, NTT, batches beyond the team kernel.  Default: the ring kernel (3 waves per bit, 2 teams per work-group,
     ragged last group).  With the pair switch at 0: between 4 x and 6 x CUs bits the 6-waves-per-CU build
