@@ -72,10 +72,10 @@ ALG_ADDSUB_PER_BIT_ITER = 6 * 10 * 512 * 2         # 61,440
 ALG_MODMUL_PER_BIT_ITER = 6 * 1024 + 8 * 1024      # 14,336
 
 
-# `roofline.frac` is FROZEN at the round-3 definition ("vs_measured_class_rates": issued instructions x the best rate
-# each issue class reaches on this chip at any occupancy, over the SIMD cycles of the launch) so that
-# rounds compare; the streaming-model fraction (BASELINE's HBM axis) and the nominal-2-cycle fraction ride beside it
-# unchanged under `streaming_model.frac` and `fractions.vs_nominal_2_cycle_issue`.
+# `roofline.frac` is BASELINE's HBM axis (streaming model) since round 5.  `roofline.valu_issue.frac` is FROZEN at the
+# round-3 definition ("vs_measured_class_rates": issued instructions x the best rate each issue class reaches on this chip
+# at any occupancy, over the SIMD cycles of the launch) so that rounds compare -- it was the headline `frac`
+# of rounds 3 and 4 --; the nominal-2-cycle fraction rides beside it under `valu_issue.fractions.vs_nominal_2_cycle_issue`.
 FRAC_DEFINITION = "r03"
 
 
@@ -597,26 +597,33 @@ def main():
                 "bits_per_gpu": B, "transform": args.transform, "parallelism": "bits sharded over %d GPU(s), keys replicated" % world},
             "roofline": {},
         }
-        streaming = {
+        # `roofline` IS BASELINE.json's axis (the contract of the bench line): the ALGORITHMIC bytes of one launch of the
+        # dominant kernel -- SURVEY 8d: every bit streams its 32.8 MB key once, no reuse -- over the HIP-event duration of
+        # the launch, against the 8 TB/s HBM peak; `traffic` = the HBM bytes the counters saw.  What actually bounds
+        # the kernel (VALU issue) is priced under `roofline.valu_issue`, with every fraction naming
+        # its denominator.  (Until round 4 the issue-model fraction was the headline `frac` and this object sat under
+        # `streaming_model`; the numbers are the same, the one BASELINE names now comes first.)
+        live_clock = sum(clock_ghz) / len(clock_ghz) if clock_ghz else None
+        issue = issue_roofline(args.transform, B, n_rot, 500, br_avg, live_clock) or {}
+        roof = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": pmc_traffic(args.transform, args.gate, B),
+            "kernel": "k_bootstrap%s (fused mod-switch + blind rotate + extract)" % ("_fft" if args.transform == "FFT" else ""),
+            "kernel_ms": br_avg, "keyswitch_ms": ks_avg,
             "algorithmic_bytes_per_launch": a_kernel,
             "gate_streaming_model_GBs": a_gate / (ms_per_step * 1e-3) / 1e9,
-            "note": "BASELINE.json's HBM axis: every bit streams its 32.8 MB key once, no reuse (SURVEY §8d). The "
-                    "kernel shares each key row between all resident waves through L2, so this is a model figure, "
-                    "not traffic; the measured HBM bytes are in 'traffic'"}
-        live_clock = sum(clock_ghz) / len(clock_ghz) if clock_ghz else None
-        roof = issue_roofline(args.transform, B, n_rot, 500, br_avg, live_clock) or {}
+            "frac_is": "algorithmic bytes per launch (streaming model, SURVEY 8d) / HIP-event duration / 8 TB/s",
+            "note": "BASELINE.json's HBM axis.  The kernel shares each key row between all resident waves through L2, so "
+                    "`achieved` is a model figure, not traffic (`traffic` = measured HBM bytes per launch, ~0.4 % of the "
+                    "algorithmic bytes: no wasted re-reads); the kernel is bound by VALU issue -- see `valu_issue`",
+            "valu_issue": issue,
+            "keyswitch": keyswitch_roofline(B, ks_avg, B > 2 * 256)}
+        if "clock_ghz_in_kernel" in issue:
+            roof["clock_ghz_in_kernel"] = issue["clock_ghz_in_kernel"]
         if wave_ms:
             # one wave's blind rotation (start to end) against the kernel: rounds x wave life time ~ kernel time when
             # the waves of every SIMD finish together (pacing)
             roof["wave_ms_in_kernel"] = sum(wave_ms) / len(wave_ms)
-        if "bound" not in roof:        # profile files missing: fall back to the streaming model as the headline
-            roof.update({k: streaming[k] for k in ("bound", "achieved", "peak", "unit", "frac")})
-        roof.update({"kernel": "k_bootstrap%s (fused mod-switch + blind rotate + extract)" % (
-                         "_fft" if args.transform == "FFT" else ""),
-                     "traffic": pmc_traffic(args.transform, args.gate, B),
-                     "kernel_ms": br_avg, "keyswitch_ms": ks_avg, "streaming_model": streaming,
-                     "keyswitch": keyswitch_roofline(B, ks_avg, B > 2 * 256)})
         # self-check of the SIMD-partner pacing: the two waves of a SIMD must finish together (rounds x one
         # wave's life time ~ kernel time) and the clock must not have sagged; a line that fails this was measured on a
         # box / in a state where the kernel does not run as designed

@@ -670,7 +670,8 @@ def _check_multi_rank_line(d, world):
     assert cb['kind'] == 'port' and cb['unit'] == 'gates/s' and cb['value'] > 0 and cb['cores'] >= world
     assert cb['ranks'] == world and 'sample' in cb and cb['reference_python']['measured_in_this_run'] is False
     roof = d['roofline']
-    assert roof['kernel_ms'] > 0 and 0 < roof['frac'] and 'streaming_model' in roof
+    assert roof['kernel_ms'] > 0 and roof['bound'] == 'hbm' and roof['unit'] == 'GB/s' and 0 < roof['frac'] < 1.5
+    assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-12 and 'valu_issue' in roof
     pr = roof['per_rank']
     assert len(pr['kernel_ms']) == world and len(pr['clock_ghz_in_kernel']) == world
     assert 0 < pr['kernel_ms_min'] <= roof['kernel_ms'] <= pr['kernel_ms_max']

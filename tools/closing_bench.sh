@@ -25,8 +25,8 @@ python - "$OUT" <<'PY'
 import json, sys, os
 out = sys.argv[1]
 d = json.load(open(os.path.join(out, "bench_default_full.json")))
-print("default: %.3f ms/step, K1 %.3f ms, frac %.3f, correct %s, parity %s" % (
-    d["ms_per_step"], d["roofline"]["kernel_ms"], d["roofline"]["frac"], d["correct"],
+print("default: %.3f ms/step, K1 %.3f ms, hbm-model frac %.3f, valu-issue frac %.3f, correct %s, parity %s" % (
+    d["ms_per_step"], d["roofline"]["kernel_ms"], d["roofline"]["frac"], d["roofline"]["valu_issue"].get("frac", 0), d["correct"],
     {k: v.get("differing") for k, v in d["parity"].items() if isinstance(v, dict)}))
 for k, v in d.get("other_configs", {}).items():
     if isinstance(v, dict) and "ms_per_step_per_gpu" in v:
