@@ -58,3 +58,28 @@ def test_uint_min_gate_chain():
     import torch
     assert torch.equal(ref.a, answer.a) and torch.equal(ref.b, answer.b)
     assert torch.equal(ref.current_variances, answer.current_variances)
+
+
+@pytest.mark.gpu
+def test_uint_min_many_equals_uint_min_per_pair():
+    """uint_min_many (every step of several independent comparators as one heterogeneous gate batch): the same ciphertext
+    words as uint_min on each pair, for pairs of different leading shapes; decrypted == numpy.minimum."""
+    import nufhe_amd
+    from nufhe_amd.operators_integer import uint_min, uint_min_many, uintarray_to_bitarray, bitarray_to_uintarray
+    ctx = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(78))
+    sk, ck = ctx.make_key_pair()
+    rs = numpy.random.RandomState(6)
+    shapes = [(3,), (1,), (2, 2)]
+    xs = [rs.randint(0, 2**8, size=s).astype(numpy.uint8) for s in shapes]
+    ys = [rs.randint(0, 2**8, size=s).astype(numpy.uint8) for s in shapes]
+    ca = [ctx.encrypt(sk, uintarray_to_bitarray(x)) for x in xs]
+    cb = [ctx.encrypt(sk, uintarray_to_bitarray(y)) for y in ys]
+    many = [nufhe_amd.empty_ciphertext(ctx.thread, ck.params, s + (8,)) for s in shapes]
+    uint_min_many(ctx.thread, ck, many, ca, cb)
+    for k, s in enumerate(shapes):
+        one = nufhe_amd.empty_ciphertext(ctx.thread, ck.params, s + (8,))
+        uint_min(ctx.thread, ck, one, ca[k], cb[k])
+        assert one == many[k]
+        assert (bitarray_to_uintarray(ctx.decrypt(sk, many[k])) == numpy.minimum(xs[k], ys[k])).all()
+    with pytest.raises(ValueError):
+        uint_min_many(ctx.thread, ck, many[:2], ca, cb)

@@ -17,7 +17,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy
 import nufhe_amd as nufhe
-from nufhe_amd.operators_integer import uint_min, uintarray_to_bitarray, bitarray_to_uintarray
+from nufhe_amd.operators_integer import uint_min, uint_min_many, uintarray_to_bitarray, bitarray_to_uintarray
 
 ctx = nufhe.Context(rng=nufhe.DeterministicRNG(123))
 secret, cloud = ctx.make_key_pair()
@@ -73,14 +73,10 @@ def one_after_the_other():
 
 
 def lock_step():
-    # the schedule of uint_min (operators_integer.py), the same step of all C circuits as one batch
-    carry = [vm.empty_ciphertext((M, 1)) for _ in range(C)]
-    for c in carry:
-        vm.gate_constant(False, dest=c)
-    same = vm.gate_batch([('gate_xnor', ca, cb) for ca, cb in cts])
-    for i in reversed(range(W)):
-        vm.gate_batch([('gate_mux', same[k][..., i:i + 1], carry[k], cts[k][0][..., i:i + 1], carry[k]) for k in range(C)])
-    return vm.gate_batch([('gate_mux', carry[k], cts[k][1], cts[k][0]) for k in range(C)])
+    # the schedule of uint_min, the same step of all C circuits as one batch (nufhe_amd.operators_integer.uint_min_many)
+    res = [vm.empty_ciphertext((M, W)) for _ in range(C)]
+    uint_min_many(thr, cloud, res, [ca for ca, _ in cts], [cb for _, cb in cts])
+    return res
 
 
 t_seq, r_seq = timed(one_after_the_other, reps=3)
