@@ -297,3 +297,34 @@ def test_gather_waits_for_work_queued_on_the_destination(env, orc):
         dst_thr.synchronize()
     assert (got == src).all()
     assert torch.cuda.current_device() == 0
+
+
+def test_batch_of_many_one_bit_jobs_and_table_ring(env, orc):
+    """70 one-bit jobs of alternating kinds in one call (the job tables outgrow their first 4 KiB slot: the slot is
+    reallocated), then six more calls back to back without a synchronisation in between (the ring of four table slots
+    wraps: a slot's staging buffer is rewritten only after its previous upload has executed) -- every result equals the
+    individual gate call, the first batch also the oracle."""
+    rng = orc.DeterministicRNG(70)
+    vm, thr = env['vm'], env['thr']
+    a = _make(env, orc, rng, 70); b = _make(env, orc, rng, 70); c = _make(env, orc, rng, 70)
+    kinds = ['gate_nand', 'gate_mux', 'gate_xor', 'gate_orny', 'gate_mux', 'gate_nor', 'gate_and']
+    jobs = []
+    for i in range(70):
+        k = kinds[i % len(kinds)]
+        ops = (a[2][i:i + 1], b[2][i:i + 1]) + ((c[2][i:i + 1],) if k == 'gate_mux' else ())
+        jobs.append((k,) + ops)
+    res = vm.gate_batch(jobs)
+    for i, r in enumerate(res):
+        k = kinds[i % len(kinds)]
+        ins = [(x[0][i:i + 1], tuple(v[i:i + 1] for v in x[1]), None) for x in ((a, b, c) if k == 'gate_mux' else (a, b))]
+        _check_job(env, orc, k, r, ins)
+    outs = []
+    for rep in range(6):                              # no synchronisation between the calls
+        outs.append(vm.gate_batch([(kinds[(rep + j) % 7],) + ((a[2][:5], b[2][:5], c[2][:5]) if kinds[(rep + j) % 7] == 'gate_mux'
+                                                             else (a[2][:5], b[2][:5])) for j in range(3 + rep)]))
+    thr.synchronize()
+    for rep, group in enumerate(outs):
+        for j, r in enumerate(group):
+            k = kinds[(rep + j) % 7]
+            ops = (a[2][:5], b[2][:5], c[2][:5]) if k == 'gate_mux' else (a[2][:5], b[2][:5])
+            assert r == getattr(vm, k)(*ops), (rep, j, k)
