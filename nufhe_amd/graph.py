@@ -57,7 +57,9 @@ class GateGraph:
         read are its INPUT BUFFERS -- refresh them in place (``ct[...] = other``)."""
         stream = self.thread._torch_stream
         if not self._pinned:
-            _lib.call("nufhe_ctx_pin_scratch", self.thread.handle, 1)
+            # (straight through the binding: pinning touches no device memory, so it is not subject to the guard that
+            # ties calls to the DeviceThread's stream -- capture() may be called from outside that stream's context)
+            _lib.check(_lib.lib().nufhe_ctx_pin_scratch(self.thread.handle, 1))
             self._pinned = True
         with torch.cuda.stream(stream):
             for _ in range(max(1, int(warmup))):
@@ -82,8 +84,8 @@ class GateGraph:
         if self._pinned:
             self._pinned = False
             handle = getattr(self.thread, 'handle', None)
-            if handle is not None and handle.value is not None:
-                _lib.call("nufhe_ctx_pin_scratch", handle, -1)
+            if handle is not None and handle.value is not None and not getattr(self.thread, '_released', False):
+                _lib.check(_lib.lib().nufhe_ctx_pin_scratch(handle, -1))
 
     def __del__(self):
         try:

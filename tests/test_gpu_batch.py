@@ -218,6 +218,15 @@ def test_graph_survives_larger_eager_gates(orc):
             _capture_without_warmup(thr, lambda: vm.gate_nand(huge[0], huge[1]))
         thr.synchronize()
         assert vm.gate_nand(cs[0], cs[1]) == vm.gate_nand(cs[0], cs[1])      # the context still works
+    # capture / replay / close called from OUTSIDE the stream's context (they enter it themselves; pinning is not tied to it)
+    g3 = nufhe.GateGraph(thr)
+    out3 = g3.capture(circuit)
+    g3.replay()
+    stream.synchronize()
+    with torch.cuda.stream(stream):
+        assert out3 == expect
+    g3.close()
+    g3.close()                                                               # idempotent
 
 
 def _capture_without_warmup(thr, circuit):
