@@ -337,3 +337,41 @@ def test_batch_of_many_one_bit_jobs_and_table_ring(env, orc):
             k = kinds[(rep + j) % 7]
             ops = (a[2][:5], b[2][:5], c[2][:5]) if k == 'gate_mux' else (a[2][:5], b[2][:5])
             assert r == getattr(vm, k)(*ops), (rep, j, k)
+
+
+def test_batch_fuzz_against_individual_gate_calls(env, orc):
+    """Random job lists -- 1 to 6 jobs, any of the eleven bootstrapped gates, sizes from empty to beyond the team limit,
+    one-bit operands broadcast over a job, results written in place over an operand -- against the individual gate calls
+    on the same inputs (which the other tests pin to the oracle): equal words every time."""
+    import torch
+    rs = numpy.random.RandomState(20250926)
+    rng = orc.DeterministicRNG(99)
+    vm = env['vm']
+    names = sorted(TRUTH) + ['gate_mux']
+    sizes = [0, 1, 2, 3, 17, 64, 100, 257]
+    pool = {n: [_make(env, orc, rng, n)[2] for _ in range(3)] for n in sizes if n}
+    one = [_make(env, orc, rng, 1)[2] for _ in range(3)]
+    for trial in range(14):
+        jobs, expect = [], []
+        for _ in range(rs.randint(1, 7)):
+            name = names[rs.randint(len(names))]
+            n = sizes[rs.randint(len(sizes))]
+            arity = 3 if name == 'gate_mux' else 2
+            if n == 0:
+                ops = [pool[1][k][:0] for k in range(arity)]
+            else:
+                ops = [pool[n][k] for k in range(arity)]
+                if n > 1 and rs.rand() < 0.3:
+                    ops[rs.randint(arity)] = one[rs.randint(3)]          # broadcast operand
+            ops = [o.copy() for o in ops]                                # private buffers: some jobs overwrite an operand
+            expect.append(getattr(vm, name)(*ops))
+            if n > 0 and rs.rand() < 0.3:
+                full = [k for k, o in enumerate(ops) if o.shape == expect[-1].shape]
+                dest = ops[full[rs.randint(len(full))]]                  # result in place over one of the operands
+                jobs.append((name,) + tuple(ops) + (dest,))
+            else:
+                jobs.append((name,) + tuple(ops))
+        got = vm.gate_batch(jobs)
+        torch.cuda.synchronize()
+        for j, (g, e) in enumerate(zip(got, expect)):
+            assert g == e, (trial, j, jobs[j][0], tuple(e.shape))
