@@ -499,7 +499,7 @@ def test_large_batch_tail_goes_to_the_small_batch_kernels(env, orc):
         _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, -1)
 
 
-@pytest.mark.parametrize('script', ['gate_nand.py', 'gate_nand_low_level.py', 'serialization.py'])
+@pytest.mark.parametrize('script', ['gate_nand.py', 'gate_nand_low_level.py', 'serialization.py', 'gate_batch.py'])
 def test_examples_run(script):
     """The counterparts of the reference's examples/ run end to end on the GPU."""
     import subprocess
