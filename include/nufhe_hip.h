@@ -187,8 +187,9 @@ int nufhe_gate_mux(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe_
  *   kind NUFHE_JOB_MUX:    result = a ? b : c; c0 / pa / pb are ignored (the reference's constants are used), mu must be 2^29.
  * nbits may differ per job (0 allowed).  Every operand of every job is read (step 1) before any result is written
  * (step 4): a job may name its own or another job's result buffer as an operand and sees the values from BEFORE the
- * call (carry = MUX(same, carry, a) in place is fine); two jobs must not write the same buffer.  Not capturable into a
- * hipGraph (the job tables are uploaded from the host per call). */
+ * call (carry = MUX(same, carry, a) in place is fine); two jobs must not write the same buffer.  The job list is read
+ * during the call (its tables reach the device inside kernel arguments): `jobs` may be freed on return, and the call can
+ * be captured into a hipGraph like the other gate entry points (run it once eagerly first: scratch is sized on first use). */
 #define NUFHE_JOB_BINARY 0
 #define NUFHE_JOB_MUX 1
 typedef struct {

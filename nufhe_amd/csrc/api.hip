@@ -66,10 +66,11 @@ struct nufhe_ctx {
     // that has to grow is RETIRED (kept until the last pin is released) instead of freed (nufhe_ctx_pin_scratch)
     int scratch_pins = 0;
     std::vector<void *> retired;
-    // job tables of nufhe_gate_batch: a ring of slots, each a pinned host staging buffer, its device copy and the event
-    // behind the upload (a slot's staging buffer is rewritten only after its previous upload has executed)
-    struct TableSlot { void *h = nullptr; void *d = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; bool used = false; };
-    TableSlot tables[4];
+    // job tables of nufhe_gate_batch: a ring of device buffers (a slot is rewritten four batches later, in stream order
+    // behind the kernels that read it).  They are FILLED BY KERNELS whose arguments carry the table bytes
+    // (launch_write_table), not by copies from host memory: nothing on the host has to outlive the call, and a captured
+    // hipGraph holds the tables inside its kernel nodes.
+    Scratch tables[4];
     unsigned table_next = 0;
     long team_max_bits = -1;   // nufhe_ctx_set_team_max_bits override of tuning.team_max_bits; -1 = none
     long pair_max_bits = -1;   // nufhe_ctx_set_pair_max_bits override of the pair / ring switches; -1 = none
@@ -363,11 +364,8 @@ int nufhe_ctx_destroy(nufhe_ctx *ctx)
     if (ctx->batch_a.ptr) hipFree(ctx->batch_a.ptr);
     if (ctx->batch_b.ptr) hipFree(ctx->batch_b.ptr);
     for (void *p : ctx->retired) hipFree(p);
-    for (auto &t : ctx->tables) {
-        if (t.h) hipHostFree(t.h);
-        if (t.d) hipFree(t.d);
-        if (t.done) hipEventDestroy(t.done);
-    }
+    for (auto &t : ctx->tables)
+        if (t.ptr) hipFree(t.ptr);
     if (ctx->ev[3]) hipEventDestroy(ctx->ev[3]);
     if (ctx->ev_dst) hipEventDestroy(ctx->ev_dst);
     for (hipEvent_t e : ctx->ring)
@@ -931,28 +929,6 @@ static int run_gate(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result
     return NUFHE_OK;
 }
 
-// job tables of a heterogeneous batch: next slot of the ring, staging buffer free to be rewritten
-static int table_slot(nufhe_ctx *ctx, size_t bytes, nufhe_ctx::TableSlot **out)
-{
-    nufhe_ctx::TableSlot &t = ctx->tables[ctx->table_next++ % 4];
-    if (!t.done) HIP_TRY(hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
-    if (t.used) HIP_TRY(hipEventSynchronize(t.done));     // its previous upload has executed (4 batches ago)
-    if (t.bytes < bytes) {
-        if (t.used) HIP_TRY(hipStreamSynchronize(ctx->stream));     // kernels of that batch may still read the device copy
-        if (t.h) HIP_TRY(hipHostFree(t.h));
-        if (t.d) HIP_TRY(hipFree(t.d));
-        t.h = t.d = nullptr;
-        t.bytes = 0;
-        const size_t cap = bytes < 4096 ? 4096 : bytes * 2;
-        HIP_TRY(hipHostMalloc(&t.h, cap, hipHostMallocDefault));
-        HIP_TRY(hipMalloc(&t.d, cap));
-        t.bytes = cap;
-    }
-    t.used = true;
-    *out = &t;
-    return NUFHE_OK;
-}
-
 int nufhe_bootstrap(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe_lwe x, int32_t mu, long nbits,
                     int no_keyswitch)
 {
@@ -1031,9 +1007,6 @@ int nufhe_gate_batch(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_gate_job *
     int rc = check_key(ctx, key, true, true);
     if (rc) return rc;
     if (n_jobs < 0 || (n_jobs > 0 && !jobs)) return fail(NUFHE_EINVAL, "null job list");
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
-        return fail(NUFHE_EINVAL, "nufhe_gate_batch uploads its job tables from the host and cannot be captured into a graph");
     long out_bits = 0, mux_bits = 0;
     int live = 0;
     for (int j = 0; j < n_jobs; j++) {
@@ -1097,14 +1070,16 @@ int nufhe_gate_batch(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_gate_job *
         rots.push_back(rot(g.a, -1, g.c, 1, -MU8, start, g.nbits));           // (0,-1/8) - a + c, gates.py:648-650
     }
     const size_t rot_bytes = rots.size() * sizeof(BatchRot), out_bytes = outs.size() * sizeof(BatchOut);
-    nufhe_ctx::TableSlot *slot = nullptr;
-    if ((rc = table_slot(ctx, rot_bytes + out_bytes, &slot))) return rc;
-    memcpy(slot->h, rots.data(), rot_bytes);
-    memcpy((char *)slot->h + rot_bytes, outs.data(), out_bytes);
-    HIP_TRY(hipMemcpyAsync(slot->d, slot->h, rot_bytes + out_bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipEventRecord(slot->done, ctx->stream));
-    const BatchRot *d_rots = (const BatchRot *)slot->d;
-    const BatchOut *d_outs = (const BatchOut *)((const char *)slot->d + rot_bytes);
+    // the tables travel as kernel arguments (4 KiB per launch at most) into the next slot of the ring
+    // (all four slots are sized together: a capture that follows one eager warm-up run must not meet an unallocated slot)
+    const size_t table_bytes = rot_bytes + out_bytes < 4096 ? 4096 : 2 * (rot_bytes + out_bytes);
+    for (Scratch &t : ctx->tables)
+        if ((rc = ensure(ctx, t, table_bytes))) return rc;
+    Scratch &slot = ctx->tables[ctx->table_next++ % 4];
+    HIP_TRY(launch_write_table(slot.ptr, rots.data(), rot_bytes, ctx->stream));
+    HIP_TRY(launch_write_table((char *)slot.ptr + rot_bytes, outs.data(), out_bytes, ctx->stream));
+    const BatchRot *d_rots = (const BatchRot *)slot.ptr;
+    const BatchOut *d_outs = (const BatchOut *)((const char *)slot.ptr + rot_bytes);
 
     const int ext = key->ext_size();
     if ((rc = ensure(ctx, ctx->batch_a, (size_t)rows * key->n * sizeof(i32))) || (rc = ensure(ctx, ctx->batch_b, (size_t)rows * sizeof(i32))) ||

@@ -76,6 +76,8 @@ struct BatchOut {
     long second;
 };
 
+static_assert(sizeof(BatchRot) % 16 == 0 && sizeof(BatchOut) % 16 == 0, "the job tables are written in 16-byte words");
+
 struct KsFinal {
     // heterogeneous batch: results go to the views of `batch_outs` (n_batch_outs entries) instead of out_a / out_b / out_cv
     const BatchOut *batch_outs;
@@ -162,6 +164,10 @@ hipError_t launch_bk_from_coeffs(u64 *out, const i32 *in, long polys, const u64 
 static inline size_t ks_planes_bytes(int input_size) { return (size_t)4 * input_size * 2 * KSM_COLS * 16; }
 hipError_t launch_ks_planes(signed char *planes, const i32 *ks_a3, int input_size, int n, hipStream_t stream);
 hipError_t launch_keyswitch(const KsLaunch &P, const KsFinal &F, hipStream_t stream);
+// `bytes` bytes of host memory into device memory at d_dst THROUGH KERNEL ARGUMENTS (chunks of TABLE_CHUNK_BYTES per launch):
+// the host buffer may be freed as soon as the call returns, and under stream capture the bytes live in the graph's nodes
+#define TABLE_CHUNK_BYTES 3584
+hipError_t launch_write_table(void *d_dst, const void *h_src, size_t bytes, hipStream_t stream);
 hipError_t launch_batch_combine(i32 *out_a, i32 *out_b, const BatchRot *rots, int n_rots, long rows, int n, hipStream_t stream);
 hipError_t launch_batch_mux_fold(i32 *ext_a, i32 *ext_b, const BatchOut *outs, int n_outs, long out_bits, int ext, i32 mu,
                                  hipStream_t stream);

@@ -1070,6 +1070,16 @@ __global__ void k_lwe_linear(LweView res, LweView src, i32 p, int add_result, lo
     }
 }
 
+// Heterogeneous gate batch, step 0: the job tables reach the device as KERNEL ARGUMENTS (a few hundred bytes for a typical
+// circuit step) -- no host staging buffer whose lifetime the stream would have to respect, and capturable into a hipGraph
+struct TableChunk {
+    uint4 w[TABLE_CHUNK_BYTES / 16];
+};
+__global__ __launch_bounds__(64) void k_write_table(uint4 *__restrict__ dst, TableChunk c, int words)
+{
+    for (int i = threadIdx.x; i < words; i += 64) dst[i] = c.w[i];
+}
+
 // Heterogeneous gate batch, step 1: the linear pre-combination of every gate of the batch (gates.py:104-110 and
 // siblings: (0, c) + pa a + pb b, int32 wraparound) into the rows of ONE LWE(n) array, so that a single bootstrap launch
 // covers independent gates of different kinds.  One work-group per row.
@@ -1872,6 +1882,21 @@ hipError_t launch_keyswitch(const KsLaunch &P, const KsFinal &F, hipStream_t str
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_keyswitch_finalize, dim3((unsigned)P.nbits), dim3(256), 0, stream, F);
     return hipGetLastError();
+}
+
+hipError_t launch_write_table(void *d_dst, const void *h_src, size_t bytes, hipStream_t stream)
+{
+    // (device buffers are sized in multiples of 16 bytes and the tables' records are 16-byte multiples)
+    for (size_t off = 0; off < bytes; off += TABLE_CHUNK_BYTES) {
+        const size_t n = bytes - off < TABLE_CHUNK_BYTES ? bytes - off : TABLE_CHUNK_BYTES;
+        TableChunk c;
+        memset(&c, 0, sizeof(c));
+        memcpy(&c, (const char *)h_src + off, n);
+        hipLaunchKernelGGL(k_write_table, dim3(1), dim3(64), 0, stream, (uint4 *)((char *)d_dst + off), c, (int)((n + 15) / 16));
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_batch_combine(i32 *out_a, i32 *out_b, const BatchRot *rots, int n_rots, long rows, int n, hipStream_t stream)

@@ -29,7 +29,7 @@ The captured graph holds raw pointers into the library's scratch buffers (extrac
 which grow on demand.  A GateGraph therefore PINS the context's scratch from its first capture until ``close()`` (or
 garbage collection): a later, larger eager gate on the same DeviceThread allocates a new buffer and the old one stays
 alive for the graph (``nufhe_ctx_pin_scratch``) -- replaying an old graph after larger gates have run is safe.
-``VirtualMachine.gate_batch`` cannot be captured (its job tables are uploaded from the host per call).
+``VirtualMachine.gate_batch`` is capturable like the single gates (its job tables travel inside kernel arguments).
 """
 
 import torch

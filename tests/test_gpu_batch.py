@@ -375,3 +375,53 @@ def test_batch_fuzz_against_individual_gate_calls(env, orc):
         torch.cuda.synchronize()
         for j, (g, e) in enumerate(zip(got, expect)):
             assert g == e, (trial, j, jobs[j][0], tuple(e.shape))
+
+
+def test_gate_batch_inside_a_captured_graph(orc):
+    """gate_batch is capturable: its job tables travel inside kernel arguments, so a recorded circuit made of batches
+    (uint_min_many: 18 batches of three comparators) replays with new inputs written in place and gives the eager words."""
+    import torch
+    import nufhe_amd as nufhe
+    from nufhe_amd.device import DeviceThread
+    from nufhe_amd.operators_integer import uint_min_many, uintarray_to_bitarray, bitarray_to_uintarray
+    stream = torch.cuda.Stream()
+    rs = numpy.random.RandomState(8)
+    with torch.cuda.stream(stream):
+        thr = DeviceThread(0)
+        ctx = nufhe.Context(rng=nufhe.DeterministicRNG(43), thread=thr)
+        secret, cloud = ctx.make_key_pair()
+        shapes = [(2,), (1,), (3,)]
+
+        def fresh():
+            xs = [rs.randint(0, 2**8, size=s).astype(numpy.uint8) for s in shapes]
+            ys = [rs.randint(0, 2**8, size=s).astype(numpy.uint8) for s in shapes]
+            return xs, ys
+        xs, ys = fresh()
+        ca = [ctx.encrypt(secret, uintarray_to_bitarray(x)) for x in xs]
+        cb = [ctx.encrypt(secret, uintarray_to_bitarray(y)) for y in ys]
+        outs = [nufhe.empty_ciphertext(thr, cloud.params, s + (8,)) for s in shapes]
+
+        def circuit():
+            uint_min_many(thr, cloud, outs, ca, cb)
+            return outs
+        g = nufhe.GateGraph(thr)
+        g.capture(circuit)
+        g.replay()
+        thr.synchronize()
+        for k in range(3):
+            assert (bitarray_to_uintarray(ctx.decrypt(secret, outs[k])) == numpy.minimum(xs[k], ys[k])).all()
+        first = [o.copy() for o in outs]
+        xs, ys = fresh()                                   # new inputs IN PLACE, eager reference first
+        for k in range(3):
+            ca[k][...] = ctx.encrypt(secret, uintarray_to_bitarray(xs[k]))
+            cb[k][...] = ctx.encrypt(secret, uintarray_to_bitarray(ys[k]))
+        expect = [o.copy() for o in circuit()]
+        assert not all(e == f for e, f in zip(expect, first))
+        for o in outs:
+            o.a.zero_()
+        g.replay()
+        thr.synchronize()
+        for k in range(3):
+            assert outs[k] == expect[k]
+            assert (bitarray_to_uintarray(ctx.decrypt(secret, outs[k])) == numpy.minimum(xs[k], ys[k])).all()
+        g.close()
