@@ -5,7 +5,8 @@
  * reference (nucypher/nufhe).  Reference citations are relative to the reference repo root.
  *
  * Conventions
- *  - extern "C", POD arguments only, no exceptions cross the boundary.
+ *  - extern "C", POD arguments only, no exceptions cross the boundary: every entry point catches what its host side may
+ *    throw (std::bad_alloc -> NUFHE_ENOMEM, anything else -> NUFHE_EHIP).
  *  - every function returns 0 on success, a negative NUFHE_E* code on failure; the message is
  *    available (per thread) from nufhe_last_error().
  *  - pointers named d_* are DEVICE pointers owned by the caller (e.g. torch tensors' data_ptr);
@@ -30,6 +31,7 @@ extern "C" {
 #define NUFHE_EHIP (-2)     /* HIP runtime error */
 #define NUFHE_ENODEV (-3)   /* no usable GPU */
 #define NUFHE_ENOKEY (-4)   /* key part not uploaded */
+#define NUFHE_ENOMEM (-5)   /* host allocation failed (std::bad_alloc caught at the boundary) */
 
 #define NUFHE_TRANSFORM_NTT 0   /* negacyclic NTT-1024 over 2^64 - 2^32 + 1 (bit-exact path) */
 #define NUFHE_TRANSFORM_FFT 1   /* fp64 folded FFT-512 (polynomial_transform_fft.py), tolerance path */
@@ -43,10 +45,11 @@ typedef struct nufhe_cloudkey nufhe_cloudkey;  /* device copies of BootstrapKey 
 
 /* Bumped whenever a struct passed by value or an entry point's signature changes (3: nufhe_lwe gained `size`;
  * 4: output-stride checks, key images; 5: key images carry a header, nufhe_gate_batch, nufhe_ctx_pin_scratch,
- * nufhe_ctx_get_tuning / _set_tuning).  A
+ * nufhe_ctx_get_tuning / _set_tuning; 6: NUFHE_ENOMEM, every entry point catches C++ exceptions, nufhe_gate_batch
+ * refuses overlapping result views and MUX jobs with mu != 2^29, exact-FFT engine entry points).  A
  * binding compares nufhe_abi_version() with the macro of the header it was written against before the first real
  * call (nufhe_amd/_lib.py does). */
-#define NUFHE_ABI_VERSION 5
+#define NUFHE_ABI_VERSION 6
 
 const char *nufhe_last_error(void);
 const char *nufhe_version(void);

@@ -135,7 +135,7 @@ PROTOTYPES = {
 }
 
 # NUFHE_ABI_VERSION of the include/nufhe_hip.h these prototypes were written against
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 
@@ -179,6 +179,8 @@ def check(rc):
     msg = lib().nufhe_last_error().decode("utf-8", "replace")
     if rc == -1:
         raise ValueError(msg)
+    if rc == -5:
+        raise MemoryError(msg)
     raise NufheError("nufhe_hip error %d: %s" % (rc, msg))
 
 

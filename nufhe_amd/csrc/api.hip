@@ -7,7 +7,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
-#include <string>
+#include <exception>
+#include <new>
 #include <vector>
 
 #include "../../include/nufhe_hip.h"
@@ -16,18 +17,30 @@
 
 namespace {
 
-thread_local std::string g_last_error;
+// a fixed buffer, not a std::string: fail() is called from the catch handlers of the boundary and must not allocate
+thread_local char g_last_error[512] = {0};
 
-int fail(int code, const char *fmt, ...)
+int fail(int code, const char *fmt, ...) noexcept
 {
-    char buf[512];
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
     va_end(ap);
-    g_last_error = buf;
     return code;
 }
+
+// Every extern "C" body sits between these two: no C++ exception crosses the boundary (include/nufhe_hip.h).  The host
+// side allocates (contexts, key holders, staging vectors, job tables): std::bad_alloc becomes NUFHE_ENOMEM, anything
+// else NUFHE_EHIP, both with a message for nufhe_last_error().
+#define NUFHE_API_BEGIN try {
+#define NUFHE_API_END                                                                                      \
+    } catch (const std::bad_alloc &) {                                                                     \
+        return fail(NUFHE_ENOMEM, "%s: out of host memory (std::bad_alloc)", __func__);                    \
+    } catch (const std::exception &ex) {                                                                   \
+        return fail(NUFHE_EHIP, "%s: unexpected C++ exception: %s", __func__, ex.what());                  \
+    } catch (...) {                                                                                        \
+        return fail(NUFHE_EHIP, "%s: unexpected C++ exception", __func__);                                 \
+    }
 
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
@@ -104,15 +117,34 @@ struct nufhe_cloudkey {
 
 namespace {
 
+// is the context's stream being captured into a graph?  (a failed query counts as "no" and leaves no sticky error)
+bool stream_capturing(nufhe_ctx *ctx)
+{
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &cap) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cap != hipStreamCaptureStatusNone;
+}
+
+// buffers retired under a pin whose release fell into a capture (nufhe_ctx_pin_scratch) are freed by the next
+// non-capturing call that comes through here
+void free_retired_if_unpinned(nufhe_ctx *ctx)
+{
+    if (ctx->scratch_pins != 0 || ctx->retired.empty()) return;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { (void)hipGetLastError(); return; }
+    for (void *p : ctx->retired) hipFree(p);
+    ctx->retired.clear();
+}
+
 int ensure(nufhe_ctx *ctx, Scratch &s, size_t bytes)
 {
     if (s.bytes >= bytes) return NUFHE_OK;
     HIP_TRY(hipSetDevice(ctx->device));
+    // no allocation of any kind during a capture: neither growth nor a first-time hipMalloc
+    if (stream_capturing(ctx))
+        return fail(NUFHE_EINVAL, "a scratch buffer would have to grow (%zu -> %zu bytes) during stream capture: run the "
+                    "circuit once eagerly at this size before capturing it", s.bytes, bytes);
+    free_retired_if_unpinned(ctx);
     if (s.ptr) {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
-            return fail(NUFHE_EINVAL, "a scratch buffer would have to grow (%zu -> %zu bytes) during stream capture: run the "
-                        "circuit once eagerly at this size before capturing it", s.bytes, bytes);
         if (ctx->scratch_pins > 0) {
             ctx->retired.push_back(s.ptr);          // a captured graph may still point into it
         } else {
@@ -202,10 +234,7 @@ void profile_commit(nufhe_ctx *ctx, hipEvent_t pe[3])
 // elapsed time
 bool profiling_now(nufhe_ctx *ctx)
 {
-    if (!ctx->profile) return false;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(ctx->stream, &cap) != hipSuccess) { (void)hipGetLastError(); return true; }
-    return cap == hipStreamCaptureStatusNone;
+    return ctx->profile && !stream_capturing(ctx);
 }
 
 int pick_j_per_block(long nbits, int input_size, int num_cus)
@@ -265,12 +294,13 @@ int run_keyswitch(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result, 
 
 extern "C" {
 
-const char *nufhe_last_error(void) { return g_last_error.c_str(); }
-const char *nufhe_version(void) { return "nufhe_hip 0.4 (gfx950)"; }
+const char *nufhe_last_error(void) { return g_last_error; }
+const char *nufhe_version(void) { return "nufhe_hip 0.6 (gfx950)"; }
 int nufhe_abi_version(void) { return NUFHE_ABI_VERSION; }
 
 int nufhe_device_count(int *count)
 {
+    NUFHE_API_BEGIN
     if (!count) return fail(NUFHE_EINVAL, "null argument");
     int c = 0;
     hipError_t e = hipGetDeviceCount(&c);
@@ -280,19 +310,23 @@ int nufhe_device_count(int *count)
     }
     *count = c;
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_device_name(int device, char *buf, size_t buflen)
 {
+    NUFHE_API_BEGIN
     if (!buf || !buflen) return fail(NUFHE_EINVAL, "null argument");
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_ctx_create(int device, void *stream, int own_stream, nufhe_ctx **out)
 {
+    NUFHE_API_BEGIN
     if (!out) return fail(NUFHE_EINVAL, "null argument");
     int count = 0;
     int rc = nufhe_device_count(&count);
@@ -343,10 +377,12 @@ int nufhe_ctx_create(int device, void *stream, int own_stream, nufhe_ctx **out)
     }
     *out = ctx;
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_ctx_destroy(nufhe_ctx *ctx)
 {
+    NUFHE_API_BEGIN
     if (!ctx) return NUFHE_OK;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
@@ -373,59 +409,72 @@ int nufhe_ctx_destroy(nufhe_ctx *ctx)
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_ctx_synchronize(nufhe_ctx *ctx)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_ctx_device(nufhe_ctx *ctx, int *device)
 {
+    NUFHE_API_BEGIN
     if (!ctx || !device) return fail(NUFHE_EINVAL, "null argument");
     *device = ctx->device;
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 void *nufhe_ctx_stream(nufhe_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 int nufhe_alloc(nufhe_ctx *ctx, size_t bytes, void **d_ptr)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (!d_ptr) return fail(NUFHE_EINVAL, "null argument");
     HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 1));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_free(nufhe_ctx *ctx, void *d_ptr)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipFree(d_ptr));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_h2d(nufhe_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_d2h(nufhe_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 // ---- single-process multi-GPU: result collection (SURVEY 8b "nufhe_gather(ctxs...)") ------------------
@@ -438,6 +487,7 @@ int nufhe_d2h(nufhe_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
 int nufhe_gather(nufhe_ctx *dst, void *d_dst, const size_t *dst_offsets, nufhe_ctx *const *srcs, const void *const *d_srcs,
                  const size_t *bytes, int count)
 {
+    NUFHE_API_BEGIN
     if (!dst || !srcs || !d_srcs || !bytes || !dst_offsets || count < 0) return fail(NUFHE_EINVAL, "null argument");
     for (int i = 0; i < count; i++) {
         if (!srcs[i]) return fail(NUFHE_EINVAL, "null source context %d", i);
@@ -448,9 +498,12 @@ int nufhe_gather(nufhe_ctx *dst, void *d_dst, const size_t *dst_offsets, nufhe_c
     // Ordering contract, both ways.  (1) The copies wait for everything ALREADY QUEUED on dst's stream: d_dst may be a
     // recycled block whose last user -- a kernel still in flight on dst's stream -- must finish before a source stream
     // writes into it.  (2) dst's stream waits for every copy, so whatever is queued on dst afterwards sees the slices.
-    HIP_TRY(hipSetDevice(dst->device));
-    HIP_TRY(hipEventRecord(dst->ev_dst, dst->stream));
     int rc = NUFHE_OK;
+    {
+        hipError_t e = hipSetDevice(dst->device);
+        if (e == hipSuccess) e = hipEventRecord(dst->ev_dst, dst->stream);
+        if (e != hipSuccess) rc = fail(NUFHE_EHIP, "nufhe_gather, destination stream: %s", hipGetErrorString(e));
+    }
     for (int i = 0; i < count && rc == NUFHE_OK; i++) {
         if (!bytes[i]) continue;
         nufhe_ctx *src = srcs[i];
@@ -474,12 +527,14 @@ int nufhe_gather(nufhe_ctx *dst, void *d_dst, const size_t *dst_offsets, nufhe_c
     // the calling thread's current device is left as it was found
     if (caller_device >= 0) (void)hipSetDevice(caller_device);
     return rc;
+    NUFHE_API_END
 }
 
 // ---- cloud key ---------------------------------------------------------------------------
 
 int nufhe_cloudkey_create(nufhe_ctx *ctx, int lwe_size, int transform, int mask_size, nufhe_cloudkey **key)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (!key) return fail(NUFHE_EINVAL, "null argument");
@@ -496,10 +551,12 @@ int nufhe_cloudkey_create(nufhe_ctx *ctx, int lwe_size, int transform, int mask_
     k->mask_size = mask_size;
     *key = k;
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_cloudkey_destroy(nufhe_cloudkey *key)
 {
+    NUFHE_API_BEGIN
     if (!key) return NUFHE_OK;
     hipSetDevice(key->ctx->device);
     hipStreamSynchronize(key->ctx->stream);
@@ -512,6 +569,7 @@ int nufhe_cloudkey_destroy(nufhe_cloudkey *key)
     if (key->d_cv_table) hipFree(key->d_cv_table);
     delete key;
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 static int alloc_bk(nufhe_cloudkey *key)
@@ -522,6 +580,7 @@ static int alloc_bk(nufhe_cloudkey *key)
 
 int nufhe_bk_upload_reference(nufhe_cloudkey *key, const void *h_bk)
 {
+    NUFHE_API_BEGIN
     if (!key || !h_bk) return fail(NUFHE_EINVAL, "null argument");
     nufhe_ctx *ctx = key->ctx;
     int rc = check_ctx(ctx);
@@ -540,10 +599,12 @@ int nufhe_bk_upload_reference(nufhe_cloudkey *key, const void *h_bk)
     hipFree(tmp);
     if (e != hipSuccess) return fail(NUFHE_EHIP, "bk upload: %s", hipGetErrorString(e));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_bk_download_reference(nufhe_cloudkey *key, void *h_bk)
 {
+    NUFHE_API_BEGIN
     if (!key || !h_bk) return fail(NUFHE_EINVAL, "null argument");
     nufhe_ctx *ctx = key->ctx;
     int rc = check_key(ctx, key, true, false);
@@ -559,10 +620,12 @@ int nufhe_bk_download_reference(nufhe_cloudkey *key, void *h_bk)
     hipFree(tmp);
     if (e != hipSuccess) return fail(NUFHE_EHIP, "bk download: %s", hipGetErrorString(e));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_bk_from_coeffs(nufhe_cloudkey *key, const int32_t *d_tgsw)
 {
+    NUFHE_API_BEGIN
     if (!key || !d_tgsw) return fail(NUFHE_EINVAL, "null argument");
     nufhe_ctx *ctx = key->ctx;
     int rc = check_ctx(ctx);
@@ -575,6 +638,7 @@ int nufhe_bk_from_coeffs(nufhe_cloudkey *key, const int32_t *d_tgsw)
     else
         HIP_TRY(launch_bkf_from_coeffs((cplx *)key->d_bk, d_tgsw, key->bk_polys(), ctx->d_ftw1, ctx->d_ftw2, ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 // Uniform-variance keys (KsFinal::cv_table): table of the float32 partial sums v, v + v, (v + v) + v, ...
@@ -614,6 +678,7 @@ static int build_ks_planes(nufhe_cloudkey *key)
 
 int nufhe_ks_upload(nufhe_cloudkey *key, const int32_t *h_ks_a, const int32_t *h_ks_b, const float *h_ks_cv)
 {
+    NUFHE_API_BEGIN
     if (!key || !h_ks_a || !h_ks_b || !h_ks_cv) return fail(NUFHE_EINVAL, "null argument");
     nufhe_ctx *ctx = key->ctx;
     int rc = check_ctx(ctx);
@@ -647,6 +712,7 @@ int nufhe_ks_upload(nufhe_cloudkey *key, const int32_t *h_ks_a, const int32_t *h
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 // ---- device image of a whole cloud key (replication over RCCL: examples/multi_gpu.py) ----
@@ -684,15 +750,18 @@ static void image_layout(const nufhe_cloudkey *key, size_t off[5])
 
 int nufhe_cloudkey_image_bytes(nufhe_cloudkey *key, size_t *bytes)
 {
+    NUFHE_API_BEGIN
     if (!key || !bytes) return fail(NUFHE_EINVAL, "null argument");
     size_t off[5];
     image_layout(key, off);
     *bytes = off[4];
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_cloudkey_export_image(nufhe_cloudkey *key, void *d_image)
 {
+    NUFHE_API_BEGIN
     if (!key || !d_image) return fail(NUFHE_EINVAL, "null argument");
     nufhe_ctx *ctx = key->ctx;
     int rc = check_key(ctx, key, true, true);
@@ -713,10 +782,12 @@ int nufhe_cloudkey_export_image(nufhe_cloudkey *key, void *d_image)
     HIP_TRY(hipMemcpyAsync(dst, head, sizeof(head), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));      // `head` is a stack buffer
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_cloudkey_import_image(nufhe_cloudkey *key, const void *d_image)
 {
+    NUFHE_API_BEGIN
     if (!key || !d_image) return fail(NUFHE_EINVAL, "null argument");
     nufhe_ctx *ctx = key->ctx;
     int rc = check_ctx(ctx);
@@ -757,11 +828,13 @@ int nufhe_cloudkey_import_image(nufhe_cloudkey *key, const void *d_image)
         for (int h = 1; h < 4; h++)
             if (cv[r * 4 + h] != v0) { uniform = false; break; }
     return set_cv_table(key, uniform && v0 >= 0.0f, v0);
+    NUFHE_API_END
 }
 
 int nufhe_ks_make(nufhe_cloudkey *key, const int32_t *d_noises_a, const int32_t *d_noises_b, const int32_t *d_in_key,
                   const int32_t *d_out_key, float variance)
 {
+    NUFHE_API_BEGIN
     if (!key || !d_noises_a || !d_noises_b || !d_in_key || !d_out_key) return fail(NUFHE_EINVAL, "null argument");
     nufhe_ctx *ctx = key->ctx;
     int rc = check_ctx(ctx);
@@ -777,10 +850,12 @@ int nufhe_ks_make(nufhe_cloudkey *key, const int32_t *d_noises_a, const int32_t 
     int rcp = build_ks_planes(key);
     if (rcp) return rcp;
     return set_cv_table(key, variance >= 0.0f, variance);
+    NUFHE_API_END
 }
 
 int nufhe_ks_download_reference(nufhe_cloudkey *key, int32_t *h_ks_a, int32_t *h_ks_b, float *h_ks_cv)
 {
+    NUFHE_API_BEGIN
     if (!key || !h_ks_a || !h_ks_b || !h_ks_cv) return fail(NUFHE_EINVAL, "null argument");
     nufhe_ctx *ctx = key->ctx;
     int rc = check_key(ctx, key, false, true);
@@ -797,22 +872,26 @@ int nufhe_ks_download_reference(nufhe_cloudkey *key, int32_t *h_ks_a, int32_t *h
     hipFree(tmp);
     if (e != hipSuccess) return fail(NUFHE_EHIP, "ks download: %s", hipGetErrorString(e));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_tgsw_add_message(nufhe_ctx *ctx, int32_t *d_tgsw, const int32_t *d_messages, long count, int mask_size)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (!d_tgsw || !d_messages) return fail(NUFHE_EINVAL, "null argument");
     if (count < 0 || mask_size < 1) return fail(NUFHE_EINVAL, "bad sizes");
     HIP_TRY(launch_tgsw_add_message(d_tgsw, d_messages, count, mask_size, ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 // ---- hot path ----------------------------------------------------------------------------
 
 int nufhe_lwe_linear(nufhe_ctx *ctx, nufhe_lwe res, nufhe_lwe src, int32_t p, int add_result, long nbits, int size)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (nbits < 0 || size < 1) return fail(NUFHE_EINVAL, "bad sizes");
@@ -820,16 +899,19 @@ int nufhe_lwe_linear(nufhe_ctx *ctx, nufhe_lwe res, nufhe_lwe src, int32_t p, in
         return rc;
     HIP_TRY(launch_lwe_linear(view(res), view(src), p, add_result, nbits, size, ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_lwe_trivial_const(nufhe_ctx *ctx, nufhe_lwe res, int32_t mu, long nbits, int size)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (nbits < 0 || size < 1) return fail(NUFHE_EINVAL, "bad sizes");
     if ((rc = check_lwe(res, size, "lwe_trivial_const result", true, nbits, true))) return rc;
     HIP_TRY(launch_lwe_trivial_const(view(res), mu, nbits, size, ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 // the context's tuning with the legacy per-switch overrides applied (nufhe_ctx_set_team_max_bits: an explicit value
@@ -932,6 +1014,7 @@ static int run_gate(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result
 int nufhe_bootstrap(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe_lwe x, int32_t mu, long nbits,
                     int no_keyswitch)
 {
+    NUFHE_API_BEGIN
     int rc = check_key(ctx, key, true, !no_keyswitch);
     if (rc) return rc;
     if ((rc = check_lwe(x, key->n, "bootstrap input", false, nbits)) ||
@@ -942,10 +1025,12 @@ int nufhe_bootstrap(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe
     job.s0 = source(x, 1);
     job.c0 = 0;
     return run_gate(ctx, key, result, &job, 1, mu, nbits, !no_keyswitch, 0);
+    NUFHE_API_END
 }
 
 int nufhe_keyswitch(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe_lwe src, long nbits)
 {
+    NUFHE_API_BEGIN
     int rc = check_key(ctx, key, false, true);
     if (rc) return rc;
     if (nbits < 0) return fail(NUFHE_EINVAL, "negative batch size");
@@ -968,11 +1053,13 @@ int nufhe_keyswitch(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe
         profile_commit(ctx, pe);
     }
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_gate_binary(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe_lwe a, nufhe_lwe b, int32_t c,
                       int32_t pa, int32_t pb, int32_t mu, long nbits)
 {
+    NUFHE_API_BEGIN
     int rc = check_key(ctx, key, true, true);
     if (rc) return rc;
     if ((rc = check_lwe(result, key->n, "gate result", true, nbits, true)) || (rc = check_lwe(a, key->n, "gate operand a", false, nbits)) ||
@@ -984,11 +1071,13 @@ int nufhe_gate_binary(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nuf
     job.s1 = source(b, pb);
     job.c0 = c;
     return run_gate(ctx, key, result, &job, 1, mu, nbits, true, 0);
+    NUFHE_API_END
 }
 
 int nufhe_gate_mux(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe_lwe a, nufhe_lwe b, nufhe_lwe c,
                    long nbits)
 {
+    NUFHE_API_BEGIN
     int rc = check_key(ctx, key, true, true);
     if (rc) return rc;
     if ((rc = check_lwe(result, key->n, "mux result", true, nbits, true)) || (rc = check_lwe(a, key->n, "mux operand a", false, nbits)) ||
@@ -1000,10 +1089,12 @@ int nufhe_gate_mux(nufhe_ctx *ctx, nufhe_cloudkey *key, nufhe_lwe result, nufhe_
     jobs[0].s0 = source(a, 1);  jobs[0].s1 = source(b, 1);  jobs[0].c0 = -MU;   // (0,-1/8) + a + b, gates.py:639-641
     jobs[1].s0 = source(a, -1); jobs[1].s1 = source(c, 1);  jobs[1].c0 = -MU;   // (0,-1/8) - a + c, gates.py:648-650
     return run_gate(ctx, key, result, jobs, 2, MU, nbits, true, MU);             // (0,1/8) + u1 + u2 -> KS, :657-664
+    NUFHE_API_END
 }
 
 int nufhe_gate_batch(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_gate_job *jobs, int n_jobs, int32_t mu)
 {
+    NUFHE_API_BEGIN
     int rc = check_key(ctx, key, true, true);
     if (rc) return rc;
     if (n_jobs < 0 || (n_jobs > 0 && !jobs)) return fail(NUFHE_EINVAL, "null job list");
@@ -1029,6 +1120,33 @@ int nufhe_gate_batch(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_gate_job *
         live += g.nbits > 0;
     }
     if (out_bits == 0) return NUFHE_OK;
+    // the MUX fold and pre-combination are written for the gate constant 1/8 (gates.py:639-664)
+    if (mux_bits > 0 && mu != (i32)(1u << 29))
+        return fail(NUFHE_EINVAL, "a batch with NUFHE_JOB_MUX jobs needs mu = 2^29 (got %d)", (int)mu);
+    // result views of two jobs must not overlap: their finalize blocks run concurrently.  Views are `nbits` rows of
+    // `width` words `stride` apart; two views whose byte ranges meet are still disjoint when they interleave rows of
+    // one array (equal strides, row offsets at least a row apart modulo the stride).
+    auto rows_meet = [](const int32_t *p, long sp, long np, const int32_t *q, long sq, long nq, long width) {
+        const long pb = (long)(intptr_t)p, qb = (long)(intptr_t)q, w = width * (long)sizeof(i32);
+        const long pe = pb + (np - 1) * sp * (long)sizeof(i32) + w, qe = qb + (nq - 1) * sq * (long)sizeof(i32) + w;
+        if (pe <= qb || qe <= pb) return false;
+        if (sp == sq && sp > 0) {
+            const long s = sp * (long)sizeof(i32);
+            const long d = ((qb - pb) % s + s) % s;
+            if (d >= w && s - d >= w) return false;
+        }
+        return true;
+    };
+    for (int j = 0; j < n_jobs; j++) {
+        const nufhe_gate_job &gj = jobs[j];
+        for (int i = 0; i < j && gj.nbits > 0; i++) {
+            const nufhe_gate_job &gi = jobs[i];
+            if (gi.nbits == 0) continue;
+            if (rows_meet(gi.result.a, gi.result.a_stride, gi.nbits, gj.result.a, gj.result.a_stride, gj.nbits, key->n) ||
+                rows_meet(gi.result.b, gi.result.b_stride, gi.nbits, gj.result.b, gj.result.b_stride, gj.nbits, 1))
+                return fail(NUFHE_EINVAL, "jobs %d and %d: result views overlap", i, j);
+        }
+    }
     const long rows = out_bits + mux_bits;
     // tables: first rotations of all gates in job order (row = output bit), then the second rotations of the MUX gates
     std::vector<BatchRot> rots;
@@ -1118,78 +1236,96 @@ int nufhe_gate_batch(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_gate_job *
         profile_commit(ctx, pe);
     }
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_ctx_pin_scratch(nufhe_ctx *ctx, int delta)
 {
-    int rc = check_ctx(ctx);
-    if (rc) return rc;
+    NUFHE_API_BEGIN
+    // (called from GateGraph.__del__, i.e. at whatever moment garbage collection runs: the caller's current device is
+    // left as found, and while the stream is being captured nothing is synchronised or freed -- the retired buffers wait
+    // for the next non-capturing ensure() / pin call)
+    if (!ctx) return fail(NUFHE_EINVAL, "null context");
     if (ctx->scratch_pins + delta < 0) return fail(NUFHE_EINVAL, "scratch pin count would become negative");
     ctx->scratch_pins += delta;
-    if (ctx->scratch_pins == 0 && !ctx->retired.empty()) {
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        for (void *p : ctx->retired) hipFree(p);
-        ctx->retired.clear();
-    }
+    if (ctx->scratch_pins != 0 || ctx->retired.empty()) return NUFHE_OK;
+    int caller_device = -1;
+    HIP_TRY(hipGetDevice(&caller_device));
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess && !stream_capturing(ctx)) free_retired_if_unpinned(ctx);
+    if (caller_device >= 0) (void)hipSetDevice(caller_device);
+    if (e != hipSuccess) return fail(NUFHE_EHIP, "nufhe_ctx_pin_scratch: %s", hipGetErrorString(e));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_lwe_phase(nufhe_ctx *ctx, int32_t *d_out, long out_stride, const int32_t *d_a, long a_stride,
                     const int32_t *d_base, long base_stride, const int32_t *d_key, int32_t sign, long count, int size)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (count < 0 || size < 1) return fail(NUFHE_EINVAL, "bad sizes");
     if (sign != 1 && sign != -1) return fail(NUFHE_EINVAL, "sign must be +1 or -1");
     HIP_TRY(launch_lwe_phase(d_out, out_stride, d_a, a_stride, d_base, base_stride, d_key, sign, count, size, ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 // ---- per-kernel entry points -------------------------------------------------------------
 
 int nufhe_t32_to_phase(nufhe_ctx *ctx, int32_t *d_result, const int32_t *d_phase, long count, uint32_t mspace_size)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (mspace_size == 0) return fail(NUFHE_EINVAL, "mspace_size must be positive");
     HIP_TRY(launch_t32_to_phase(d_result, d_phase, count, mspace_size, ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_shift_torus_polynomial(nufhe_ctx *ctx, int32_t *d_result, const int32_t *d_source, const int32_t *d_powers,
                                  long powers_stride, long powers_idx, long batch, int polys, int minus_one,
                                  int invert_powers)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     HIP_TRY(launch_shift_tp(d_result, d_source, d_powers, powers_stride, powers_idx, batch, polys, minus_one,
                             invert_powers, ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_tlwe_extract(nufhe_ctx *ctx, int32_t *d_result_a, int32_t *d_result_b, const int32_t *d_tlwe, long batch,
                        int mask_size)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (mask_size < 1) return fail(NUFHE_EINVAL, "mask_size must be positive");
     HIP_TRY(launch_tlwe_extract(d_result_a, d_result_b, d_tlwe, batch, mask_size, ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_tgsw_decompose(nufhe_ctx *ctx, int32_t *d_result, const int32_t *d_sample, long polys)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (polys < 0) return fail(NUFHE_EINVAL, "negative polynomial count");
     if (polys && (!d_result || !d_sample)) return fail(NUFHE_EINVAL, "null argument");
     HIP_TRY(launch_tgsw_decompose(d_result, d_sample, polys, ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_tgsw_mac(nufhe_ctx *ctx, uint64_t *d_result, const uint64_t *d_sample, const uint64_t *d_bk, int bk_len,
                    int bk_row, long batch, int mask_size)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (mask_size != 1 && mask_size != 2) return fail(NUFHE_EINVAL, "mask_size must be 1 or 2");
@@ -1198,88 +1334,108 @@ int nufhe_tgsw_mac(nufhe_ctx *ctx, uint64_t *d_result, const uint64_t *d_sample,
     if (batch && (!d_result || !d_sample || !d_bk)) return fail(NUFHE_EINVAL, "null argument");
     HIP_TRY(launch_tgsw_mac(d_result, d_sample, d_bk, bk_row, batch, mask_size, ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_ntt_forward_i32(nufhe_ctx *ctx, uint64_t *d_out, const int32_t *d_in, long batch)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     HIP_TRY(launch_ntt_forward(d_out, d_in, 0, batch, ctx->d_tw1f, ctx->d_tw1i, ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_ntt_forward_u64(nufhe_ctx *ctx, uint64_t *d_out, const uint64_t *d_in, long batch)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     HIP_TRY(launch_ntt_forward(d_out, d_in, 1, batch, ctx->d_tw1f, ctx->d_tw1i, ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_ntt_inverse_i32(nufhe_ctx *ctx, int32_t *d_out, const uint64_t *d_in, long batch)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     HIP_TRY(launch_ntt_inverse(d_out, d_in, 0, batch, ctx->d_tw1f, ctx->d_tw1i, ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_ntt_inverse_u64(nufhe_ctx *ctx, uint64_t *d_out, const uint64_t *d_in, long batch)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     HIP_TRY(launch_ntt_inverse(d_out, d_in, 1, batch, ctx->d_tw1f, ctx->d_tw1i, ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_fft_forward_i32(nufhe_ctx *ctx, double *d_out, const int32_t *d_in, long batch)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     HIP_TRY(launch_fft_forward((cplx *)d_out, d_in, batch, ctx->d_ftw1, ctx->d_ftw2, ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_fft_inverse_i32(nufhe_ctx *ctx, int32_t *d_out, const double *d_in, long batch)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     HIP_TRY(launch_fft_inverse(d_out, (const cplx *)d_in, batch, ctx->d_ftw1, ctx->d_ftw2, ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_ff_op(nufhe_ctx *ctx, uint64_t *d_out, const uint64_t *d_a, const uint64_t *d_b, const uint64_t *d_c,
                 const uint64_t *d_d, const uint64_t *d_e, int op, int shift, long count)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (op < 0 || op > 8 || shift < 0 || shift >= 192) return fail(NUFHE_EINVAL, "bad ff op %d / shift %d", op, shift);
     HIP_TRY(launch_ff_op(d_out, d_a, d_b, d_c, d_d, d_e, op, shift, count, ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_l4_op(nufhe_ctx *ctx, uint32_t *d_out, uint32_t *d_out2, const uint32_t *d_a, const uint32_t *d_b,
                 const uint32_t *d_c, int op, int shift, long count)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (op < 0 || op > 10 || shift < 0 || shift >= 192) return fail(NUFHE_EINVAL, "bad limb op %d / shift %d", op, shift);
     if (!d_out || !d_out2 || !d_a) return fail(NUFHE_EINVAL, "null operand");
     HIP_TRY(launch_l4_op(d_out, d_out2, d_a, d_b, d_c, op, shift, count, ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_poly_mul_i32(nufhe_ctx *ctx, int32_t *d_out, const int32_t *d_x, const int32_t *d_y, long batch, long y_batch)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (y_batch < 1) return fail(NUFHE_EINVAL, "y_batch must be positive");
     HIP_TRY(launch_poly_mul(d_out, d_x, d_y, nullptr, 1024, batch, y_batch, ctx->d_tw1f, ctx->d_tw1i, ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_external_mul(nufhe_ctx *ctx, nufhe_cloudkey *key, int32_t *d_accum, int bk_row, long batch)
 {
+    NUFHE_API_BEGIN
     int rc = check_key(ctx, key, true, false);
     if (rc) return rc;
     if (bk_row < 0 || bk_row >= key->n) return fail(NUFHE_EINVAL, "bk_row %d out of range", bk_row);
@@ -1289,11 +1445,13 @@ int nufhe_external_mul(nufhe_ctx *ctx, nufhe_cloudkey *key, int32_t *d_accum, in
                                       fft ? (const void *)ctx->d_ftw2 : (const void *)ctx->d_tw1i, key->transform,
                                       key->mask_size, ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_blind_rotate(nufhe_ctx *ctx, nufhe_cloudkey *key, int32_t *d_accum, const int32_t *d_bara, long bara_stride,
                        int n_rows, long batch)
 {
+    NUFHE_API_BEGIN
     int rc = check_key(ctx, key, true, false);
     if (rc) return rc;
     if (n_rows < 0 || n_rows > key->n) return fail(NUFHE_EINVAL, "n_rows %d out of range", n_rows);
@@ -1303,11 +1461,13 @@ int nufhe_blind_rotate(nufhe_ctx *ctx, nufhe_cloudkey *key, int32_t *d_accum, co
                                       fft ? (const void *)ctx->d_ftw2 : (const void *)ctx->d_tw1i, key->transform,
                                       key->mask_size, ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_tlwe_encrypt_zero(nufhe_ctx *ctx, int32_t *d_result_a, const int32_t *d_key, const int32_t *d_noises1,
                             const int32_t *d_noises2, long batch, int mask_size)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (mask_size < 1) return fail(NUFHE_EINVAL, "mask_size must be positive");
@@ -1322,35 +1482,43 @@ int nufhe_tlwe_encrypt_zero(nufhe_ctx *ctx, int32_t *d_result_a, const int32_t *
                                         d_key + (size_t)i * 1024, i == 0 ? d_noises2 : body,
                                         i == 0 ? 1024L : (long)k1 * 1024, batch, ctx->d_tw1f, ctx->d_tw1i, ctx->stream));
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_ctx_set_team_max_bits(nufhe_ctx *ctx, long bits)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     ctx->team_max_bits = bits;
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_ctx_set_keyswitch_mfma(nufhe_ctx *ctx, int enable)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (enable < 0 || enable > 2) return fail(NUFHE_EINVAL, "keyswitch mode must be 0, 1 or 2");
     ctx->ks_mfma = enable;
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_ctx_set_pair_max_bits(nufhe_ctx *ctx, long bits)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     ctx->pair_max_bits = bits;
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_ctx_get_tuning(nufhe_ctx *ctx, nufhe_tuning *out)
 {
+    NUFHE_API_BEGIN
     if (!ctx || !out) return fail(NUFHE_EINVAL, "null argument");
     const BrTuning &T = ctx->tuning;
     memset(out, 0, sizeof(*out));
@@ -1361,10 +1529,12 @@ int nufhe_ctx_get_tuning(nufhe_ctx *ctx, nufhe_tuning *out)
     out->measured = T.measured; out->num_cus = T.num_cus;
     snprintf(out->arch_name, sizeof(out->arch_name), "%s", ctx->arch_name);
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_ctx_set_tuning(nufhe_ctx *ctx, const nufhe_tuning *in)
 {
+    NUFHE_API_BEGIN
     if (!ctx) return fail(NUFHE_EINVAL, "null context");
     if (!in) {                                   // NULL: back to what the device table says
         ctx->tuning = br_tuning_for(ctx->arch_name, ctx->num_cus);
@@ -1380,27 +1550,33 @@ int nufhe_ctx_set_tuning(nufhe_ctx *ctx, const nufhe_tuning *in)
     T.ring_k2 = in->ring_k2 != 0; T.k2_roomy_ratio_pct = in->k2_roomy_ratio_pct;
     T.measured = 0;                              // (num_cus and arch_name are the device's, not the caller's)
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_ctx_set_team8(nufhe_ctx *ctx, int enable)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     ctx->team8 = enable != 0;
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_profile_enable(nufhe_ctx *ctx, int enable)
 {
+    NUFHE_API_BEGIN
     if (!ctx) return fail(NUFHE_EINVAL, "null context");
     ctx->profile = enable != 0;
     ctx->ev_valid = false;
     ctx->ring_count = 0;
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_profile_history(nufhe_ctx *ctx, float *blind_rotate_ms, float *keyswitch_ms, int capacity, int *count)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (!count || capacity < 0 || (capacity > 0 && (!blind_rotate_ms || !keyswitch_ms))) return fail(NUFHE_EINVAL, "null argument");
@@ -1415,10 +1591,12 @@ int nufhe_profile_history(nufhe_ctx *ctx, float *blind_rotate_ms, float *keyswit
     *count = (int)n;
     ctx->ring_count = 0;
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_profile_last(nufhe_ctx *ctx, float *blind_rotate_ms, float *keyswitch_ms)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (!ctx->ev_valid) return fail(NUFHE_EINVAL, "no profiled launch recorded");
@@ -1429,10 +1607,12 @@ int nufhe_profile_last(nufhe_ctx *ctx, float *blind_rotate_ms, float *keyswitch_
     if (blind_rotate_ms) *blind_rotate_ms = br;
     if (keyswitch_ms) *keyswitch_ms = ks;
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_profile_clock(nufhe_ctx *ctx, double *shader_ghz, double *wave_ms)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (!ctx->ev_valid) return fail(NUFHE_EINVAL, "no profiled launch recorded");
@@ -1443,10 +1623,12 @@ int nufhe_profile_clock(nufhe_ctx *ctx, double *shader_ghz, double *wave_ms)
     if (shader_ghz) *shader_ghz = (double)h[0] / ((double)h[1] * 10.0);     // 100 MHz ticks = 10 ns
     if (wave_ms) *wave_ms = (double)h[1] * 1e-5;
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 int nufhe_profile_waves(nufhe_ctx *ctx, double *start_ms, double *end_ms, int *simd, int capacity, int *count)
 {
+    NUFHE_API_BEGIN
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (!ctx->ev_valid) return fail(NUFHE_EINVAL, "no profiled launch recorded");
@@ -1468,6 +1650,7 @@ int nufhe_profile_waves(nufhe_ctx *ctx, double *start_ms, double *end_ms, int *s
     *count = n;
     if (n == 0) return fail(NUFHE_EINVAL, "the last profiled launch did not run a wave-per-bit kernel");
     return NUFHE_OK;
+    NUFHE_API_END
 }
 
 }  // extern "C"

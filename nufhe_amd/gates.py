@@ -262,8 +262,17 @@ def gate_batch(thr, cloud_key, jobs, perf_params=None):
         if len(job) != (5 if name == 'gate_mux' else 4):
             raise ValueError("gate_batch: %s takes %d ciphertext arguments" % (name, 4 if name == 'gate_mux' else 3))
     if not single_kernel(perf_params):
+        # same contract as the fused path (include/nufhe_hip.h, nufhe_gate_batch): every operand is read before any
+        # result is written.  The gates run one after the other here, so each one writes a temporary and the results
+        # are stored at the end -- a job that names another job's result as an operand sees the old value in both modes.
+        temps = []
         for job in jobs:
-            globals()[job[0]](thr, cloud_key, *job[1:], perf_params=perf_params)
+            result = job[1]
+            tmp = LweSampleArray.empty(thr, result.params, result.shape)
+            globals()[job[0]](thr, cloud_key, tmp, *job[2:], perf_params=perf_params)
+            temps.append((result, tmp))
+        for result, tmp in temps:
+            lwe_copy(thr, result, tmp)
         return
     thr.check_stream()
     descs = (_lib.NufheGateJob * max(1, len(jobs)))()

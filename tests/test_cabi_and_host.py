@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     lib.nufhe_abi_version.restype = ctypes.c_int
     assert macro == built_lib.ABI_VERSION == lib.nufhe_abi_version()
     lib.nufhe_version.restype = ctypes.c_char_p
-    assert b'0.4' in lib.nufhe_version()
+    assert b'0.6' in lib.nufhe_version()
 
 
 def test_no_cpu_fallback(built_lib):
@@ -353,3 +353,19 @@ def test_bench_traffic_lookup_covers_every_baseline_configuration():
         # a MUX launch moves twice the key traffic of a NAND launch
         assert 1.8 < bench.pmc_traffic(tr, 'mux', 4096) / bench.pmc_traffic(tr, 'nand', 4096) < 2.2
     assert bench.pmc_traffic('NTT', 'nand', 77) is None
+
+
+def test_every_entry_point_catches_cpp_exceptions():
+    """include/nufhe_hip.h: "no exceptions cross the boundary" -- every `int nufhe_*` body of api.hip sits between
+    NUFHE_API_BEGIN / NUFHE_API_END (std::bad_alloc -> NUFHE_ENOMEM), and the binding maps -5 to MemoryError."""
+    src = open(os.path.join(ROOT, 'nufhe_amd', 'csrc', 'api.hip')).read()
+    body = src[src.index('extern "C" {'):]
+    defs = re.findall(r'^int (nufhe_\w+)\([^;{]*\)\n\{\n(.*?)^\}', body, re.S | re.M)
+    assert len(defs) >= 60
+    for name, text in defs:
+        assert text.lstrip().startswith('NUFHE_API_BEGIN') and text.rstrip().endswith('NUFHE_API_END'), name
+    header = open(os.path.join(ROOT, 'include', 'nufhe_hip.h')).read()
+    assert re.search(r'#define\s+NUFHE_ENOMEM\s+\(-5\)', header)
+    from nufhe_amd import _lib
+    import inspect
+    assert 'MemoryError' in inspect.getsource(_lib.check)
