@@ -90,7 +90,9 @@ def issue_roofline(transform, bits, rotations, n_iter, kernel_ms, live_clock_ghz
     pmc = _profile_json("pmc_%s.json" % transform)
     if mix is None:
         return None
-    k = mix["k_bootstrap<1>" if transform == "NTT" else "k_bootstrap_fft"]
+    k = mix.get({"NTT": "k_bootstrap<1>", "FFT": "k_bootstrap_fft", "XFFT": "k_bootstrap_xfft"}[transform])
+    if k is None:
+        return None
     iters = bits * rotations * n_iter
     out = {"isa_mix_per_iteration": {c: k.get(c, 0) for c in (
         "valu", "valu_plain", "valu_other", "valu_f64", "s_nop", "lds", "vmem", "scratch")},
@@ -307,6 +309,10 @@ def main():
     ap.add_argument("--bits", type=int, default=4096, help="bits per GPU")
     ap.add_argument("--transform", choices=["NTT", "FFT"], default="NTT",
                     help="NTT = BASELINE configs 2-4 (bit-exact path); FFT = config 5 (fp64, tolerance path)")
+    ap.add_argument("--engine", choices=["native", "exact-fft"], default="native",
+                    help="arithmetic of the NTT path: native = u64 prime-field NTT kernels (the BASELINE headline); "
+                         "exact-fft = fp64 folded FFT on a 16-bit split key, bit-identical by construction "
+                         "(nufhe_cloudkey_set_engine)")
     ap.add_argument("--cpu-sample-bits", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true",
@@ -368,6 +374,11 @@ def main():
         keygen_ms[label] = 1e3 * (time.perf_counter() - t_k)
         return pair
     secret_key, cloud_key = timed_key_pair(ctx, args.transform, transform_type=args.transform)
+    if args.engine != "native":
+        if args.transform != "NTT":
+            sys.exit("bench.py: --engine %s applies to --transform NTT" % args.engine)
+        cloud_key.set_engine(args.engine)
+    xfft = args.engine == "exact-fft"
     vm = ctx.make_virtual_machine(cloud_key)
 
     B = args.bits
@@ -513,7 +524,32 @@ def main():
         ok = bool((ctx_o.decrypt(sk_o, out3) == ~(ms[0] & ms[1])).all())
         other["gate_nand_%s" % other_tr] = {
             "ms_per_step_per_gpu": 1e3 * dt, "ms_per_bit": 1e3 * dt / B, "gates_per_s_per_gpu": B / dt, "correct": ok}
+        out3 = out3.copy()                               # (the buffer is reused below; this copy goes to the parity leg)
         del vm_o, ck_o
+        out4 = None
+        if args.transform == "NTT":
+            # the other engine of the NTT path on the SAME key and ciphertexts (its output words go through the same
+            # parity leg below: differing must be 0)
+            other_engine = "native" if xfft else "exact-fft"
+            out4 = vm.empty_ciphertext((B,))
+            cloud_key.set_engine(other_engine)
+            try:
+                t_img = time.perf_counter()
+                vm.gate_nand(cs[0][:1], cs[1][:1])                     # builds the split key image on first use
+                torch.cuda.synchronize()
+                keygen_ms["%s_engine_first_gate" % other_engine] = 1e3 * (time.perf_counter() - t_img)
+                dt = measure(lambda: vm.gate_nand(cs[0], cs[1], dest=out4))
+                out5 = vm.empty_ciphertext((B,))
+                dtm = measure(lambda: vm.gate_mux(cs[0], cs[1], cs[2], dest=out5))
+                del out5
+            finally:
+                cloud_key.set_engine(args.engine)
+            ok = bool((ctx.decrypt(secret_key, out4) == ~(ms[0] & ms[1])).all())
+            other["gate_nand_%s_engine_NTT" % other_engine.replace("-", "_")] = {
+                "engine": other_engine, "ms_per_step_per_gpu": 1e3 * dt, "ms_per_bit": 1e3 * dt / B,
+                "gates_per_s_per_gpu": B / dt, "correct": ok, "mux_ms_per_step_per_gpu": 1e3 * dtm,
+                "note": "same NTT key, same ciphertexts, the other engine of nufhe_cloudkey_set_engine; bit-identical "
+                        "outputs by construction (include/nufhe_hip.h), checked under `parity`"}
         if world == 1:
             ctx_k = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(123), thread=thr)
             for tr in ("NTT", "FFT"):
@@ -575,8 +611,8 @@ def main():
         achieved = a_kernel / (br_avg * 1e-3) / 1e9
         a_gate = (A_MUX if args.gate == "mux" else A_NAND) * B
         result = {
-            "metric": "bootstrapped gates/sec (%s), %d-bit batch per GPU, %s, n=500 N=1024 k=1 l=2" % (
-                args.gate.upper(), B, args.transform),
+            "metric": "bootstrapped gates/sec (%s), %d-bit batch per GPU, %s%s, n=500 N=1024 k=1 l=2" % (
+                args.gate.upper(), B, args.transform, " (exact-fft engine)" if xfft else ""),
             "value": gates_per_s,
             "unit": "gates/s",
             "n_gpus": world,
@@ -587,8 +623,10 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("u64 mod 2^64-2^32+1 (NTT) / int32 torus" if args.transform == "NTT"
+            "dtype": ("f64 complex (folded FFT-512 on a 16-bit split key: exact integer results) / int32 torus" if xfft
+                      else "u64 mod 2^64-2^32+1 (NTT) / int32 torus" if args.transform == "NTT"
                       else "f64 complex (folded FFT-512) / int32 torus"),
+            "engine": args.engine,
             "data": "synthetic (seeded keys and ciphertexts, resident in HBM)",
             "correct": correct,
             "config": {"workload": "gate_%s, %d-bit batch per GPU (BASELINE config %s)" % (
@@ -604,11 +642,18 @@ def main():
         # its denominator.  (Until round 4 the issue-model fraction was the headline `frac` and this object sat under
         # `streaming_model`; the numbers are the same, the one BASELINE names now comes first.)
         live_clock = sum(clock_ghz) / len(clock_ghz) if clock_ghz else None
-        issue = issue_roofline(args.transform, B, n_rot, 500, br_avg, live_clock) or {}
+        kernel_name = "k_bootstrap_xfft" if xfft else "k_bootstrap_fft" if args.transform == "FFT" else "k_bootstrap<1>"
+        issue = issue_roofline("XFFT" if xfft else args.transform, B, n_rot, 500, br_avg, live_clock) or {}
+        traffic = pmc_traffic("XFFT" if xfft else args.transform, args.gate, B)
+        if xfft:
+            a_kernel = 2 * a_kernel                 # the split key image is two fp64 planes: 65.5 MB per bit and rotation
+            achieved = a_kernel / (br_avg * 1e-3) / 1e9
         roof = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(args.transform, args.gate, B),
-            "kernel": "k_bootstrap%s (fused mod-switch + blind rotate + extract)" % ("_fft" if args.transform == "FFT" else ""),
+            "traffic": traffic,
+            "traffic_source": None if traffic is None else
+                              "tracked rocprofv3 --pmc pass of this same command (profiles/pmc_traffic.json), not this run",
+            "kernel": "%s (fused mod-switch + blind rotate + extract)" % kernel_name,
             "kernel_ms": br_avg, "keyswitch_ms": ks_avg,
             "algorithmic_bytes_per_launch": a_kernel,
             "gate_streaming_model_GBs": a_gate / (ms_per_step * 1e-3) / 1e9,
@@ -618,6 +663,18 @@ def main():
                     "algorithmic bytes: no wasted re-reads); the kernel is bound by VALU issue -- see `valu_issue`",
             "valu_issue": issue,
             "keyswitch": keyswitch_roofline(B, ks_avg, B > 2 * 256)}
+        if args.transform == "FFT" or xfft:
+            # the streaming-model axis carries no information for the fp64 kernels: key rows are shared by the resident
+            # waves through L2, so the model figure exceeds the HBM peak; the second axis is the vector fp64 rate
+            fp64 = (issue.get("isa_mix_per_iteration") or {}).get("valu_f64")
+            if fp64:
+                tflops = 2.0 * fp64 * 64 * B * n_rot * 500 / (br_avg * 1e-3) / 1e12      # an fp64 VALU instruction = 64 lanes x (fma = 2 flop; adds counted alike)
+                roof["fp64_vector"] = {"achieved_tflops_upper": tflops, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                                       "frac_upper": tflops / FP64_VECTOR_PEAK_TFLOPS,
+                                       "note": "fp64 VALU instructions per iteration (profiles/isa_mix.json) x 64 lanes x 2 flop over the "
+                                               "kernel time: an upper figure (adds and multiplies count as 2 like an fma)"}
+            roof["frac_note"] = ("streaming-model frac > 1 = L2 reuse of key rows between resident waves, not skipped work (the "
+                                 "parity leg checks the timed output); read `valu_issue` and `fp64_vector` for what bounds this kernel")
         if "clock_ghz_in_kernel" in issue:
             roof["clock_ghz_in_kernel"] = issue["clock_ghz_in_kernel"]
         if wave_ms:
@@ -682,6 +739,8 @@ def main():
             if not args.no_extra:
                 gpu_out["gate_%s_%s" % (other_gate, args.transform)] = (other_gate, args.transform == "NTT", host(out2))
                 gpu_out["gate_nand_%s" % other_tr] = ("nand", other_tr == "NTT", host(out3))
+                if out4 is not None:
+                    gpu_out["gate_nand_%s_engine_NTT" % other_engine.replace("-", "_")] = ("nand", True, host(out4))
             result["cpu_baseline"], result["parity"] = cpu_baseline_and_parity(
                 args.gate, sample, [host(c) for c in cs], gpu_out)
             result["parity"]["note"] = ("GPU output words (a[500] and b per bit) vs the CPU oracle on the same input "

@@ -93,6 +93,21 @@ int nufhe_gather(nufhe_ctx *dst, void *d_dst, const size_t *dst_offsets, nufhe_c
  * domain and the shape [n][k+1][2][k+1][...] of the bootstrapping key and the keyswitch input size k*1024. */
 int nufhe_cloudkey_create(nufhe_ctx *ctx, int lwe_size, int transform, int mask_size, nufhe_cloudkey **key);
 int nufhe_cloudkey_destroy(nufhe_cloudkey *key);
+
+/* ---- engine of the NTT path (no reference counterpart: the reference has one NTT implementation,
+ * polynomial_transform_ntt.py:29-131) ----
+ * The gates of a NUFHE_TRANSFORM_NTT key compute the EXACT integer negacyclic convolutions of tgsw_cpu.py:82-106; which
+ * arithmetic produces them is an implementation choice:
+ *   NUFHE_ENGINE_NATIVE     the 64-bit prime-field NTT kernels (u64 mod 2^64 - 2^32 + 1), the default;
+ *   NUFHE_ENGINE_EXACT_FFT  the fp64 folded FFT on a key whose coefficients are split into two balanced 16-bit halves:
+ *                           all sums stay below 2^36, where the worst-case fp64 error (0.037) cannot
+ *                           change a rounding -- the same words as the native engine for every key and every input,
+ *                           at ~0.4 x its time.  tlwe_mask_size 1 only.  The split image (65.5 MB for n = 500) is
+ *                           derived from the uploaded key on first use; key images / downloads are unaffected. */
+#define NUFHE_ENGINE_NATIVE 0
+#define NUFHE_ENGINE_EXACT_FFT 1
+int nufhe_cloudkey_set_engine(nufhe_cloudkey *key, int engine);
+int nufhe_cloudkey_get_engine(nufhe_cloudkey *key, int *engine);
 /* Bootstrapping key in the REFERENCE's storage format, as produced by TLweTransformSamples
  * (tlwe_gpu.py:199-236) and pickled by BootstrapKey.dump (bootstrap.py:78-80).  Host pointer.
  *   NTT key: uint64 [n][k+1][2][k+1][1024], natural-order NTT, Montgomery-prepared (x * 2^64)

@@ -60,6 +60,10 @@ class NufheTuning(ctypes.Structure):
     ]
 
 
+ENGINE_NATIVE = 0
+ENGINE_EXACT_FFT = 1
+ENGINES = {'native': ENGINE_NATIVE, 'ntt': ENGINE_NATIVE, 'exact-fft': ENGINE_EXACT_FFT, 'exact_fft': ENGINE_EXACT_FFT}
+
 JOB_BINARY = 0
 JOB_MUX = 1
 
@@ -96,6 +100,8 @@ PROTOTYPES = {
     "nufhe_tgsw_add_message": [_vp, _vp, _vp, _long, _int],
     "nufhe_l4_op": [_vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _long],
     "nufhe_cloudkey_destroy": [_vp],
+    "nufhe_cloudkey_set_engine": [_vp, _int],
+    "nufhe_cloudkey_get_engine": [_vp, ctypes.POINTER(_int)],
     "nufhe_bk_upload_reference": [_vp, _vp],
     "nufhe_bk_download_reference": [_vp, _vp],
     "nufhe_bk_from_coeffs": [_vp, _vp],

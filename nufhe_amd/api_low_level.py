@@ -146,6 +146,16 @@ class NuFHECloudKey:
             thr, rng, params.ks_decomp_length, params.ks_log2_base, secret_key.lwe_key, tgsw_key, native=native)
         return cls(params, bk, ks, native)
 
+    def set_engine(self, engine):
+        """'native' | 'exact-fft': which exact arithmetic computes this NTT key's gates (NativeCloudKey.set_engine);
+        results are bit-identical, the exact-FFT engine is ~2.4 x faster on large batches."""
+        self._native.set_engine(engine)
+        return self
+
+    @property
+    def engine(self):
+        return self._native.get_engine()
+
     def device_image(self):
         """(params, uint8 device tensor): the key as the kernels hold it, for device-to-device replication
         (multi_gpu.broadcast_cloud_key); the serialized form for everything else is dump / dumps."""

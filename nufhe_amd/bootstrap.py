@@ -15,6 +15,7 @@ device path to be compared with (tests/test_gpu_stepwise.py): same bits, ~100x t
 """
 
 import ctypes
+import os
 import pickle
 
 import numpy
@@ -50,6 +51,22 @@ class NativeCloudKey:
         ref = weakref.ref(thr)
         _lib.register_stream_guard(handle, lambda: (ref() is not None) and ref().check_stream())
         thr._cloud_keys.add(self)
+        default_engine = os.environ.get("NUFHE_NTT_ENGINE")
+        if default_engine and transform_type == 'NTT' and mask_size == 1:
+            self.set_engine(default_engine)
+
+    def set_engine(self, engine):
+        """Arithmetic behind the gates of an NTT key: 'native' (u64 prime-field NTT kernels) or 'exact-fft' (fp64 folded FFT
+        on a 16-bit split key: the same words for every input, ~0.4 x the time; include/nufhe_hip.h,
+        nufhe_cloudkey_set_engine).  The NUFHE_NTT_ENGINE environment variable sets the default of new keys."""
+        if engine not in _lib.ENGINES:
+            raise ValueError("unknown engine %r (one of %s)" % (engine, sorted(set(_lib.ENGINES))))
+        _lib.call("nufhe_cloudkey_set_engine", self.handle, _lib.ENGINES[engine])
+
+    def get_engine(self):
+        e = ctypes.c_int(0)
+        _lib.call("nufhe_cloudkey_get_engine", self.handle, ctypes.byref(e))
+        return {_lib.ENGINE_NATIVE: 'native', _lib.ENGINE_EXACT_FFT: 'exact-fft'}[e.value]
 
     def image_bytes(self):
         size = ctypes.c_size_t(0)

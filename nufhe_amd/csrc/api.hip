@@ -13,6 +13,7 @@
 
 #include "../../include/nufhe_hip.h"
 #include "kernels.h"
+#include "blind_rotate_xfft.h"
 #include "ntt_tables.h"
 
 namespace {
@@ -75,6 +76,7 @@ struct nufhe_ctx {
     cplx *d_ftw2 = nullptr;
     Scratch ext_a, ext_b, ks_acc, ks_digits;
     Scratch batch_a, batch_b;  // nufhe_gate_batch: the combined LWE(n) inputs of all rotations of a batch
+    Scratch xfft_park;         // exact-FFT engine: the accumulators' parking space, 8 KiB per rotation (blind_rotate_xfft.h)
     // Scratch that a captured hipGraph points into must not be freed while the graph lives: while scratch_pins > 0 a buffer
     // that has to grow is RETIRED (kept until the last pin is released) instead of freed (nufhe_ctx_pin_scratch)
     int scratch_pins = 0;
@@ -108,6 +110,11 @@ struct nufhe_cloudkey {
     void *d_bk = nullptr;     // wave layout: u64 [n][8][1024] or complex128 [n][8][512] (same bytes)
     u64 *d_bk_half = nullptr; // NTT, k = 1: the same key in the half-ring layout of k_bootstrap_team8, made on first use
     bool bk_half_valid = false;
+    // NTT, k = 1, engine NUFHE_ENGINE_EXACT_FFT: the same key as the split fp64 image of blind_rotate_xfft.h
+    // (complex128 [n][8][2][512], 65.5 MB), derived from d_bk on first use after every change of the key
+    int engine = 0;
+    cplx *d_bkx = nullptr;
+    bool bkx_valid = false;
     i32 *d_ks_a3 = nullptr;   // [k*1024][8][3][n]
     signed char *d_ks_planes = nullptr;   // the same key as signed byte planes in MFMA operand order (k_ks_planes)
     i32 *d_ks_b = nullptr;    // [k*1024][8][4]
@@ -399,6 +406,7 @@ int nufhe_ctx_destroy(nufhe_ctx *ctx)
     if (ctx->ks_digits.ptr) hipFree(ctx->ks_digits.ptr);
     if (ctx->batch_a.ptr) hipFree(ctx->batch_a.ptr);
     if (ctx->batch_b.ptr) hipFree(ctx->batch_b.ptr);
+    if (ctx->xfft_park.ptr) hipFree(ctx->xfft_park.ptr);
     for (void *p : ctx->retired) hipFree(p);
     for (auto &t : ctx->tables)
         if (t.ptr) hipFree(t.ptr);
@@ -562,12 +570,44 @@ int nufhe_cloudkey_destroy(nufhe_cloudkey *key)
     hipStreamSynchronize(key->ctx->stream);
     if (key->d_bk) hipFree(key->d_bk);
     if (key->d_bk_half) hipFree(key->d_bk_half);
+    if (key->d_bkx) hipFree(key->d_bkx);
     if (key->d_ks_a3) hipFree(key->d_ks_a3);
     if (key->d_ks_planes) hipFree(key->d_ks_planes);
     if (key->d_ks_b) hipFree(key->d_ks_b);
     if (key->d_ks_cv) hipFree(key->d_ks_cv);
     if (key->d_cv_table) hipFree(key->d_cv_table);
     delete key;
+    return NUFHE_OK;
+    NUFHE_API_END
+}
+
+int nufhe_cloudkey_set_engine(nufhe_cloudkey *key, int engine)
+{
+    NUFHE_API_BEGIN
+    if (!key) return fail(NUFHE_EINVAL, "null cloud key");
+    if (engine != NUFHE_ENGINE_NATIVE && engine != NUFHE_ENGINE_EXACT_FFT) return fail(NUFHE_EINVAL, "unknown engine %d", engine);
+    if (engine == NUFHE_ENGINE_EXACT_FFT && (key->transform != NUFHE_TRANSFORM_NTT || key->mask_size != 1))
+        return fail(NUFHE_EINVAL, "the exact-FFT engine serves NTT keys with tlwe_mask_size 1 (this key: transform %d, mask size %d)",
+                    key->transform, key->mask_size);
+    key->engine = engine;
+    if (engine == NUFHE_ENGINE_NATIVE && key->d_bkx) {
+        // the 65.5 MB image goes with the engine
+        int rc = check_ctx(key->ctx);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(key->ctx->stream));
+        HIP_TRY(hipFree(key->d_bkx));
+        key->d_bkx = nullptr;
+        key->bkx_valid = false;
+    }
+    return NUFHE_OK;
+    NUFHE_API_END
+}
+
+int nufhe_cloudkey_get_engine(nufhe_cloudkey *key, int *engine)
+{
+    NUFHE_API_BEGIN
+    if (!key || !engine) return fail(NUFHE_EINVAL, "null argument");
+    *engine = key->engine;
     return NUFHE_OK;
     NUFHE_API_END
 }
@@ -593,7 +633,7 @@ int nufhe_bk_upload_reference(nufhe_cloudkey *key, const void *h_bk)
     hipError_t e = hipMemcpyAsync(tmp, h_bk, bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess)
         e = key->transform == NUFHE_TRANSFORM_NTT
-                ? (key->bk_half_valid = false, launch_bk_from_reference((u64 *)key->d_bk, tmp, key->bk_polys(), ctx->stream))
+                ? (key->bk_half_valid = key->bkx_valid = false, launch_bk_from_reference((u64 *)key->d_bk, tmp, key->bk_polys(), ctx->stream))
                 : launch_bkf_permute((cplx *)key->d_bk, (const cplx *)tmp, key->bk_polys(), 0, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     hipFree(tmp);
@@ -632,7 +672,7 @@ int nufhe_bk_from_coeffs(nufhe_cloudkey *key, const int32_t *d_tgsw)
     if (rc) return rc;
     rc = alloc_bk(key);
     if (rc) return rc;
-    key->bk_half_valid = false;
+    key->bk_half_valid = key->bkx_valid = false;
     if (key->transform == NUFHE_TRANSFORM_NTT)
         HIP_TRY(launch_bk_from_coeffs((u64 *)key->d_bk, d_tgsw, key->bk_polys(), ctx->d_tw1f, ctx->d_tw1i, ctx->stream));
     else
@@ -816,7 +856,7 @@ int nufhe_cloudkey_import_image(nufhe_cloudkey *key, const void *d_image)
                            rows * 4 * sizeof(int32_t), rows * 4 * sizeof(float)};
     for (int i = 0; i < 4; i++)
         HIP_TRY(hipMemcpyAsync(dst[i], src + off[i], len[i], hipMemcpyDeviceToDevice, ctx->stream));
-    key->bk_half_valid = false;
+    key->bk_half_valid = key->bkx_valid = false;
     if ((rc = build_ks_planes(key))) return rc;
     // the variance table of a uniform-variance key (what nufhe_ks_upload derives from the host arrays)
     std::vector<float> cv(rows * 4);
@@ -914,6 +954,40 @@ int nufhe_lwe_trivial_const(nufhe_ctx *ctx, nufhe_lwe res, int32_t mu, long nbit
     NUFHE_API_END
 }
 
+// exact-FFT engine: (re)build the split fp64 image of an NTT key from its device copy -- inverse NTT of every key
+// polynomial back to its int32 coefficients (exact), 16-bit split, forward FFT of both halves (kernels_xfft.hip)
+static int ensure_bkx(nufhe_ctx *ctx, nufhe_cloudkey *key)
+{
+    if (key->bkx_valid) return NUFHE_OK;
+    if (stream_capturing(ctx))
+        return fail(NUFHE_EINVAL, "the exact-FFT key image is built on first use: run one gate eagerly before capturing");
+    const long polys = key->bk_polys();
+    if (!key->d_bkx) HIP_TRY(hipMalloc((void **)&key->d_bkx, (size_t)polys * BKX_POLY_ELEMS * sizeof(cplx)));
+    i32 *coeffs = nullptr;      // [polys][1024] coefficients, then one flag word
+    HIP_TRY(hipMalloc((void **)&coeffs, ((size_t)polys * 1024 + 1) * sizeof(i32)));
+    int *flag = (int *)(coeffs + (size_t)polys * 1024);
+    int not_int32 = 0;
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), ctx->stream);
+    if (e == hipSuccess) e = launch_bk_to_coeffs(coeffs, (const u64 *)key->d_bk, polys, ctx->d_tw1f, ctx->d_tw1i, flag, ctx->stream);
+    if (e == hipSuccess) e = launch_bkx_from_coeffs(key->d_bkx, coeffs, polys, ctx->d_ftw1, ctx->d_ftw2, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&not_int32, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(coeffs);
+    if (e != hipSuccess) return fail(NUFHE_EHIP, "exact-FFT key image: %s", hipGetErrorString(e));
+    // the engine's guarantee covers keys made of int32 torus polynomials (every key the scheme generates); a key of
+    // arbitrary field elements (synthetic test data) has 64-bit coefficients and only the prime-field kernels compute with it
+    if (not_int32)
+        return fail(NUFHE_EINVAL, "the bootstrapping key is not the transform of int32 polynomials: the exact-FFT engine "
+                    "cannot serve it (use NUFHE_ENGINE_NATIVE)");
+    key->bkx_valid = true;
+    return NUFHE_OK;
+}
+
+static bool uses_xfft(const nufhe_cloudkey *key)
+{
+    return key->engine == NUFHE_ENGINE_EXACT_FFT && key->transform == NUFHE_TRANSFORM_NTT && key->mask_size == 1;
+}
+
 // the context's tuning with the legacy per-switch overrides applied (nufhe_ctx_set_team_max_bits: an explicit value
 // counts half for the FFT kernels; nufhe_ctx_set_pair_max_bits: the NTT k = 1 limit itself, for FFT / k = 2 an on-off switch)
 static BrTuning effective_tuning(const nufhe_ctx *ctx)
@@ -931,8 +1005,24 @@ static BrTuning effective_tuning(const nufhe_ctx *ctx)
 }
 
 // key, tables and kernel-family preparation common to every fused bootstrap launch of `total` rotations
-static void prepare_launch(nufhe_ctx *ctx, nufhe_cloudkey *key, BrLaunch &P, long total, i32 mu)
+// *transform receives the kernel family to launch (the key's transform, or BR_TRANSFORM_XFFT for the exact-FFT engine)
+static int prepare_launch(nufhe_ctx *ctx, nufhe_cloudkey *key, BrLaunch &P, long total, i32 mu, int *transform)
 {
+    *transform = key->transform;
+    if (uses_xfft(key)) {
+        int rc = ensure_bkx(ctx, key);
+        if (rc) return rc;
+        if ((rc = ensure(ctx, ctx->xfft_park, (size_t)total * 2048 * sizeof(u32)))) return rc;
+        P.nbits_total = total;
+        P.bk = key->d_bkx;
+        P.park = (u32 *)ctx->xfft_park.ptr;
+        P.n = key->n;
+        P.mu = mu;
+        P.tw_a = ctx->d_ftw1;
+        P.tw_b = ctx->d_ftw2;
+        *transform = BR_TRANSFORM_XFFT;
+        return NUFHE_OK;
+    }
     P.nbits_total = total;
     P.bk = key->d_bk;
     P.bk_half = nullptr;
@@ -960,6 +1050,7 @@ static void prepare_launch(nufhe_ctx *ctx, nufhe_cloudkey *key, BrLaunch &P, lon
     const bool fft = key->transform == NUFHE_TRANSFORM_FFT;
     P.tw_a = fft ? (const void *)ctx->d_ftw1 : (const void *)ctx->d_tw1x;
     P.tw_b = fft ? (const void *)ctx->d_ftw2 : (const void *)ctx->d_tw1i;
+    return NUFHE_OK;
 }
 
 // shared by bootstrap / gate_binary / gate_mux: jobs -> (optional keyswitch) -> result
@@ -973,7 +1064,11 @@ static int run_gate(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result
     memset(&P, 0, sizeof(P));
     for (int j = 0; j < njobs; j++) P.job[j] = jobs[j];
     P.bits_per_job = nbits;
-    prepare_launch(ctx, key, P, total, mu);
+    int transform = 0;
+    {
+        int rcp = prepare_launch(ctx, key, P, total, mu, &transform);
+        if (rcp) return rcp;
+    }
     const bool prof = profiling_now(ctx);
     P.clock_probe = prof ? ctx->d_clock : nullptr;
     if (keyswitch) {
@@ -995,7 +1090,7 @@ static int run_gate(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_lwe &result
         HIP_TRY(hipMemsetAsync(ctx->d_clock, 0, CLOCK_PROBE_WORDS * sizeof(unsigned long long), ctx->stream));
         HIP_TRY(hipEventRecord(pe[0], ctx->stream));
     }
-    HIP_TRY(launch_bootstrap(P, key->transform, key->mask_size, effective_tuning(ctx), ctx->stream));
+    HIP_TRY(launch_bootstrap(P, transform, key->mask_size, effective_tuning(ctx), ctx->stream));
     if (prof) HIP_TRY(hipEventRecord(pe[1], ctx->stream));
     if (keyswitch) {
         const i32 *ea = (const i32 *)ctx->ext_a.ptr, *eb = (const i32 *)ctx->ext_b.ptr;
@@ -1210,7 +1305,8 @@ int nufhe_gate_batch(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_gate_job *
     P.job[0].s0 = BrSource{(const i32 *)ctx->batch_a.ptr, (const i32 *)ctx->batch_b.ptr, (long)key->n, 1, 1};
     P.job[0].c0 = 0;
     P.bits_per_job = rows;
-    prepare_launch(ctx, key, P, rows, mu);
+    int transform = 0;
+    if ((rc = prepare_launch(ctx, key, P, rows, mu, &transform))) return rc;
     const bool prof = profiling_now(ctx);
     P.clock_probe = prof ? ctx->d_clock : nullptr;
     P.out_a = (i32 *)ctx->ext_a.ptr; P.out_a_stride = ext;
@@ -1221,7 +1317,7 @@ int nufhe_gate_batch(nufhe_ctx *ctx, nufhe_cloudkey *key, const nufhe_gate_job *
         HIP_TRY(hipMemsetAsync(ctx->d_clock, 0, CLOCK_PROBE_WORDS * sizeof(unsigned long long), ctx->stream));
         HIP_TRY(hipEventRecord(pe[0], ctx->stream));
     }
-    HIP_TRY(launch_bootstrap(P, key->transform, key->mask_size, effective_tuning(ctx), ctx->stream));
+    HIP_TRY(launch_bootstrap(P, transform, key->mask_size, effective_tuning(ctx), ctx->stream));
     if (prof) HIP_TRY(hipEventRecord(pe[1], ctx->stream));
     if (mux_bits > 0)
         HIP_TRY(launch_batch_mux_fold((i32 *)ctx->ext_a.ptr, (i32 *)ctx->ext_b.ptr, d_outs, (int)outs.size(), out_bits, ext, MU8,
@@ -1439,6 +1535,12 @@ int nufhe_external_mul(nufhe_ctx *ctx, nufhe_cloudkey *key, int32_t *d_accum, in
     int rc = check_key(ctx, key, true, false);
     if (rc) return rc;
     if (bk_row < 0 || bk_row >= key->n) return fail(NUFHE_EINVAL, "bk_row %d out of range", bk_row);
+    if (uses_xfft(key)) {
+        if ((rc = ensure_bkx(ctx, key)) || (rc = ensure(ctx, ctx->xfft_park, (size_t)batch * 2048 * sizeof(u32)))) return rc;
+        HIP_TRY(launch_blind_rotate_accum_xfft(d_accum, key->d_bkx, nullptr, 0, bk_row, 1, 1, batch, ctx->d_ftw1, ctx->d_ftw2,
+                                               (u32 *)ctx->xfft_park.ptr, ctx->stream));
+        return NUFHE_OK;
+    }
     const bool fft = key->transform == NUFHE_TRANSFORM_FFT;
     HIP_TRY(launch_blind_rotate_accum(d_accum, key->d_bk, nullptr, 0, bk_row, 1, 1, batch,
                                       fft ? (const void *)ctx->d_ftw1 : (const void *)ctx->d_tw1x,
@@ -1455,6 +1557,12 @@ int nufhe_blind_rotate(nufhe_ctx *ctx, nufhe_cloudkey *key, int32_t *d_accum, co
     int rc = check_key(ctx, key, true, false);
     if (rc) return rc;
     if (n_rows < 0 || n_rows > key->n) return fail(NUFHE_EINVAL, "n_rows %d out of range", n_rows);
+    if (uses_xfft(key)) {
+        if ((rc = ensure_bkx(ctx, key)) || (rc = ensure(ctx, ctx->xfft_park, (size_t)batch * 2048 * sizeof(u32)))) return rc;
+        HIP_TRY(launch_blind_rotate_accum_xfft(d_accum, key->d_bkx, d_bara, bara_stride, 0, n_rows, 0, batch, ctx->d_ftw1,
+                                               ctx->d_ftw2, (u32 *)ctx->xfft_park.ptr, ctx->stream));
+        return NUFHE_OK;
+    }
     const bool fft = key->transform == NUFHE_TRANSFORM_FFT;
     HIP_TRY(launch_blind_rotate_accum(d_accum, key->d_bk, d_bara, bara_stride, 0, n_rows, 0, batch,
                                       fft ? (const void *)ctx->d_ftw1 : (const void *)ctx->d_tw1x,

@@ -39,6 +39,8 @@ struct BrLaunch {
     // profiling only (nufhe_profile_enable), else nullptr: wave 0 of work-group 0 of the wave-per-bit kernels stores
     // how long it lived, {shader-clock ticks (s_memtime), constant 100 MHz ticks (s_memrealtime)}
     unsigned long long *clock_probe;     // nullptr or CLOCK_PROBE_WORDS words (ClockProbe, kernels.hip)
+    // exact-FFT engine (transform 2, kernels_xfft.hip): global parking space of the accumulators, 2048 words per bit
+    u32 *park;
 };
 
 struct KsLaunch {
@@ -125,7 +127,8 @@ struct BrTuning {
 BrTuning br_tuning_for(const char *arch_name, int num_cus);
 
 hipError_t kernels_init_device(int *num_cus, char *arch_name, size_t arch_len);
-// transform: 0 = NTT, 1 = FFT
+// transform: 0 = NTT, 1 = FFT, 2 = exact FFT on a split key (NTT parameters, P.bk = the split image, P.park set)
+#define BR_TRANSFORM_XFFT 2
 hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, const BrTuning &T, hipStream_t stream);
 hipError_t launch_ff_op(u64 *out, const u64 *a, const u64 *b, const u64 *c, const u64 *d, const u64 *e, int op,
                         int shift, long count, hipStream_t stream);
@@ -144,6 +147,18 @@ hipError_t launch_fft_inverse(i32 *out, const cplx *in, long batch, const cplx *
                               hipStream_t stream);
 hipError_t launch_bkf_from_coeffs(cplx *out, const i32 *in, long polys, const cplx *tw1, const cplx *tw2,
                                   hipStream_t stream);
+// exact-FFT engine (kernels_xfft.hip)
+hipError_t xfft_init();
+hipError_t launch_bootstrap_xfft(const BrLaunch &P, int num_cus, hipStream_t stream);
+hipError_t launch_blind_rotate_accum_xfft(i32 *accum, const cplx *bkx, const i32 *bara, long bara_stride, int row0, int n_rows,
+                                          int external_mul_only, long batch, const cplx *tw1, const cplx *tw2, u32 *park,
+                                          hipStream_t stream);
+// int32 TGSW polynomials [polys][1024] -> split key image complex128 [polys][2][8][64] (blind_rotate_xfft.h)
+hipError_t launch_bkx_from_coeffs(cplx *out, const i32 *in, long polys, const cplx *tw1, const cplx *tw2, hipStream_t stream);
+// NTT key in the wave layout -> its int32 coefficients [polys][1024]
+// (*not_int32, a zeroed device word, is set when some coefficient is not a centred 32-bit integer)
+hipError_t launch_bk_to_coeffs(i32 *out, const u64 *bk_wave, long polys, const u64 *tw1f, const u64 *tw1i, int *not_int32,
+                               hipStream_t stream);
 hipError_t launch_bkf_permute(cplx *out, const cplx *in, long polys, int to_reference, hipStream_t stream);
 hipError_t launch_ntt_forward(u64 *out, const void *in, int mode, long batch, const u64 *tw1f, const u64 *tw1i,
                               hipStream_t stream);

@@ -10,6 +10,7 @@
 #include "kernels.h"
 #include "ntt1024.h"
 #include "l4_hook.h"
+#include "kernel_parts.h"
 
 // ------------------------------------------------------------------------------------------
 // LDS carving
@@ -22,12 +23,9 @@
 #define WAVE_ACC_BYTES WAVE_ACC_BYTES_K(1)
 #define WAVE_BARA_BYTES (BR_MAX_LWE * 2)
 #define WAVE_BR_LDS_BYTES_K(K) (WAVE_XBUF_BYTES + WAVE_ACC_BYTES_K(K) + WAVE_BARA_BYTES)
-#define BR_PACE_BYTES 128                 /* pacing words of the one-bit kernels, see carve_pace */
 // waves (= bits) per work-group, one work-group per CU: mask size 1 runs 2 waves/SIMD (<= 256 VGPRs,
 // ~19 KiB of LDS each); mask size 2 has a 12 KiB accumulator mirror per wave, 6 waves fill the LDS
 #define BR_WAVES_K(K) ((K) == 1 ? 8 : 6)
-
-extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
 
 __device__ __forceinline__ void load_tables(const u64 *__restrict__ g_tw1f, const u64 *__restrict__ g_tw1i)
 {
@@ -38,35 +36,6 @@ __device__ __forceinline__ void load_tables(const u64 *__restrict__ g_tw1f, cons
     }
     if (threadIdx.x < BR_PACE_BYTES / 4) ((u32 *)(g_smem + TABLE_LDS_BYTES))[threadIdx.x] = 0;
     __syncthreads();
-}
-
-// Pacing words behind the tables at `base` (zeroed by load_tables / load_ftables): [0..7] progress counter of wave w,
-// [8..15] arrival counters of the pair kernel, [16..19] number of registered waves per SIMD, [20..27] their indices.
-// Every wave of the work-group must call this (it contains a work-group barrier); waves that will run a bit
-// (`active`) register under the SIMD they were placed on (HW_REG_HW_ID bits 5:4 -- observed: SIMDs are dealt in the
-// cyclic order 0, 2, 1, 3 from a varying start, so waves w and w + 4 meet, but nothing guarantees it), and a wave
-// that finds exactly one other active wave on its SIMD paces itself against it (BrPace, blind_rotate.h).
-__device__ __forceinline__ BrPace carve_pace(unsigned char *base, int wave, bool active)
-{
-    u32 *words = (u32 *)base;
-    wave = __builtin_amdgcn_readfirstlane(wave);
-    const int simd = (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));    // HW_ID.SIMD_ID
-    u32 slot = 0;
-    if (active && (threadIdx.x & 63) == 0) {
-        slot = atomicAdd(&words[16 + simd], 1u);
-        if (slot < 2) words[20 + 2 * simd + slot] = (u32)wave;
-    }
-    slot = (u32)__builtin_amdgcn_readfirstlane((int)slot);
-    __syncthreads();
-    BrPace p;
-    p.mine = nullptr;
-    p.other = nullptr;
-    if (active && words[16 + simd] == 2u) {
-        const int other = __builtin_amdgcn_readfirstlane((int)words[20 + 2 * simd + (slot ^ 1u)]);
-        p.mine = words + wave;
-        p.other = words + other;
-    }
-    return p;
 }
 
 template <int K>
@@ -83,36 +52,6 @@ __device__ __forceinline__ BrLds carve_br_lds(int wave)
     lds.tw1i = (const u64 *)g_smem + 1024;
     return lds;
 }
-
-// life time of the waves of work-group 0 in both clocks (BrLaunch::clock_probe): words [0], [1] = shader-clock and
-// 100 MHz ticks of wave 0 (their ratio is the sustained shader clock of the launch); then, for each of its up to 8
-// waves w, words [2 + 3 w ..] = start, end (100 MHz ticks) and 1 + the SIMD the wave ran on -- what the pacing
-// self-check reads (two waves that share a SIMD must end together)
-struct ClockProbe {
-    long long t0, r0;
-    __device__ __forceinline__ void begin(const BrLaunch &P)
-    {
-        if (P.clock_probe && blockIdx.x == 0 && (threadIdx.x & 63) == 0) { t0 = clock64(); r0 = wall_clock64(); }
-    }
-    __device__ __forceinline__ void end(const BrLaunch &P) const
-    {
-        if (P.clock_probe && blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
-            const long long t1 = clock64(), r1 = wall_clock64();
-            const unsigned wave = threadIdx.x >> 6;
-            if (wave == 0) {
-                P.clock_probe[0] = (unsigned long long)(t1 - t0);
-                P.clock_probe[1] = (unsigned long long)(r1 - r0);
-            }
-            if (wave < 8) {
-                unsigned hw;
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-                P.clock_probe[2 + 3 * wave] = (unsigned long long)r0;
-                P.clock_probe[3 + 3 * wave] = (unsigned long long)r1;
-                P.clock_probe[4 + 3 * wave] = 1ull + ((hw >> 4) & 3u);
-            }
-        }
-    }
-};
 
 // ------------------------------------------------------------------------------------------
 // K1: fused bootstrap (prologue + blind rotate + extract), one wave per bit
@@ -312,22 +251,11 @@ __global__ __launch_bounds__(64 * BR_WAVES_K(K), K == 1 ? 2 : 1) void k_blind_ro
 // FFT variants (BASELINE config 5).  LDS: tw1 (8 KiB) | tw2 (1 KiB) | per wave: xbuf 9216 B,
 // accumulator mirror 8 KiB, bara 1 KiB
 // ------------------------------------------------------------------------------------------
-#define FTABLE_LDS_BYTES ((FFT_TW1_ELEMS + FFT_TW2_ELEMS) * 16)
-#define WAVE_FXBUF_BYTES (FFT_XBUF_ELEMS * 16)
 #define WAVE_BRF_LDS_BYTES (2 * WAVE_FXBUF_BYTES + BRF_PARK_EXTRA_BYTES)   /* acc mirror and bara are aliased: blind_rotate_fft.h */
 #define BRF_BASE_PAD 128   /* tables | pacing words | pad: every per-wave region then starts at a multiple of 256 bytes and the
                               constant part of the accumulator-mirror addresses folds into the offsets of ds_read2st64_b32 */
 static_assert((FTABLE_LDS_BYTES + BR_PACE_BYTES + BRF_BASE_PAD) % 256 == 0 && WAVE_BRF_LDS_BYTES % 256 == 0 && WAVE_FXBUF_BYTES % 256 == 0,
               "per-wave LDS regions of k_bootstrap_fft are 256-byte aligned");
-
-__device__ __forceinline__ void load_ftables(const cplx *__restrict__ g_tw1, const cplx *__restrict__ g_tw2)
-{
-    cplx *t = (cplx *)g_smem;
-    for (int i = threadIdx.x; i < FFT_TW1_ELEMS; i += blockDim.x) t[i] = g_tw1[i];
-    for (int i = threadIdx.x; i < FFT_TW2_ELEMS; i += blockDim.x) t[FFT_TW1_ELEMS + i] = g_tw2[i];
-    if (threadIdx.x < BR_PACE_BYTES / 4) ((u32 *)(g_smem + FTABLE_LDS_BYTES))[threadIdx.x] = 0;
-    __syncthreads();
-}
 
 __device__ __forceinline__ BrFftLds carve_brf_lds(int wave)
 {
@@ -880,6 +808,34 @@ __global__ __launch_bounds__(NTT_BLOCK_THREADS) void k_bk_from_coeffs(u64 *__res
     for (int r = 0; r < 16; r++) out[p * 1024 + bk_elem_offset(lane, r)] = x[r];
 }
 
+// NTT key in the wave layout -> coefficient-domain TGSW polynomials (int32): the inverse of k_bk_from_coeffs (the exact-FFT
+// engine builds its split key image from them, nufhe_cloudkey_set_engine)
+// *not_int32 is set when a coefficient is not a centred 32-bit integer, i.e. the key is not the transform of int32 torus
+// polynomials (synthetic keys of random field elements): the exact engine cannot serve such a key and says so.
+__global__ __launch_bounds__(NTT_BLOCK_THREADS) void k_bk_to_coeffs(i32 *__restrict__ out, const u64 *__restrict__ in,
+                                                                    long polys, const u64 *__restrict__ tw1f,
+                                                                    const u64 *__restrict__ tw1i, int *__restrict__ not_int32)
+{
+    load_tables(tw1f, tw1i);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long p = (long)blockIdx.x * NTT_WAVES_PER_BLOCK + wave;
+    if (p >= polys) return;
+    const NttLane L = ntt_lane_init(lane);
+    u64 x[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[r] = ff_canon(in[p * 1024 + bk_elem_offset(lane, r)]);
+    ntt_inverse(x, carve_ntt_xbuf(wave), (const u64 *)g_smem + 1024, L);
+#pragma unroll
+    for (int r = 0; r < 16; r++) out[p * 1024 + ntt_coef_index(lane, r)] = ff_to_i32(x[r]);
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const u64 v = ff_canon(x[r]);
+        bad |= !(v < (1ull << 31) || v >= FF_P - (1ull << 31));
+    }
+    if (bad) atomicOr(not_int32, 1);
+}
+
 // ------------------------------------------------------------------------------------------
 // K2: LWE keyswitch (lwe_gpu.mako:59-120, lwe_cpu.py:62-93)
 //   out_a[bit][c] = - sum_{j < 1024, k < 8} KS_a[j][k][digit_jk(src_a[bit][j])][c]
@@ -1286,7 +1242,6 @@ __global__ void k_l4_op(u32 *__restrict__ out, u32 *__restrict__ out2, const u32
 // ------------------------------------------------------------------------------------------
 // Host launchers
 // ------------------------------------------------------------------------------------------
-static inline unsigned blocks_for(long n, int per) { return (unsigned)((n + per - 1) / per); }
 
 static constexpr size_t br_lds_bytes(int K, int waves) { return TABLE_LDS_BYTES + BR_PACE_BYTES + (size_t)waves * WAVE_BR_LDS_BYTES_K(K); }
 static constexpr size_t br_lds_bytes(int K) { return br_lds_bytes(K, BR_WAVES_K(K)); }
@@ -1295,20 +1250,6 @@ static constexpr size_t brf_lds_bytes(int waves) { return FTABLE_LDS_BYTES + BR_
 static_assert(brf_lds_bytes(BR_WAVES_PER_BLOCK) <= 160 * 1024, "LDS budget of k_bootstrap_fft");
 static const size_t kBrfLds = brf_lds_bytes(BR_WAVES_PER_BLOCK);
 
-// Waves (= bits) per work-group for a batch of nbits: one work-group per CU and `max_waves` waves
-// fill a CU, so a batch that does not fill the chip is spread over as many CUs as possible (a wave
-// that has a SIMD to itself runs its 500 iterations ~1.7x sooner than two waves sharing one) and a
-// batch needing r rounds uses the smallest group size that still needs r rounds.
-static int br_pick_waves(long nbits, int max_waves, int num_cus)
-{
-    const long per_round = (long)num_cus * max_waves;
-    const long rounds = (nbits + per_round - 1) / per_round;
-    const long groups = (long)num_cus * rounds;
-    long w = (nbits + groups - 1) / groups;
-    if (w < 1) w = 1;
-    if (w > max_waves) w = max_waves;
-    return (int)w;
-}
 static const size_t kFftLds = FTABLE_LDS_BYTES + (size_t)FFT_WAVES_PER_BLOCK * WAVE_FXBUF_BYTES;
 
 // per-device one-time setup: the fused kernels use up to ~156 KiB of dynamic LDS (> the 64 KiB default cap)
@@ -1343,6 +1284,8 @@ hipError_t kernels_init_device(int *num_cus, char *arch_name, size_t arch_len)
     e = team8_init();
     if (e != hipSuccess) return e;
     e = team_init();
+    if (e != hipSuccess) return e;
+    e = xfft_init();
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)brp_lds_bytes(BRP_MAX_PAIRS));
     if (e != hipSuccess) return e;
@@ -1450,6 +1393,10 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, con
     // size) kernel; FFT k = 1: pair kernel up to pair_max_bits_fft (team kernel up to team_max_bits_fft when the pair
     // switch is 0), k = 2: team kernel, then the ring kernel
     const int num_cus = T.num_cus;
+    if (transform == BR_TRANSFORM_XFFT) {
+        if (mask_size != 1 || !P.park) return hipErrorInvalidValue;
+        return launch_bootstrap_xfft(P, num_cus, stream);
+    }
     const long team_max_bits = transform == 0 ? T.team_max_bits : 2 * T.team_max_bits_fft;    // (FFT: halved again below)
     const long pair_max_bits = transform == 0 ? (mask_size == 1 ? T.pair_max_bits_ntt : (long)T.ring_k2)
                                               : (mask_size == 1 ? T.pair_max_bits_fft : (long)T.ring_k2);
@@ -1616,6 +1563,15 @@ hipError_t launch_ntt_inverse(void *out, const u64 *in, int mode, long batch, co
     const dim3 grid(blocks_for(batch, NTT_WAVES_PER_BLOCK)), block(NTT_BLOCK_THREADS);
     if (mode == 0) hipLaunchKernelGGL(k_ntt_inverse<0>, grid, block, kNttLds, stream, out, in, batch, tw1f, tw1i);
     else hipLaunchKernelGGL(k_ntt_inverse<1>, grid, block, kNttLds, stream, out, in, batch, tw1f, tw1i);
+    return hipGetLastError();
+}
+
+hipError_t launch_bk_to_coeffs(i32 *out, const u64 *bk_wave, long polys, const u64 *tw1f, const u64 *tw1i, int *not_int32,
+                               hipStream_t stream)
+{
+    if (polys == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_bk_to_coeffs, dim3(blocks_for(polys, NTT_WAVES_PER_BLOCK)), dim3(NTT_BLOCK_THREADS), kNttLds, stream,
+                       out, bk_wave, polys, tw1f, tw1i, not_int32);
     return hipGetLastError();
 }
 

@@ -1,0 +1,162 @@
+// kernels_xfft.hip -- the exact-FFT engine for NTT-parameter keys (blind_rotate_xfft.h): __global__ wrappers, the key
+// image builder and the launchers.  A translation unit of its own: its register budget is tuned separately from the
+// frozen kernels of kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include "blind_rotate_xfft.h"
+#include "kernel_parts.h"
+
+// per-wave LDS: the two exchange buffers (accumulator mirror aliased onto B, bara in the row padding of A)
+#define WAVE_BRX_LDS_BYTES (2 * WAVE_FXBUF_BYTES)
+#define BRX_BASE_PAD 128
+static_assert((FTABLE_LDS_BYTES + BR_PACE_BYTES + BRX_BASE_PAD) % 256 == 0 && WAVE_BRX_LDS_BYTES % 256 == 0,
+              "per-wave LDS regions of k_bootstrap_xfft are 256-byte aligned");
+static constexpr size_t brx_lds_bytes(int waves) { return FTABLE_LDS_BYTES + BR_PACE_BYTES + BRX_BASE_PAD + (size_t)waves * WAVE_BRX_LDS_BYTES; }
+static_assert(brx_lds_bytes(BR_WAVES_PER_BLOCK) <= 160 * 1024, "LDS budget of k_bootstrap_xfft");
+
+__device__ __forceinline__ BrXfftLds carve_brx_lds(int wave)
+{
+    unsigned char *base = g_smem + FTABLE_LDS_BYTES + BR_PACE_BYTES + BRX_BASE_PAD + wave * WAVE_BRX_LDS_BYTES;
+    BrXfftLds lds;
+    lds.pace.mine = nullptr;
+    lds.pace.other = nullptr;
+    lds.xbufA = (cplx *)base;
+    lds.xbufB = (cplx *)(base + WAVE_FXBUF_BYTES);
+    lds.tw1 = (const cplx *)g_smem;
+    lds.tw2 = (const cplx *)g_smem + FFT_TW1_ELEMS;
+    lds.park = nullptr;
+    return lds;
+}
+
+__global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_bootstrap_xfft(BrLaunch P)
+{
+    load_ftables((const cplx *)P.tw_a, (const cplx *)P.tw_b);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long gbit = (long)blockIdx.x * (blockDim.x >> 6) + wave;   // waves per group chosen at launch
+    const BrPace pace = carve_pace(g_smem + FTABLE_LDS_BYTES, wave, gbit < P.nbits_total);
+    if (gbit >= P.nbits_total) return;
+    const int job = gbit >= P.bits_per_job ? 1 : 0;
+    const long bit = gbit - (job ? P.bits_per_job : 0);
+
+    BrXfftLds lds = carve_brx_lds(wave);
+    lds.pace = pace;
+    lds.park = P.park + gbit * 2048;
+    const FftLane L = fft_lane_init(lane);
+    const u32 barb = brf_prologue(P.job[job].s0, P.job[job].s1, P.job[job].c0, bit, P.n, brx_as_fft_lds(lds), lane);
+    WAVE_SYNC();
+    u32 acc[2][16];
+    ClockProbe probe;
+    probe.begin(P);
+    brx_blind_rotate(acc, (const cplx *)P.bk, P.n, barb, P.mu, lds, L);
+    probe.end(P);
+    br_extract<1>(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, acc, lane);
+}
+
+// step-by-step driver / nufhe_external_mul / nufhe_blind_rotate on the exact engine (cf. k_blind_rotate_accum_fft)
+__global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_blind_rotate_accum_xfft(
+    i32 *__restrict__ accum, const cplx *__restrict__ bk, const i32 *__restrict__ bara, long bara_stride,
+    int row0, int n_rows, int external_mul_only, long batch, const cplx *__restrict__ tw1,
+    const cplx *__restrict__ tw2, u32 *__restrict__ park)
+{
+    load_ftables(tw1, tw2);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long bit = (long)blockIdx.x * BR_WAVES_PER_BLOCK + wave;
+    if (bit >= batch) return;
+    BrXfftLds lds = carve_brx_lds(wave);
+    lds.park = park + bit * 2048;
+    const FftLane L = fft_lane_init(lane);
+    i32 *my = accum + bit * 2048;
+    i32 *mirror = (i32 *)lds.xbufB;
+    u32 acc[2][16];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            acc[m][r] = (u32)my[m * 1024 + lane + 64 * r];
+            mirror[m * 1024 + lane + 64 * r] = (i32)acc[m][r];
+        }
+    WAVE_SYNC();
+    if (external_mul_only) {
+        u32 res[2][16];
+        brx_external_product(res, acc, bk + (long)row0 * BKX_ROW_ELEMS, lds, lds.tw2, L);
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][r] = res[m][r];
+    } else {
+        for (int i = 0; i < n_rows; i++) {
+            const u32 a = WAVE_UNIFORM((u32)bara[bit * bara_stride + i]) & 2047u;
+            if (a == 0) continue;
+            brx_step(acc, a, bk + (long)(row0 + i) * BKX_ROW_ELEMS, lds, lds.tw2, L);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) my[m * 1024 + lane + 64 * r] = (i32)acc[m][r];
+}
+
+// Split key image: one wave per (polynomial, half).  K = lo + 2^16 hi (xfft_split), each half through the forward
+// transform, stored in the wave layout of the product phase: [poly][half][reg][lane].
+#define BKX_WAVES_PER_BLOCK 4
+__global__ __launch_bounds__(64 * BKX_WAVES_PER_BLOCK) void k_bkx_from_coeffs(cplx *__restrict__ out, const i32 *__restrict__ in,
+                                                                               long polys, const cplx *__restrict__ tw1,
+                                                                               const cplx *__restrict__ tw2)
+{
+    load_ftables(tw1, tw2);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long ph = (long)blockIdx.x * BKX_WAVES_PER_BLOCK + wave;
+    if (ph >= 2 * polys) return;
+    const long p = ph >> 1;
+    const int h = (int)(ph & 1);
+    const FftLane L = fft_lane_init(lane);
+    cplx x[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        i32 lo0, hi0, lo1, hi1;
+        xfft_split(in[p * 1024 + lane + 64 * r], lo0, hi0);
+        xfft_split(in[p * 1024 + lane + 64 * r + 512], lo1, hi1);
+        x[r] = h == 0 ? cplx{(double)lo0, -(double)lo1} : cplx{(double)hi0, -(double)hi1};
+    }
+    cplx *xbuf = (cplx *)(g_smem + FTABLE_LDS_BYTES + BR_PACE_BYTES + BRX_BASE_PAD + wave * WAVE_FXBUF_BYTES);
+    fft_forward(x, xbuf, (const cplx *)g_smem, (const cplx *)g_smem + FFT_TW1_ELEMS, L);
+#pragma unroll
+    for (int r = 0; r < 8; r++) out[ph * BKF_POLY_ELEMS + bkf_elem_offset(lane, r)] = x[r];
+}
+
+hipError_t xfft_init()
+{
+    hipError_t e = hipFuncSetAttribute((const void *)k_bootstrap_xfft, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)brx_lds_bytes(BR_WAVES_PER_BLOCK));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void *)k_blind_rotate_accum_xfft, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)brx_lds_bytes(BR_WAVES_PER_BLOCK));
+}
+
+hipError_t launch_bootstrap_xfft(const BrLaunch &P, int num_cus, hipStream_t stream)
+{
+    if (P.nbits_total == 0) return hipSuccess;
+    const int w = br_pick_waves(P.nbits_total, BR_WAVES_PER_BLOCK, num_cus);
+    hipLaunchKernelGGL(k_bootstrap_xfft, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), brx_lds_bytes(w), stream, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_blind_rotate_accum_xfft(i32 *accum, const cplx *bkx, const i32 *bara, long bara_stride, int row0, int n_rows,
+                                          int external_mul_only, long batch, const cplx *tw1, const cplx *tw2, u32 *park,
+                                          hipStream_t stream)
+{
+    if (batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_blind_rotate_accum_xfft, dim3(blocks_for(batch, BR_WAVES_PER_BLOCK)), dim3(BR_BLOCK_THREADS),
+                       brx_lds_bytes(BR_WAVES_PER_BLOCK), stream, accum, bkx, bara, bara_stride, row0, n_rows, external_mul_only,
+                       batch, tw1, tw2, park);
+    return hipGetLastError();
+}
+
+hipError_t launch_bkx_from_coeffs(cplx *out, const i32 *in, long polys, const cplx *tw1, const cplx *tw2, hipStream_t stream)
+{
+    if (polys == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_bkx_from_coeffs, dim3(blocks_for(2 * polys, BKX_WAVES_PER_BLOCK)), dim3(64 * BKX_WAVES_PER_BLOCK),
+                       FTABLE_LDS_BYTES + BR_PACE_BYTES + BRX_BASE_PAD + (size_t)BKX_WAVES_PER_BLOCK * WAVE_FXBUF_BYTES, stream,
+                       out, in, polys, tw1, tw2);
+    return hipGetLastError();
+}

@@ -193,3 +193,42 @@ def nth_inverse_i32(x):
     r = numpy.empty(1024, numpy.uint32)
     lib().emu_nth_inverse_i32(_p(r, c_u32p), _p(x, c_u64p))
     return r
+
+
+# ---- exact-FFT engine (csrc/blind_rotate_xfft.h) ----
+
+def bkx_from_coeffs(tgsw):
+    """int32 TGSW polynomials [..., 1024] -> split key image complex128 [polys, 2, 512] in the wave layout"""
+    tgsw = numpy.ascontiguousarray(tgsw, numpy.int32)
+    polys = tgsw.size // 1024
+    out = numpy.empty((polys, 2, 512), numpy.complex128)
+    lib().emu_bkx_from_coeffs(_p(out.view(numpy.float64), c_f64p), _p(tgsw, c_i32p), ctypes.c_long(polys))
+    return out
+
+
+def xfft_external_product(T, row):
+    """T int32 [2, 1024], row = bkx_from_coeffs of one TGSW row (8 polynomials) -> int32 [2, 1024]"""
+    T = numpy.ascontiguousarray(T, numpy.int32)
+    row = numpy.ascontiguousarray(row, numpy.complex128)
+    assert T.shape == (2, 1024) and row.size == 8 * 2 * 512
+    res = numpy.empty((2, 1024), numpy.int32)
+    lib().emu_xfft_external_product(_p(res, c_i32p), _p(T, c_i32p), _p(row.view(numpy.float64), c_f64p))
+    return res
+
+
+def xfft_margin():
+    a = ctypes.c_double(); b = ctypes.c_double()
+    lib().emu_xfft_margin(ctypes.byref(a), ctypes.byref(b))
+    return a.value, b.value
+
+
+def bootstrap_bit_xfft(bkx, n, src0, p0, src1, p1, c0, mu):
+    a0 = numpy.ascontiguousarray(src0[0], numpy.int32); b0 = numpy.ascontiguousarray(src0[1], numpy.int32).reshape(1)
+    a1 = numpy.ascontiguousarray(src1[0], numpy.int32); b1 = numpy.ascontiguousarray(src1[1], numpy.int32).reshape(1)
+    out_a = numpy.empty(1024, numpy.int32); out_b = numpy.empty(1, numpy.int32)
+    bkx = numpy.ascontiguousarray(bkx, numpy.complex128)
+    lib().emu_bootstrap_bit_xfft(_p(out_a, c_i32p), _p(out_b, c_i32p), _p(bkx.view(numpy.float64), c_f64p),
+                                 ctypes.c_int(n), _p(a0, c_i32p), _p(b0, c_i32p), ctypes.c_int32(p0),
+                                 _p(a1, c_i32p), _p(b1, c_i32p), ctypes.c_int32(p1),
+                                 ctypes.c_int32(c0), ctypes.c_int32(mu))
+    return out_a, out_b[0]

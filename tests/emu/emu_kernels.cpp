@@ -15,9 +15,11 @@
 #include "../../nufhe_amd/csrc/l4_hook.h"
 #include "../../nufhe_amd/csrc/fft512.h"
 #include "../../nufhe_amd/csrc/blind_rotate_fft.h"
+#include "../../nufhe_amd/csrc/blind_rotate_xfft.h"
 #include "emu_wave.h"
 
 double g_emu_fft_max_frac = 0.0, g_emu_fft_max_abs = 0.0;   // fft512.h (NUFHE_EMU)
+double g_emu_xfft_max_frac = 0.0, g_emu_xfft_max_abs = 0.0; // blind_rotate_xfft.h (NUFHE_EMU)
 static u64 g_tw1f[1024], g_tw1i[1024], g_tw1x[1024];
 static bool g_tables = false;
 static void tables()
@@ -473,6 +475,73 @@ void emu_bootstrap_bit_fft(i32 *out_a, i32 *out_b, const double *bk_internal, in
         WAVE_SYNC();
         u32 acc[2][16];
         brf_blind_rotate(acc, (const cplx *)bk_internal, n, barb, mu, lds, L);
+        br_extract<1>(out_a, out_b, acc, lane);
+    });
+}
+
+// ---- exact-FFT engine (blind_rotate_xfft.h) ----------------------------------------------------------------------
+
+// distance of the values handed to xfft_round_lo32 from the nearest integer, and their largest magnitude; reset on read
+void emu_xfft_margin(double *max_frac, double *max_abs)
+{
+    *max_frac = g_emu_xfft_max_frac; *max_abs = g_emu_xfft_max_abs;
+    g_emu_xfft_max_frac = 0.0; g_emu_xfft_max_abs = 0.0;
+}
+
+// int32 TGSW polynomials [polys][1024] -> split key image complex128 [polys][half 2][reg 8][lane 64]
+void emu_bkx_from_coeffs(double *out, const i32 *in, long polys)
+{
+    ftables();
+    std::vector<cplx> xbuf(FFT_XBUF_ELEMS);
+    cplx *o = (cplx *)out;
+    for (long p = 0; p < polys; p++)
+        for (int h = 0; h < 2; h++)
+            emu_run_wave([&](int lane) {
+                FftLane L = fft_lane_init(lane);
+                cplx x[8];
+                for (int r = 0; r < 8; r++) {
+                    i32 lo0, hi0, lo1, hi1;
+                    xfft_split(in[p * 1024 + lane + 64 * r], lo0, hi0);
+                    xfft_split(in[p * 1024 + lane + 64 * r + 512], lo1, hi1);
+                    x[r] = h == 0 ? cplx{(double)lo0, -(double)lo1} : cplx{(double)hi0, -(double)hi1};
+                }
+                fft_forward(x, xbuf.data(), g_ftw1, g_ftw2, L);
+                for (int r = 0; r < 8; r++) o[(p * 2 + h) * BKF_POLY_ELEMS + bkf_elem_offset(lane, r)] = x[r];
+            });
+}
+
+// one external product: res[2][1024] = sum_{m,d} digit_d(T_m) (*) row[m][d][:]  (mod 2^32), row in the split layout
+void emu_xfft_external_product(i32 *res, const i32 *T, const double *row)
+{
+    ftables();
+    std::vector<cplx> xbuf(2 * FFT_XBUF_ELEMS);
+    BrXfftLds lds{xbuf.data(), xbuf.data() + FFT_XBUF_ELEMS, g_ftw1, g_ftw2, {nullptr, nullptr}, nullptr};
+    emu_run_wave([&](int lane) {
+        FftLane L = fft_lane_init(lane);
+        u32 t[2][16], r_[2][16];
+        for (int m = 0; m < 2; m++)
+            for (int r = 0; r < 16; r++) t[m][r] = (u32)T[m * 1024 + lane + 64 * r];
+        brx_external_product(r_, t, (const cplx *)row, lds, lds.tw2, L);
+        for (int m = 0; m < 2; m++)
+            for (int r = 0; r < 16; r++) res[m * 1024 + lane + 64 * r] = (i32)r_[m][r];
+    });
+}
+
+void emu_bootstrap_bit_xfft(i32 *out_a, i32 *out_b, const double *bkx, int n,
+                            const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,
+                            i32 c0, i32 mu)
+{
+    ftables();
+    std::vector<cplx> xbuf(2 * FFT_XBUF_ELEMS);
+    std::vector<u32> park(32 * 64);
+    BrXfftLds lds{xbuf.data(), xbuf.data() + FFT_XBUF_ELEMS, g_ftw1, g_ftw2, {nullptr, nullptr}, park.data()};
+    BrSource s0{a0, b0, 0, 0, p0}, s1{a1, b1, 0, 0, p1};
+    emu_run_wave([&](int lane) {
+        FftLane L = fft_lane_init(lane);
+        u32 barb = brf_prologue(s0, s1, c0, 0, n, brx_as_fft_lds(lds), lane);
+        WAVE_SYNC();
+        u32 acc[2][16];
+        brx_blind_rotate(acc, (const cplx *)bkx, n, barb, mu, lds, L);
         br_extract<1>(out_a, out_b, acc, lane);
     });
 }

@@ -1,10 +1,10 @@
 """
 isa_mix.py -- instruction mix of one blind-rotate iteration of the bootstrap kernels, counted in the ISA.
 
-    python tools/isa_mix.py            # compiles nufhe_amd/csrc/kernels.hip to assembly (hipcc -S) and prints
+    python tools/isa_mix.py            # compiles nufhe_amd/csrc/kernels.hip / kernels_xfft.hip to assembly (hipcc -S) and prints
     python tools/isa_mix.py --write    # ... and refreshes profiles/isa_mix.json (read by bench.py)
 
-For the body of the per-iteration loop of k_bootstrap<1> (NTT) and k_bootstrap_fft it reports VGPR /
+For the body of the per-iteration loop of k_bootstrap<1> (NTT), k_bootstrap_fft and k_bootstrap_xfft it reports VGPR /
 scratch use and the number of VALU instructions by ISSUE CLASS (measured on gfx950 at the kernel's
 occupancy, profiles/r02_microbench_l4.txt):
     full   v_add/sub/subrev_u32, v_and/or/xor/not_b32, v_lshrrev_b32, v_ashrrev_i32, v_mov_b32, v_cndmask_b32
@@ -28,7 +28,9 @@ CSRC = os.path.join(ROOT, 'nufhe_amd', 'csrc')
 FULL_RATE = {'v_add_u32', 'v_sub_u32', 'v_subrev_u32', 'v_and_b32', 'v_or_b32', 'v_xor_b32', 'v_not_b32',
              'v_lshrrev_b32', 'v_ashrrev_i32', 'v_mov_b32', 'v_cndmask_b32'}
 F64 = {'v_fma_f64': 2, 'v_fmac_f64': 2, 'v_mul_f64': 1, 'v_add_f64': 1}
-KERNELS = {'k_bootstrap<1>': '_Z11k_bootstrapILi1EEv8BrLaunch', 'k_bootstrap_fft': '_Z15k_bootstrap_fft8BrLaunch'}
+KERNELS = {'k_bootstrap<1>': ('kernels.hip', '_Z11k_bootstrapILi1EEv8BrLaunch'),
+           'k_bootstrap_fft': ('kernels.hip', '_Z15k_bootstrap_fft8BrLaunch'),
+           'k_bootstrap_xfft': ('kernels_xfft.hip', '_Z16k_bootstrap_xfft8BrLaunch')}
 
 
 def source_hash():
@@ -109,18 +111,20 @@ def count(body):
 
 
 def main():
-    asm = '/tmp/nufhe_kernels.s'
     args = [a for a in sys.argv[1:] if a != '--write']
-    out = subprocess.run(
-        ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', 'kernels.hip', '-o', asm,
-         '-Rpass-analysis=kernel-resource-usage'] + args, cwd=CSRC, capture_output=True, text=True)
-    if out.returncode:
-        sys.exit(out.stderr[-3000:])
-    text = out.stderr
-    all_lines = open(asm).read().split('\n')
     result = {'source_hash': source_hash(),
               'note': 'python tools/isa_mix.py --write; per blind-rotate iteration of one wave (one bit)'}
-    for name, sym in KERNELS.items():
+    compiled = {}
+    for name, (src, sym) in KERNELS.items():
+        if src not in compiled:
+            asm = '/tmp/nufhe_%s.s' % src.replace('.hip', '')
+            out = subprocess.run(
+                ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', src, '-o', asm,
+                 '-Rpass-analysis=kernel-resource-usage'] + args, cwd=CSRC, capture_output=True, text=True)
+            if out.returncode:
+                sys.exit(out.stderr[-3000:])
+            compiled[src] = (out.stderr, open(asm).read().split('\n'))
+        text, all_lines = compiled[src]
         m = re.search(r'Function Name: ' + re.escape(sym) + r'\b.*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+)', text, re.S)
         start = next(i for i, l in enumerate(all_lines) if l.startswith(sym + ':'))
         end = next(i for i, l in enumerate(all_lines) if i > start and 's_endpgm' in l)
