@@ -31,8 +31,8 @@ __device__ __forceinline__ BrXfftLds carve_brx_lds(int wave)
 __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_bootstrap_xfft(BrLaunch P)
 {
     load_ftables((const cplx *)P.tw_a, (const cplx *)P.tw_b);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long gbit = (long)blockIdx.x * (blockDim.x >> 6) + wave;   // waves per group chosen at launch
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const long gbit = (long)blockIdx.x * (blockDim.x >> 6) + wave;   // waves per group chosen at launch; wave-uniform
     const BrPace pace = carve_pace(g_smem + FTABLE_LDS_BYTES, wave, gbit < P.nbits_total);
     if (gbit >= P.nbits_total) return;
     const int job = gbit >= P.bits_per_job ? 1 : 0;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_blind_rotate_accum_xfft
     const cplx *__restrict__ tw2, u32 *__restrict__ park)
 {
     load_ftables(tw1, tw2);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const long bit = (long)blockIdx.x * BR_WAVES_PER_BLOCK + wave;
     if (bit >= batch) return;
     BrXfftLds lds = carve_brx_lds(wave);
@@ -87,7 +87,10 @@ __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_blind_rotate_accum_xfft
         for (int i = 0; i < n_rows; i++) {
             const u32 a = WAVE_UNIFORM((u32)bara[bit * bara_stride + i]) & 2047u;
             if (a == 0) continue;
-            brx_step(acc, a, bk + (long)(row0 + i) * BKX_ROW_ELEMS, lds, lds.tw2, L);
+#if defined(BR_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+            BrProbe probe_ = {};
+#endif
+            brx_step(acc, a, bk + (long)(row0 + i) * BKX_ROW_ELEMS, lds, lds.tw2, L BR_PROBE_PASS);
         }
     }
 #pragma unroll
@@ -160,3 +163,14 @@ hipError_t launch_bkx_from_coeffs(cplx *out, const i32 *in, long polys, const cp
                        out, in, polys, tw1, tw2);
     return hipGetLastError();
 }
+
+#if defined(BR_PROBE)
+// variant builds only (blind_rotate.h, BR_PROBE): read and clear the phase tick counters of this unit's kernels
+extern "C" int nufhe_probe_read_xfft(unsigned long long *out16)
+{
+    unsigned long long zero[16] = {0};
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_br_probe), sizeof(zero)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_br_probe), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
