@@ -84,6 +84,30 @@ FF_FN u32 xfft_round_lo32(double v)
 #else
 #define BRX_GROUP_SYNC() ((void)0)
 #endif
+#if defined(BRX_MAC_PRIO) && defined(__HIP_DEVICE_COMPILE__)
+#define BRX_MAC_PRIO_BEGIN() __builtin_amdgcn_s_setprio(BRX_MAC_PRIO)
+#define BRX_MAC_PRIO_END() __builtin_amdgcn_s_setprio(1)
+#else
+#define BRX_MAC_PRIO_BEGIN() ((void)0)
+#define BRX_MAC_PRIO_END() ((void)0)
+#endif
+// BRX_FRESH_LANE: the ~27 lane-dependent LDS addresses of the exchanges are loop invariants that the compiler keeps in
+// registers across the product phases (and partly spills).  Re-deriving the lane record from an opaque copy of the lane
+// index in front of every transform group makes them phase-local: ~30 more integer instructions per group, ~25 registers
+// free while the key loads are in flight.
+#ifndef BRX_FRESH_LANE
+#define BRX_FRESH_LANE 1
+#endif
+FF_FN FftLane brx_fresh_lane(const FftLane &L)
+{
+#if BRX_FRESH_LANE && defined(__HIP_DEVICE_COMPILE__)
+    int lane = L.lane;
+    asm volatile("" : "+v"(lane));
+    return fft_lane_init(lane);
+#else
+    return L;
+#endif
+}
 #ifndef BRX_KEY_AUX
 #define BRX_KEY_AUX 0        /* cache policy bits of the key loads */
 #endif
@@ -253,10 +277,12 @@ FF_FN void brx_external_product_sums(cplx (&sum)[2][2][8], const u32 (&T)[2][16]
             x[0][r] = cplx{(double)br_digit<0>(T[m][r]), -(double)br_digit<0>(T[m][r + 8])};   // a_j - i a_{j+512}
             x[1][r] = cplx{(double)br_digit<1>(T[m][r]), -(double)br_digit<1>(T[m][r + 8])};
         }
-        fft_forward_n<2>(x, bufs, lds.tw1, tw2, L);
+        fft_forward_n<2>(x, bufs, lds.tw1, tw2, brx_fresh_lane(L));
         BR_PROBE_MARK(1 + 2 * m);
         BRX_GROUP_SYNC();
+        BRX_MAC_PRIO_BEGIN();
         brx_mac_pair(sum, x, row, m, L.lane);
+        BRX_MAC_PRIO_END();
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("" ::: "memory");      // keep the key loads of the next polynomial below this point (register pressure)
 #endif
@@ -440,7 +466,8 @@ FF_FN void brx_step(u32 (&acc)[2][16], u32 a, const cplx *row, const BrXfftLds &
     cplx sum[2][2][8];
     BR_PROBE_MARK(0);
     brx_external_product_sums(sum, T, row, lds, tw2, L BR_PROBE_PASS);
-    fft_inverse_2s<true>(sum[0], bufs, lds.tw1, tw2, L);
+    const FftLane Li = brx_fresh_lane(L);
+    fft_inverse_2s<true>(sum[0], bufs, lds.tw1, tw2, Li);
 #if BRX_PARK_LOAD == 0
     // the parked accumulator comes back behind the first inverse pair and takes the rounded low halves at once
     brx_park_load(acc, lds.park, lane);
@@ -477,7 +504,7 @@ FF_FN void brx_step(u32 (&acc)[2][16], u32 a, const cplx *row, const BrXfftLds &
     BR_ISSUE_FENCE();
 #endif
     BR_PROBE_MARK(5);
-    fft_inverse_2s<true>(sum[1], bufs, lds.tw1, tw2, L);
+    fft_inverse_2s<true>(sum[1], bufs, lds.tw1, tw2, Li);
     BR_PROBE_MARK(6);
 #if BRX_PARK_LOAD == 2
     brx_park_load(acc, lds.park, lane);
@@ -504,6 +531,13 @@ FF_FN void brx_blind_rotate(u32 (&acc)[2][16], const cplx *bk, int n, u32 barb, 
 {
     brx_init_acc(acc, barb, mu, lds, L.lane);
     const BrFftLds f = brx_as_fft_lds(lds);
+#if defined(BRX_TW2_REGS)
+    FftTw2Regs tw2r;
+    fft_tw2_load(tw2r, lds.tw2, L);
+#define BRX_TW2 tw2r
+#else
+#define BRX_TW2 lds.tw2
+#endif
 #if defined(BR_PROBE) && defined(__HIP_DEVICE_COMPILE__)
     BrProbe probe_ = {};
     const long long probe_w0 = clock64(), probe_r0 = wall_clock64();
@@ -517,7 +551,7 @@ FF_FN void brx_blind_rotate(u32 (&acc)[2][16], const cplx *bk, int n, u32 barb, 
 #if defined(BRX_ABLATE_ROW0)
         brx_step(acc, a, bk + (long)(i & 3) * BKX_ROW_ELEMS, lds, lds.tw2, L BR_PROBE_PASS);      // TIMING ONLY: four hot rows
 #else
-        brx_step(acc, a, bk + (long)i * BKX_ROW_ELEMS, lds, lds.tw2, L BR_PROBE_PASS);
+        brx_step(acc, a, bk + (long)i * BKX_ROW_ELEMS, lds, BRX_TW2, L BR_PROBE_PASS);
 #endif
     }
     br_pace_done(lds.pace);

@@ -369,3 +369,22 @@ def test_every_entry_point_catches_cpp_exceptions():
     from nufhe_amd import _lib
     import inspect
     assert 'MemoryError' in inspect.getsource(_lib.check)
+
+
+def test_no_scalar_offset_rewritten_behind_a_buffer_instruction_in_the_exact_fft_unit():
+    """round 6 machine fact (profiles/r06_xfft_experiments.txt 4b): an SGPR read as `soffset` by a buffer instruction and
+    rewritten right behind it gave wrong words with two waves per SIMD.  The exact-FFT unit is compiled to ISA here and
+    scanned (4 s); `python tools/check_soffset_war.py` scans every unit (1 min)."""
+    import importlib.util
+    import subprocess
+    spec = importlib.util.spec_from_file_location('check_soffset_war', os.path.join(ROOT, 'tools', 'check_soffset_war.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    asm = '/tmp/test_war_xfft.s'
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-S', '--cuda-device-only',
+                           'kernels_xfft.hip', '-o', asm], cwd=os.path.join(ROOT, 'nufhe_amd', 'csrc'), stderr=subprocess.DEVNULL)
+    lines = open(asm).read().split('\n')
+    assert sum(1 for l in lines if 'buffer_load_dwordx4' in l) >= 128
+    assert mod.scan(lines, 4) == []
+    # the scanner does find the pattern
+    assert mod.scan(['_Zf:', '\tbuffer_load_dwordx4 v[2:5], v1, s[20:23], s2 offen', '\ts_movk_i32 s2, 0x800'], 4)
