@@ -26,6 +26,15 @@ class DeviceParams:
         self.local_mem_size = 160 * 1024
 
 
+class _Api:
+    """``thread.api.get_id()`` of a Reikna thread (the reference's tests compare it with ``cuda_id()`` to skip their
+    PTX-only variants): this backend is neither CUDA nor OpenCL."""
+
+    @staticmethod
+    def get_id():
+        return 'hip'
+
+
 _NP_TO_TORCH = {
     numpy.dtype('int32'): torch.int32,
     numpy.dtype('float32'): torch.float32,
@@ -59,6 +68,7 @@ class DeviceThread:
         _lib.register_stream_guard(handle, lambda: (ref() is not None) and ref().check_stream())
         props = torch.cuda.get_device_properties(self.device)
         self.device_params = DeviceParams(props.name, props.multi_processor_count)
+        self.api = _Api()
         self._released = False
         self._cloud_keys = weakref.WeakSet()     # native cloud keys living in this context (freed by release())
 

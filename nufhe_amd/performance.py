@@ -36,3 +36,22 @@ class PerformanceParameters:
         if self.single_kernel_bootstrap is not None:
             res.single_kernel_bootstrap = bool(self.single_kernel_bootstrap)
         return res
+
+
+# The reference's capability queries (nufhe/blind_rotate.py:192-203, nufhe/polynomial_transform.py:23-39): its tests
+# skip configurations a device cannot run.  The gfx950 library is compiled ahead of time for one device class and
+# serves every configuration the reference's gate tests ask for.
+
+def single_kernel_bootstrap_supported(nufhe_params, device_params):
+    """The fused bootstrap kernels exist for both transforms and tlwe_mask_size 1 and 2 (csrc/kernels.hip)."""
+    return True
+
+
+def transform_supported(device_params, transform_type):
+    return transform_type in ('NTT', 'FFT')
+
+
+def max_supported_transforms_per_block(device_params, transform_type):
+    """The reference sizes its work-groups by this (performance.py:159-180); here a work-group holds 8 one-wave
+    transforms (one per ciphertext bit) whatever the transform -- the knob it feeds, `transforms_per_block`, is ignored."""
+    return 8
