@@ -253,7 +253,7 @@ def reference_python_entry(gate):
         "source": "profiles/reference_python_cpu_timing.json (tools/time_reference_cpu.py)"}
 
 
-def shard_parity(gate, transform, sample_bits, cs_host, out_host, dist, dev, world):
+def shard_parity(gate, transform, sample_bits, cs_host, out_host, dist, dev, world, group=None):
     """N > 1: EVERY rank compares the first `sample_bits` ciphertexts of its own shard (its own inputs, its own
     output of the last timed step) with the CPU oracle and the counts are all-reduced, so that a multi-GPU line
     carries a parity verdict over all ranks (the N = 1 line compares a larger sample, cpu_baseline_and_parity)."""
@@ -264,7 +264,7 @@ def shard_parity(gate, transform, sample_bits, cs_host, out_host, dist, dev, wor
     lwe_key, tlwe_key, ck = orc.make_key_pair(orc.DeterministicRNG(123))
     n = sample_bits
     cs = [tuple(x[:n] for x in c) for c in cs_host]
-    dist.barrier()                  # all ranks start their oracle run together: the host cores are shared evenly
+    dist.barrier(group=group)       # all ranks start their oracle run together: the host cores are shared evenly
     t_cpu = time.time()
     ref = orc.gate_mux(ck, cs[0], cs[1], cs[2]) if gate == 'mux' else orc.gate('gate_nand', ck, cs[0], cs[1])
     t_cpu = time.time() - t_cpu
@@ -273,8 +273,8 @@ def shard_parity(gate, transform, sample_bits, cs_host, out_host, dist, dev, wor
     sums = torch.tensor([int((da != 0).sum() + (db != 0).sum()), int(da.size + db.size),
                          int((out_host[2][:n] != ref[2]).sum()), 1], dtype=torch.int64, device=dev)
     worst = torch.tensor([int(max(abs(da).max(), abs(db).max()))], dtype=torch.int64, device=dev)
-    dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-    dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(worst, op=dist.ReduceOp.MAX, group=group)
     entry = {"bits_per_rank": n, "ranks_reporting": int(sums[3].item()), "words": int(sums[1].item()),
              "differing": int(sums[0].item()), "variances_differing": int(sums[2].item()),
              "note": "every rank: first %d ciphertexts of its shard (a[500] and b) vs the CPU oracle on the same inputs, "
@@ -287,7 +287,7 @@ def shard_parity(gate, transform, sample_bits, cs_host, out_host, dist, dev, wor
     # node running theirs at the same time), scaled to the node: `world` ranks finished `world * n` bits in the
     # slowest rank's time
     slowest = torch.tensor([t_cpu], dtype=torch.float64, device=dev)
-    dist.all_reduce(slowest, op=dist.ReduceOp.MAX)
+    dist.all_reduce(slowest, op=dist.ReduceOp.MAX, group=group)
     dt = float(slowest.item())
     base = dict(value=world * n / dt, unit="gates/s", cores=orc.num_threads() * local_world, kind="port",
                 sample="first %d bits of EVERY rank's %s shard (%d ranks x %d threads at the same time on this host), full "
@@ -298,6 +298,83 @@ def shard_parity(gate, transform, sample_bits, cs_host, out_host, dist, dev, wor
     if ref_py is not None:
         base["reference_python"] = ref_py
     return entry, base
+
+
+def peer_main(args):
+    """`--gather-backend peer`: the RCCL-free route of the N > 1 line.  ONE process drives all N GPUs through one
+    DeviceThread each -- the reference's own scheme (examples/multi_gpu.py:46-114: a thread and a Thread object per GPU,
+    the main thread collects) -- and the slices reach GPU 0 by hipMemcpyPeerAsync on the source streams (nufhe_gather,
+    multi_gpu.gather_threads).  Launches are asynchronous (a gate is tens of milliseconds, a launch microseconds), so one
+    host thread keeps every GPU busy.  Same shard sizes, same timed region (K steps between device-wide synchronisations,
+    the gather of every step inside it), same JSON shape, fewer diagnostics."""
+    import nufhe_amd
+    from nufhe_amd import multi_gpu
+    from nufhe_amd.device import DeviceThread
+    n = args.gpus
+    if torch.cuda.device_count() < n:
+        print(json.dumps({"error": "--gather-backend peer needs %d GPUs in one process, %d visible" % (n, torch.cuda.device_count())}))
+        return
+    B = args.bits
+    thrs, vms, css, mss, outs, sks = [], [], [], [], [], []
+    for d in range(n):
+        thr = DeviceThread(d)
+        ctx = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(123), thread=thr)
+        secret_key, cloud_key = ctx.make_key_pair(transform_type=args.transform)
+        if args.engine != "native":
+            cloud_key.set_engine(args.engine)
+        vm = ctx.make_virtual_machine(cloud_key)
+        rs = numpy.random.RandomState(456 + d)
+        ms = [rs.randint(0, 2, size=(B,)).astype(bool) for _ in range(3)]
+        ctx.rng = nufhe_amd.DeterministicRNG(1000 + d)
+        with torch.cuda.device(thr.device):
+            cs = [ctx.encrypt(secret_key, m) for m in ms]
+            out = vm.empty_ciphertext((B,))
+        thrs.append(thr); vms.append((ctx, vm)); css.append(cs); mss.append(ms); outs.append(out); sks.append(secret_key)
+
+    def step():
+        for d in range(n):
+            with torch.cuda.device(thrs[d].device):
+                if args.gate == "mux":
+                    vms[d][1].gate_mux(*css[d], dest=outs[d])
+                else:
+                    vms[d][1].gate_nand(css[d][0], css[d][1], dest=outs[d])
+        return multi_gpu.gather_threads(thrs[0], [(thrs[d], outs[d]) for d in range(n)])
+
+    def sync_all():
+        for thr in thrs:
+            with torch.cuda.device(thr.device):
+                thr.synchronize()
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full = step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    ok = True
+    for d in range(n):
+        with torch.cuda.device(thrs[d].device):
+            dec = vms[d][0].decrypt(sks[d], outs[d])
+        exp = numpy.where(mss[d][0], mss[d][1], mss[d][2]) if args.gate == "mux" else ~(mss[d][0] & mss[d][1])
+        ok = ok and bool((dec == exp).all())
+        ok = ok and bool((full.a[d * B:(d + 1) * B].to(thrs[d].device) == outs[d].a).all())       # slice d sits at its place
+    ms_per_step = 1e3 * elapsed / args.steps
+    print(json.dumps({
+        "metric": "bootstrapped gates/sec (%s), %d-bit batch per GPU, %s%s, n=500 N=1024 k=1 l=2" % (
+            args.gate.upper(), B, args.transform, " (exact-fft engine)" if args.engine != "native" else ""),
+        "value": n * B * args.steps / elapsed, "unit": "gates/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "ms_per_bit": ms_per_step / (n * B), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u64 mod 2^64-2^32+1 (NTT) / int32 torus" if args.transform == "NTT" and args.engine == "native"
+        else "f64 complex (folded FFT-512) / int32 torus", "engine": args.engine,
+        "data": "synthetic (seeded keys and ciphertexts, resident in HBM)", "correct": ok,
+        "config": {"workload": "gate_%s, %d-bit batch per GPU" % (args.gate, B), "bits_per_gpu": B, "transform": args.transform,
+                   "parallelism": "bits sharded over %d GPU(s) driven by ONE process, keys generated per GPU from one seed" % n},
+        "gather": {"backend": "peer (hipMemcpyPeerAsync on the source streams, nufhe_gather)", "dst": 0, "verified": ok,
+                   "collectives_per_step": 0, "inside_timed_region": True},
+        "roofline": None, "cpu_baseline": None,
+        "note": "RCCL-free route of the N > 1 line (--gather-backend peer): no roofline / cpu_baseline objects -- run the default "
+                "route, or N = 1, for those"}))
 
 
 def main():
@@ -313,12 +390,24 @@ def main():
                     help="arithmetic of the NTT path: native = u64 prime-field NTT kernels (the BASELINE headline); "
                          "exact-fft = fp64 folded FFT on a 16-bit split key, bit-identical by construction "
                          "(nufhe_cloudkey_set_engine)")
+    ap.add_argument("--gather-backend", choices=["rccl", "gloo", "peer"], default=None,
+                    help="N > 1, how the result slices reach rank 0: rccl = one async RCCL gather per step (default); gloo = the "
+                         "same collective staged through the host (also the automatic fallback when RCCL cannot start); peer = "
+                         "ONE process drives all N GPUs and collects with hipMemcpyPeerAsync (nufhe_gather), no RCCL at all")
     ap.add_argument("--cpu-sample-bits", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the secondary measurements (other gate / FFT transform) reported under 'other_configs'")
     args = ap.parse_args()
 
+    if args.gather_backend is None:
+        args.gather_backend = "gloo" if os.environ.get("NUFHE_BENCH_BACKEND") == "gloo" else "rccl"
+    if args.gather_backend == "peer":
+        # one process, one DeviceThread per GPU (the reference's own model, examples/multi_gpu.py:46-114).  Under a
+        # torch.distributed.run launch only rank 0 works; the other ranks leave at once.
+        if int(os.environ.get("RANK", "0")) == 0:
+            peer_main(args)
+        return
     if "RANK" not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N` is a complete command: it starts its own N ranks on this node (one per GPU,
         # torch.distributed.run, free port on 127.0.0.1) the way the reference's example starts its own per-GPU
@@ -326,7 +415,7 @@ def main():
         from nufhe_amd import multi_gpu as _mg
         try:
             sys.exit(_mg.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus,
-                                      backend=os.environ.get("NUFHE_BENCH_BACKEND", "nccl")))
+                                      backend="gloo" if args.gather_backend == "gloo" else "nccl"))
         except RuntimeError as e:
             sys.exit("bench.py: " + str(e))
 
@@ -339,22 +428,42 @@ def main():
     # launched by torch.distributed.run (RANK set): the process group is created for ANY world size, so
     # a 1-GPU box still drives device-side RCCL gathers; a plain `python bench.py` has no group
     use_dist = world > 1 or ("RANK" in os.environ and os.environ.get("NUFHE_BENCH_NO_DIST") != "1")
+    errors = []          # what went wrong on the way to a working gather (reported in the line, never a traceback)
+    ctl = None           # control-plane group: barriers and scalar reductions always travel over gloo on the host
+    data_backend = None  # what carries the result slices
     if use_dist:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = os.environ.get("NUFHE_BENCH_BACKEND", "nccl")   # "gloo": test-only, ranks may share a GPU
+        # RCCL has never run here with more than one rank before the driver's own 8-GPU run: make its first contact loud
+        # (NCCL_DEBUG=WARN prints the failing call) and keep the dmabuf IPC mode the host driver needs
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = "gloo" if args.gather_backend == "gloo" else "nccl"
+        if backend == "nccl" and torch.cuda.device_count() <= local_rank:
+            # (not a software failure to fall back from: a line that says n_gpus = N must come from N GPUs)
+            sys.exit("bench.py: rank %d (local %d) has no GPU of its own: %d visible; RCCL needs one per rank" % (
+                rank, local_rank, torch.cuda.device_count()))
+        local_rank = local_rank % max(1, torch.cuda.device_count())      # (gloo test route: ranks may share a GPU)
+        torch.cuda.set_device(local_rank)
+        fail_hook = os.environ.get("NUFHE_BENCH_FAIL_RCCL", "")          # tests only: "init" / "gather" raise at that point
+        if backend == "nccl":
+            try:
+                if fail_hook == "init":
+                    raise RuntimeError("NUFHE_BENCH_FAIL_RCCL=init (test hook)")
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                        timeout=datetime.timedelta(seconds=300))
+                ctl = dist.new_group(backend="gloo")
+                data_backend = "nccl"
+            except Exception as e:                  # RCCL could not start: the run still yields N kernel times
+                errors.append("RCCL process group: %s: %s" % (type(e).__name__, str(e)[:500]))
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                backend = "gloo"
         if backend == "gloo":
-            local_rank = local_rank % max(1, torch.cuda.device_count())
-            torch.cuda.set_device(local_rank)
             dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            if torch.cuda.device_count() <= local_rank:
-                sys.exit("bench.py: rank %d (local %d) has no GPU of its own: %d visible; RCCL needs one per rank" % (
-                    rank, local_rank, torch.cuda.device_count()))
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+            data_backend = "gloo"
 
     import nufhe_amd
     from nufhe_amd import _lib
@@ -395,7 +504,7 @@ def main():
         packs = [multi_gpu.PackedCiphertext(cs[0].params, B, thr.device) for _ in range(2)]
         outs = [p.ciphertext for p in packs]
         recv = [torch.empty(world * B * (cs[0].params.size + 2), dtype=torch.int32, device=thr.device)
-                if rank == 0 and dist.get_backend() == "nccl" else None for _ in range(2)]
+                if rank == 0 and data_backend == "nccl" else None for _ in range(2)]
     else:
         packs, recv = None, None
         outs = [vm.empty_ciphertext((B,))]
@@ -413,7 +522,7 @@ def main():
         else:
             vm.gate_nand(cs[0], cs[1], dest=outs[k])
         if use_dist:
-            pending[k] = multi_gpu.gather_packed_async(packs[k], world * B, dst=0, recv=recv[k])
+            pending[k] = multi_gpu.gather_packed_async(packs[k], world * B, dst=0, recv=recv[k], group=data_group)
         return k
 
     def drain():
@@ -424,13 +533,33 @@ def main():
 
     import ctypes
     lib = _lib.lib()
+    data_group = None          # default group (RCCL, or gloo when that is the default); the gloo side group after a failure
+    if use_dist and data_backend == "nccl":
+        # first contact with RCCL on more than one rank: one gather, checked on every rank.  If it raises anywhere, ALL
+        # ranks switch to the host-staged gather over the gloo group (agreed over gloo) and the line says why.
+        failed = 0
+        try:
+            if os.environ.get("NUFHE_BENCH_FAIL_RCCL") == "gather":
+                raise RuntimeError("NUFHE_BENCH_FAIL_RCCL=gather (test hook)")
+            step(); drain(); torch.cuda.synchronize()
+        except Exception as e:
+            failed = 1
+            errors.append("first RCCL gather on rank %d: %s: %s" % (rank, type(e).__name__, str(e)[:500]))
+            pending[0] = pending[1] = None
+        flag = torch.tensor([failed], dtype=torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=ctl)
+        if int(flag.item()):
+            if not failed:
+                errors.append("the first RCCL gather failed on another rank")
+            data_backend, data_group = "gloo", ctl
+            recv = [None, None]
     for _ in range(args.warmup):
         step()
     drain()
     lib.nufhe_profile_enable(thr.handle, 1)
     torch.cuda.synchronize()
     if use_dist:
-        dist.barrier()
+        dist.barrier(group=ctl)
     br_ms, ks_ms, clock_ghz, wave_ms = [], [], [], []
     t0 = time.perf_counter()
     last = 0
@@ -441,7 +570,7 @@ def main():
     torch.cuda.synchronize()
     own_elapsed = time.perf_counter() - t0          # this rank alone (a straggler shows up here)
     if use_dist:
-        dist.barrier()
+        dist.barrier(group=ctl)
     elapsed = time.perf_counter() - t0
     # HIP-event durations of the bootstrap kernel / the keyswitch stage of EVERY timed step, read after the timed region
     hist_n = min(args.steps, 256)
@@ -454,20 +583,20 @@ def main():
     per_rank_ms = [1e3 * own_elapsed / args.steps]
     per_rank_kernel = None
     if use_dist:
-        dev = thr.device if dist.get_backend() == "nccl" else "cpu"
+        dev = "cpu"
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
         elapsed = float(t.item())
         own = torch.tensor([1e3 * own_elapsed / args.steps], dtype=torch.float64, device=dev)
         every = torch.zeros(world, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(every, own)
+        dist.all_gather_into_tensor(every, own, group=ctl)
         per_rank_ms = [float(x) for x in every.cpu()]
         # the dominant kernel on every rank: mean HIP-event duration of its timed launches and its in-kernel clock, so
         # that a slow GPU shows in the roofline figure (rank 0's kernel is the one `roofline` is computed from)
         mine = torch.tensor([float(numpy.mean(br_ms)) if br_ms else 0.0, float(numpy.mean(ks_ms)) if ks_ms else 0.0,
                              clock_ghz[0] if clock_ghz else 0.0], dtype=torch.float64, device=dev)
         allk = torch.zeros(3 * world, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(allk, mine)
+        dist.all_gather_into_tensor(allk, mine, group=ctl)
         allk = allk.cpu().view(world, 3)
         per_rank_kernel = {"kernel_ms": [float(x) for x in allk[:, 0]], "keyswitch_ms": [float(x) for x in allk[:, 1]],
                            "clock_ghz_in_kernel": [float(x) for x in allk[:, 2]]}
@@ -477,12 +606,12 @@ def main():
     gathered_ok = None
     out = outs[last]                                # the result of the last timed step
     if use_dist:
-        full = multi_gpu.gather_packed_async(packs[last], world * B, dst=0).wait()
-        torch.cuda.synchronize(); dist.barrier()
+        full = multi_gpu.gather_packed_async(packs[last], world * B, dst=0, group=data_group).wait()
+        torch.cuda.synchronize(); dist.barrier(group=ctl)
         t1 = time.perf_counter()
         for _ in range(5):
-            multi_gpu.gather_packed_async(packs[last], world * B, dst=0, recv=recv[last]).wait(unpack=False)
-        torch.cuda.synchronize(); dist.barrier()
+            multi_gpu.gather_packed_async(packs[last], world * B, dst=0, recv=recv[last], group=data_group).wait(unpack=False)
+        torch.cuda.synchronize(); dist.barrier(group=ctl)
         gather_ms = 1e3 * (time.perf_counter() - t1) / 5
         if rank == 0:
             # rank 0's own slice must sit at the head of the gathered arrays
@@ -497,13 +626,13 @@ def main():
             fn()
             torch.cuda.synchronize()
             if use_dist:
-                dist.barrier()
+                dist.barrier(group=ctl)
             t1 = time.perf_counter()
             for _ in range(nsteps):
                 fn()
             torch.cuda.synchronize()
             if use_dist:
-                dist.barrier()
+                dist.barrier(group=ctl)
             return (time.perf_counter() - t1) / nsteps
         out2 = vm.empty_ciphertext((B,))
         out3 = vm.empty_ciphertext((B,))
@@ -591,16 +720,20 @@ def main():
     correct = bool((dec == expect).all())
     multi_parity = multi_base = None
     if use_dist:
-        dev = thr.device if dist.get_backend() == "nccl" else "cpu"
+        dev = "cpu"
         okt = torch.tensor([1 if correct else 0], dtype=torch.int64, device=dev)
-        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN, group=ctl)
         correct = bool(okt.item())
         if world > 1 and not args.no_cpu_baseline:
             def host_(ct):
                 return tuple(x.detach().cpu().numpy() for x in (ct.a, ct.b, ct.current_variances))
             multi_parity, multi_base = shard_parity(args.gate, args.transform, min(B, args.cpu_sample_bits or 256), [host_(c) for c in cs], host_(out),
-                                        dist, dev, world)
+                                        dist, dev, world, group=ctl)
 
+    if use_dist:
+        every_err = [None] * world
+        dist.all_gather_object(every_err, errors, group=ctl)
+        errors = sorted({e for lst in every_err for e in (lst or [])})
     if rank == 0:
         total_bits = world * B * args.steps
         gates_per_s = total_bits / elapsed
@@ -710,7 +843,12 @@ def main():
         if gather_ms is not None:
             result["gather_ms"] = gather_ms
             result["gather_bytes_per_rank"] = B * 2008
-            result["gather"] = {"backend": dist.get_backend(), "dst": 0, "verified": gathered_ok,
+            result["gather"] = {"backend": data_backend, "dst": 0, "verified": gathered_ok,
+                                "requested": args.gather_backend, "control_plane": "gloo (barriers, timings, verdicts)",
+                                "env": {k: os.environ.get(k) for k in ("NCCL_DEBUG", "HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_SOCKET_IFNAME",
+                                                                        "MASTER_ADDR", "OMP_NUM_THREADS")},
+                                "env_note": "HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver only supports dmabuf IPC, without it RCCL "
+                                            "fails with hipIpcGetMemHandle: invalid argument; NCCL_DEBUG=WARN names a failing call",
                                 "collectives_per_step": 1, "overlapped": True,
                                 "note": "a | b | variances of a slice share one buffer: ONE gather per step, started "
                                         "async after the gate and overlapped with the next gate (two result buffers "
@@ -725,6 +863,10 @@ def main():
         if world > 1:
             result["config"]["note"] = ("weak scaling: %d bits per GPU; config 4 (32768 bits over 8 GPUs) is this line at "
                                         "N = 8 -- the same run read as a strong-scaling split of 32768 bits" % B)
+        if errors:
+            result["error"] = "; ".join(errors)
+            result["error_note"] = ("the requested gather route did not work; the line was produced over the fallback named in "
+                                    "gather.backend -- kernel times, parity and value are real, gather_ms is the fallback's")
         if other:
             result["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:

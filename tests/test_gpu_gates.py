@@ -537,6 +537,45 @@ def test_bench_two_ranks_on_one_gpu():
     assert d['parity']['variances_differing'] == 0 and d['roofline']['kernel_ms'] > 0
 
 
+@pytest.mark.parametrize('hook', ['init', 'gather'])
+def test_bench_survives_an_rccl_failure_with_an_error_field(hook):
+    """RCCL has never run with more than one rank before the driver's own 8-GPU run.  If its process
+    group or its first gather fails, the line must still come out -- over the host-staged gloo gather, with the reason
+    under "error" -- instead of a traceback (the failure is injected: NUFHE_BENCH_FAIL_RCCL)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != 'NUFHE_BENCH_BACKEND'}
+    env['NUFHE_BENCH_FAIL_RCCL'] = hook
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+           '--master-addr', '127.0.0.1', '--master-port', '29561', os.path.join(root, 'bench.py'),
+           '--gpus', '1', '--steps', '2', '--warmup', '1', '--bits', '256', '--no-extra', '--no-cpu-baseline']
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+    lines = [l for l in proc.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert 'NUFHE_BENCH_FAIL_RCCL=%s' % hook in d['error'] and d['gather']['backend'] == 'gloo' and d['gather']['requested'] == 'rccl'
+    assert d['correct'] and d['gather']['verified'] is True and d['roofline']['kernel_ms'] > 0 and d['value'] > 0
+    assert d['gather']['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and d['gather']['env']['NCCL_DEBUG']
+
+
+def test_bench_peer_route_one_process():
+    """`--gather-backend peer`: the RCCL-free route of the N > 1 line (one process, a DeviceThread per GPU, slices
+    collected by nufhe_gather) -- with the one GPU of this box"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--gather-backend', 'peer', '--steps', '2',
+           '--warmup', '1', '--bits', '300']
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+    d = json.loads([l for l in proc.stdout.splitlines() if l.startswith('{')][0])
+    assert d['correct'] and d['n_gpus'] == 1 and d['gather']['backend'].startswith('peer') and d['value'] > 0
+
+
 @pytest.mark.parametrize('backend,nproc,bits', [('gloo', 2, 70), ('gloo', 2, 37), ('nccl', 1, 64)])
 def test_multi_gpu_example_under_torchrun(backend, nproc, bits):
     """examples/multi_gpu.py (the counterpart of the reference's examples/multi_gpu.py:46-114) launched the way
