@@ -17,14 +17,16 @@ GROUPS_PMC=(
   "FETCH_SIZE"
   "WRITE_SIZE"
 )
-for TR in ${TRANSFORMS:-NTT FFT}; do
+for TR in ${TRANSFORMS:-NTT FFT XFFT}; do
+    ARGS="--transform $TR"
+    [ "$TR" = "XFFT" ] && ARGS="--transform NTT --engine exact-fft"      # the exact fp64 engine of the NTT path
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$TR" -- \
-        python "$ROOT/bench.py" --steps 10 --warmup 2 --transform $TR --no-extra --no-cpu-baseline \
+        python "$ROOT/bench.py" --steps 10 --warmup 2 $ARGS --no-extra --no-cpu-baseline \
         > "$OUT/bench_$TR.json" 2> "$OUT/stats_$TR.log"
     i=0
     for G in "${GROUPS_PMC[@]}"; do
         rocprofv3 --kernel-trace --pmc $G --output-format csv -d "$OUT/pmc_${TR}_g$i" -- \
-            python "$ROOT/bench.py" --steps 2 --warmup 1 --transform $TR --no-extra --no-cpu-baseline \
+            python "$ROOT/bench.py" --steps 2 --warmup 1 $ARGS --no-extra --no-cpu-baseline \
             > /dev/null 2> "$OUT/pmc_${TR}_g$i.log"
         i=$((i+1))
     done

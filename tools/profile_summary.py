@@ -9,7 +9,7 @@ import json
 import os
 import sys
 
-KERNELS = {'NTT': 'k_bootstrap', 'FFT': 'k_bootstrap_fft'}
+KERNELS = {'NTT': 'k_bootstrap', 'FFT': 'k_bootstrap_fft', 'XFFT': 'k_bootstrap_xfft'}   # XFFT = NTT key, exact-fft engine
 
 
 def find_all(d, suffix):
