@@ -43,8 +43,8 @@ def function_map(path):
 def main():
     pos = [a for a in sys.argv[1:] if not a.startswith('-')]
     want = pos[0] if pos else 'k_bootstrap<1>'
-    sym = isa_mix.KERNELS.get(want, want)
-    src = os.path.abspath(pos[1]) if len(pos) > 1 else os.path.join(CSRC, 'kernels.hip')
+    unit, sym = isa_mix.KERNELS.get(want, ('kernels.hip', want))
+    src = os.path.abspath(pos[1]) if len(pos) > 1 else os.path.join(CSRC, unit)
     asm = '/tmp/nufhe_kernels_g.s'
     out = subprocess.run(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only', '-I' + CSRC,
                           '-gline-tables-only', src, '-o', asm] + [a for a in sys.argv[1:] if a.startswith('-D')],
