@@ -681,9 +681,27 @@ def main():
                         "outputs by construction (include/nufhe_hip.h), checked under `parity`"}
         if world == 1:
             ctx_k = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(123), thread=thr)
+            k2 = {}
             for tr in ("NTT", "FFT"):
-                pair = timed_key_pair(ctx_k, tr + "_k2", transform_type=tr, tlwe_mask_size=2)
-                del pair
+                sk_k, ck_k = timed_key_pair(ctx_k, tr + "_k2", transform_type=tr, tlwe_mask_size=2)
+                # the same NAND with tlwe_mask_size = 2 (test/test_gates.py:96-100), 3 timed calls per engine
+                vm_k = ctx_k.make_virtual_machine(ck_k)
+                ck2 = [ctx_k.encrypt(sk_k, m) for m in ms[:2]]
+                outk = vm_k.empty_ciphertext((B,))
+                for engine in (("native", "exact-fft") if tr == "NTT" else ("native",)):
+                    ck_k.set_engine(engine) if tr == "NTT" else None
+                    vm_k.gate_nand(ck2[0], ck2[1], dest=outk)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(3):
+                        vm_k.gate_nand(ck2[0], ck2[1], dest=outk)
+                    torch.cuda.synchronize()
+                    dtk = (time.perf_counter() - t1) / 3
+                    k2["gate_nand_%s%s" % (tr, "" if engine == "native" else "_exact_fft_engine")] = {
+                        "ms_per_step_per_gpu": 1e3 * dtk, "ms_per_bit": 1e3 * dtk / B,
+                        "correct": bool((ctx_k.decrypt(sk_k, outk) == ~(ms[0] & ms[1])).all())}
+                del vm_k, ck_k, sk_k, ck2, outk
+            other["tlwe_mask_size_2"] = k2
         other["keygen_ms"] = dict(keygen_ms, note="Context.make_key_pair wall time incl. host random numbers "
                                   "(numpy RandomState, reference draw order) and their upload; the first entry "
                                   "also pays the one-time kernel loading")

@@ -148,7 +148,7 @@ class NuFHECloudKey:
 
     def set_engine(self, engine):
         """'native' | 'exact-fft': which exact arithmetic computes this NTT key's gates (NativeCloudKey.set_engine);
-        results are bit-identical, the exact-FFT engine is ~2.4 x faster on large batches."""
+        results are bit-identical, the exact-FFT engine is ~2 x faster on large batches (tlwe_mask_size 1 and 2)."""
         self._native.set_engine(engine)
         return self
 

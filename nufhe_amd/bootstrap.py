@@ -52,7 +52,7 @@ class NativeCloudKey:
         _lib.register_stream_guard(handle, lambda: (ref() is not None) and ref().check_stream())
         thr._cloud_keys.add(self)
         default_engine = os.environ.get("NUFHE_NTT_ENGINE")
-        if default_engine and transform_type == 'NTT' and mask_size == 1:
+        if default_engine and transform_type == 'NTT':
             self.set_engine(default_engine)
 
     def set_engine(self, engine):

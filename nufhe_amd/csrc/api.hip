@@ -586,9 +586,8 @@ int nufhe_cloudkey_set_engine(nufhe_cloudkey *key, int engine)
     NUFHE_API_BEGIN
     if (!key) return fail(NUFHE_EINVAL, "null cloud key");
     if (engine != NUFHE_ENGINE_NATIVE && engine != NUFHE_ENGINE_EXACT_FFT) return fail(NUFHE_EINVAL, "unknown engine %d", engine);
-    if (engine == NUFHE_ENGINE_EXACT_FFT && (key->transform != NUFHE_TRANSFORM_NTT || key->mask_size != 1))
-        return fail(NUFHE_EINVAL, "the exact-FFT engine serves NTT keys with tlwe_mask_size 1 (this key: transform %d, mask size %d)",
-                    key->transform, key->mask_size);
+    if (engine == NUFHE_ENGINE_EXACT_FFT && key->transform != NUFHE_TRANSFORM_NTT)
+        return fail(NUFHE_EINVAL, "the exact-FFT engine serves NTT keys (this key: transform %d)", key->transform);
     key->engine = engine;
     if (engine == NUFHE_ENGINE_NATIVE && key->d_bkx) {
         // the 65.5 MB image goes with the engine
@@ -985,7 +984,7 @@ static int ensure_bkx(nufhe_ctx *ctx, nufhe_cloudkey *key)
 
 static bool uses_xfft(const nufhe_cloudkey *key)
 {
-    return key->engine == NUFHE_ENGINE_EXACT_FFT && key->transform == NUFHE_TRANSFORM_NTT && key->mask_size == 1;
+    return key->engine == NUFHE_ENGINE_EXACT_FFT && key->transform == NUFHE_TRANSFORM_NTT;
 }
 
 // the context's tuning with the legacy per-switch overrides applied (nufhe_ctx_set_team_max_bits: an explicit value
@@ -1012,10 +1011,13 @@ static int prepare_launch(nufhe_ctx *ctx, nufhe_cloudkey *key, BrLaunch &P, long
     if (uses_xfft(key)) {
         int rc = ensure_bkx(ctx, key);
         if (rc) return rc;
-        if ((rc = ensure(ctx, ctx->xfft_park, (size_t)total * 2048 * sizeof(u32)))) return rc;
+        P.park = nullptr;
+        if (key->mask_size == 1) {          // (k = 2 keeps its accumulator in LDS: nothing to park)
+            if ((rc = ensure(ctx, ctx->xfft_park, (size_t)total * 2048 * sizeof(u32)))) return rc;
+            P.park = (u32 *)ctx->xfft_park.ptr;
+        }
         P.nbits_total = total;
         P.bk = key->d_bkx;
-        P.park = (u32 *)ctx->xfft_park.ptr;
         P.n = key->n;
         P.mu = mu;
         P.tw_a = ctx->d_ftw1;
@@ -1538,7 +1540,7 @@ int nufhe_external_mul(nufhe_ctx *ctx, nufhe_cloudkey *key, int32_t *d_accum, in
     if (uses_xfft(key)) {
         if ((rc = ensure_bkx(ctx, key)) || (rc = ensure(ctx, ctx->xfft_park, (size_t)batch * 2048 * sizeof(u32)))) return rc;
         HIP_TRY(launch_blind_rotate_accum_xfft(d_accum, key->d_bkx, nullptr, 0, bk_row, 1, 1, batch, ctx->d_ftw1, ctx->d_ftw2,
-                                               (u32 *)ctx->xfft_park.ptr, ctx->stream));
+                                               (u32 *)ctx->xfft_park.ptr, key->mask_size, ctx->stream));
         return NUFHE_OK;
     }
     const bool fft = key->transform == NUFHE_TRANSFORM_FFT;
@@ -1560,7 +1562,7 @@ int nufhe_blind_rotate(nufhe_ctx *ctx, nufhe_cloudkey *key, int32_t *d_accum, co
     if (uses_xfft(key)) {
         if ((rc = ensure_bkx(ctx, key)) || (rc = ensure(ctx, ctx->xfft_park, (size_t)batch * 2048 * sizeof(u32)))) return rc;
         HIP_TRY(launch_blind_rotate_accum_xfft(d_accum, key->d_bkx, d_bara, bara_stride, 0, n_rows, 0, batch, ctx->d_ftw1,
-                                               ctx->d_ftw2, (u32 *)ctx->xfft_park.ptr, ctx->stream));
+                                               ctx->d_ftw2, (u32 *)ctx->xfft_park.ptr, key->mask_size, ctx->stream));
         return NUFHE_OK;
     }
     const bool fft = key->transform == NUFHE_TRANSFORM_FFT;

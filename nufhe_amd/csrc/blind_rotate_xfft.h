@@ -565,6 +565,160 @@ FF_FN void brx_blind_rotate(u32 (&acc)[2][16], const cplx *bk, int n, u32 barb, 
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// tlwe_mask_size = K = 2 on the exact engine (cf. brfk_* in blind_rotate_fft.h: the accumulator int32[K+1][1024] lives
+// only in LDS, one wave per SIMD, 512 registers per wave).  TGSW rows have (K+1) * 2 * (K+1) = 18 polynomials, each with
+// two halves: [m][d][mo][half][reg][lane].  Six digit polynomials per sum: the error bound of DESIGN.md section 7 grows
+// from four terms to six, 0.037 -> 0.055, still an order below the 0.5 at which a rounding could change.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int K>
+FF_FN void brxk_mac_pair(cplx (&sum)[2][K + 1][8], const cplx (&x)[2][8], const cplx *row, int m, int lane)
+{
+    // load index gi = ((d * (K+1) + mo) * 2 + h) * 8 + r, consecutive in memory; groups of 4, one group ahead
+    constexpr int NG = 2 * (K + 1) * 2 * 2;
+    const cplx *base = row + (long)(m * 2) * (K + 1) * BKX_POLY_ELEMS + lane;
+    auto addr = [&](int g, int i) { return base + (g * 4 + i) * 64; };
+    cplx k[4], n[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) k[i] = *addr(0, i);
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) n[i] = *addr(g + 1, i);
+            BR_ISSUE_FENCE();
+        }
+        const int h = (g >> 1) & 1, dm = g >> 2, d = dm / (K + 1), mo = dm % (K + 1);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = 4 * (g & 1) + i;
+            c_fma_acc(sum[h][mo][r], x[d][r], k[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) k[i] = n[i];
+    }
+}
+
+// emit(mo, r, v): v = coefficient lane + 64 r (mod 2^32, exact) of sum_{m,d} digit_d(T_m) (*) BK_row[m][d][mo];
+// tsrc(m, T) fills T[r] = coefficient lane + 64 r of input polynomial m; all sources are read before the first emit
+template <int K, class TSource, class Emit>
+FF_FN void brxk_external_product(TSource &&tsrc, Emit &&emit, const cplx *row, const BrFftLdsK &lds, const FftLane &L)
+{
+    static_assert(K == 2, "pairing of the inverse transforms below is written for three polynomials");
+    cplx *const bufs[2] = {lds.xbufA, lds.xbufB};
+    cplx sum[2][K + 1][8];
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int mo = 0; mo <= K; mo++)
+#pragma unroll
+            for (int r = 0; r < 8; r++) sum[h][mo][r] = cplx{0.0, 0.0};
+#pragma unroll
+    for (int m = 0; m <= K; m++) {
+        u32 T[16];
+        tsrc(m, T);
+        cplx x[2][8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            x[0][r] = cplx{(double)br_digit<0>(T[r]), -(double)br_digit<0>(T[r + 8])};   // a_j - i a_{j+512}
+            x[1][r] = cplx{(double)br_digit<1>(T[r]), -(double)br_digit<1>(T[r + 8])};
+        }
+        fft_forward_n<2>(x, bufs, lds.tw1, lds.tw2, L);
+        brxk_mac_pair<K>(sum, x, row, m, L.lane);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" ::: "memory");
+#endif
+    }
+    // six inverse transforms as three staggered pairs: (lo 0, lo 1), (lo 2, hi 2), (hi 0, hi 1)
+    u32 res[K + 1][16];
+    {
+        fft_inverse_2s<true>(reinterpret_cast<cplx (&)[2][8]>(sum[0]), bufs, lds.tw1, lds.tw2, L);       // lo 0, lo 1
+#pragma unroll
+        for (int mo = 0; mo < 2; mo++)
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                res[mo][r] = xfft_round_lo32(sum[0][mo][r].re);
+                res[mo][r + 8] = xfft_round_lo32(sum[0][mo][r].im);
+            }
+        cplx pair[2][8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) { pair[0][r] = sum[0][2][r]; pair[1][r] = sum[1][2][r]; }
+        fft_inverse_2s<true>(pair, bufs, lds.tw1, lds.tw2, L);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            res[2][r] = xfft_round_lo32(pair[0][r].re) + (xfft_round_lo32(pair[1][r].re) << 16);
+            res[2][r + 8] = xfft_round_lo32(pair[0][r].im) + (xfft_round_lo32(pair[1][r].im) << 16);
+        }
+        fft_inverse_2s<true>(reinterpret_cast<cplx (&)[2][8]>(sum[1]), bufs, lds.tw1, lds.tw2, L);       // hi 0, hi 1
+#pragma unroll
+        for (int mo = 0; mo < 2; mo++)
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                res[mo][r] += xfft_round_lo32(sum[1][mo][r].re) << 16;
+                res[mo][r + 8] += xfft_round_lo32(sum[1][mo][r].im) << 16;
+            }
+    }
+#pragma unroll
+    for (int mo = 0; mo <= K; mo++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) emit(mo, r, res[mo][r]);
+}
+
+template <int K>
+FF_FN void brxk_step(u32 a, const cplx *row, const BrFftLdsK &lds, const FftLane &L)
+{
+    const int lane = L.lane;
+    brxk_external_product<K>(
+        [&](int m, u32 (&T)[16]) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const u32 j = (u32)(lane + 64 * r);
+                const u32 t = (j - a) & 2047u;
+                const u32 v = (u32)lds.acc[m * 1024 + (t & 1023u)];
+                const u32 self = (u32)lds.acc[m * 1024 + j];
+                T[r] = ((t & 1024u) ? 0u - v : v) - self;               // polynomials_cpu.py:46-58
+            }
+        },
+        [&](int mo, int r, u32 v) { lds.acc[mo * 1024 + lane + 64 * r] += (i32)v; }, row, lds, L);
+    WAVE_SYNC();
+}
+
+// prologue + blind rotation + load of the accumulator into registers for br_extract<K> (cf. brfk_bootstrap_body)
+template <int K>
+FF_FN void brxk_bootstrap_body(u32 (&acc)[K + 1][16], const BrSource &s0, const BrSource &s1, i32 c0, long bit,
+                               const cplx *bk, int n, i32 mu, const BrFftLdsK &lds, const FftLane &L)
+{
+    const int lane = L.lane;
+    for (int i = lane; i < n; i += 64) {
+        u32 v = 0;
+        if (s0.p) v += (u32)s0.p * (u32)s0.a[bit * s0.a_stride + i];
+        if (s1.p) v += (u32)s1.p * (u32)s1.a[bit * s1.a_stride + i];
+        *brfk_bara_slot(lds, i) = (uint16_t)br_modswitch(v);
+    }
+    u32 vb = (u32)c0;
+    if (s0.p) vb += (u32)s0.p * (u32)s0.b[bit * s0.b_stride];
+    if (s1.p) vb += (u32)s1.p * (u32)s1.b[bit * s1.b_stride];
+    const u32 barb = br_modswitch(vb);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const u32 j = (u32)(lane + 64 * r);
+        const u32 t = (j + barb) & 2047u;
+#pragma unroll
+        for (int m = 0; m < K; m++) lds.acc[m * 1024 + j] = 0;
+        lds.acc[K * 1024 + j] = (t < 1024u) ? mu : (i32)(0u - (u32)mu);
+    }
+    WAVE_SYNC();
+    for (int i = 0; i < n; i++) {
+        const u32 a = WAVE_UNIFORM((u32)*brfk_bara_slot(lds, i));
+        if (a == 0) continue;
+        brxk_step<K>(a, bk + (long)i * BK_ROW_POLYS(K) * BKX_POLY_ELEMS, lds, L);
+    }
+#pragma unroll
+    for (int m = 0; m <= K; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[m][r] = (u32)lds.acc[m * 1024 + lane + 64 * r];
+}
+
 // Key preparation: one TGSW polynomial (int32 coefficients) -> its two balanced halves, each as the (a_j, -a_{j+512})
 // input of the forward transform (kernels.hip k_bkx_from_coeffs).  K = lo + 2^16 hi with lo = sign-extended low half.
 FF_FN void xfft_split(i32 k, i32 &lo, i32 &hi)

@@ -1394,8 +1394,8 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, con
     // switch is 0), k = 2: team kernel, then the ring kernel
     const int num_cus = T.num_cus;
     if (transform == BR_TRANSFORM_XFFT) {
-        if (mask_size != 1 || !P.park) return hipErrorInvalidValue;
-        return launch_bootstrap_xfft(P, num_cus, stream);
+        if (mask_size == 1 && !P.park) return hipErrorInvalidValue;
+        return launch_bootstrap_xfft(P, mask_size, num_cus, stream);
     }
     const long team_max_bits = transform == 0 ? T.team_max_bits : 2 * T.team_max_bits_fft;    // (FFT: halved again below)
     const long pair_max_bits = transform == 0 ? (mask_size == 1 ? T.pair_max_bits_ntt : (long)T.ring_k2)

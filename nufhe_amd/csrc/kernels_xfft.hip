@@ -99,6 +99,77 @@ __global__ __launch_bounds__(BR_BLOCK_THREADS, 2) void k_blind_rotate_accum_xfft
         for (int r = 0; r < 16; r++) my[m * 1024 + lane + 64 * r] = (i32)acc[m][r];
 }
 
+// ---- tlwe_mask_size = 2 (brxk_*): per wave two exchange buffers + the accumulator int32[3][1024], one wave per SIMD ----
+#define BRX2_WAVES 4
+#define WAVE_BRX2_LDS_BYTES (2 * WAVE_FXBUF_BYTES + 3 * 1024 * 4)
+static constexpr size_t brx2_lds_bytes(int waves) { return FTABLE_LDS_BYTES + BR_PACE_BYTES + BRX_BASE_PAD + (size_t)waves * WAVE_BRX2_LDS_BYTES; }
+
+__device__ __forceinline__ BrFftLdsK carve_brx2_lds(int wave)
+{
+    unsigned char *base = g_smem + FTABLE_LDS_BYTES + BR_PACE_BYTES + BRX_BASE_PAD + wave * WAVE_BRX2_LDS_BYTES;
+    BrFftLdsK lds;
+    lds.xbufA = (cplx *)base;
+    lds.xbufB = (cplx *)(base + WAVE_FXBUF_BYTES);
+    lds.acc = (i32 *)(base + 2 * WAVE_FXBUF_BYTES);
+    lds.tw1 = (const cplx *)g_smem;
+    lds.tw2 = (const cplx *)g_smem + FFT_TW1_ELEMS;
+    return lds;
+}
+
+__global__ __launch_bounds__(64 * BRX2_WAVES, 1) void k_bootstrap_xfft_k2(BrLaunch P)
+{
+    load_ftables((const cplx *)P.tw_a, (const cplx *)P.tw_b);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long gbit = (long)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (gbit >= P.nbits_total) return;
+    const int job = gbit >= P.bits_per_job ? 1 : 0;
+    const long bit = gbit - (job ? P.bits_per_job : 0);
+    const BrFftLdsK lds = carve_brx2_lds(wave);
+    const FftLane L = fft_lane_init(lane);
+    u32 acc[3][16];
+    brxk_bootstrap_body<2>(acc, P.job[job].s0, P.job[job].s1, P.job[job].c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L);
+    br_extract<2>(P.out_a + gbit * P.out_a_stride, P.out_b + gbit * P.out_b_stride, acc, lane);
+}
+
+__global__ __launch_bounds__(64 * BRX2_WAVES, 1) void k_blind_rotate_accum_xfft_k2(
+    i32 *__restrict__ accum, const cplx *__restrict__ bk, const i32 *__restrict__ bara, long bara_stride,
+    int row0, int n_rows, int external_mul_only, long batch, const cplx *__restrict__ tw1,
+    const cplx *__restrict__ tw2)
+{
+    load_ftables(tw1, tw2);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long bit = (long)blockIdx.x * BRX2_WAVES + wave;
+    if (bit >= batch) return;
+    const BrFftLdsK lds = carve_brx2_lds(wave);
+    const FftLane L = fft_lane_init(lane);
+    i32 *my = accum + bit * 3 * 1024;
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) lds.acc[m * 1024 + lane + 64 * r] = my[m * 1024 + lane + 64 * r];
+    WAVE_SYNC();
+    constexpr long kRow = (long)BK_ROW_POLYS(2) * BKX_POLY_ELEMS;
+    if (external_mul_only) {
+        brxk_external_product<2>(
+            [&](int m, u32(&T)[16]) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) T[r] = (u32)lds.acc[m * 1024 + lane + 64 * r];
+            },
+            [&](int mo, int r, u32 v) { lds.acc[mo * 1024 + lane + 64 * r] = (i32)v; }, bk + row0 * kRow, lds, L);
+    } else {
+        for (int i = 0; i < n_rows; i++) {
+            const u32 a = WAVE_UNIFORM((u32)bara[bit * bara_stride + i]) & 2047u;
+            if (a == 0) continue;
+            brxk_step<2>(a, bk + (row0 + i) * kRow, lds, L);
+        }
+    }
+    WAVE_SYNC();
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) my[m * 1024 + lane + 64 * r] = lds.acc[m * 1024 + lane + 64 * r];
+}
+
 // Split key image: one wave per (polynomial, half).  K = lo + 2^16 hi (xfft_split), each half through the forward
 // transform, stored in the wave layout of the product phase: [poly][half][reg][lane].
 #define BKX_WAVES_PER_BLOCK 4
@@ -132,13 +203,23 @@ hipError_t xfft_init()
     hipError_t e = hipFuncSetAttribute((const void *)k_bootstrap_xfft, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)brx_lds_bytes(BR_WAVES_PER_BLOCK));
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void *)k_blind_rotate_accum_xfft, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)brx_lds_bytes(BR_WAVES_PER_BLOCK));
+    e = hipFuncSetAttribute((const void *)k_blind_rotate_accum_xfft, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)brx_lds_bytes(BR_WAVES_PER_BLOCK));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_bootstrap_xfft_k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)brx2_lds_bytes(BRX2_WAVES));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void *)k_blind_rotate_accum_xfft_k2, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)brx2_lds_bytes(BRX2_WAVES));
 }
 
-hipError_t launch_bootstrap_xfft(const BrLaunch &P, int num_cus, hipStream_t stream)
+hipError_t launch_bootstrap_xfft(const BrLaunch &P, int mask_size, int num_cus, hipStream_t stream)
 {
     if (P.nbits_total == 0) return hipSuccess;
+    if (mask_size == 2) {
+        const int w = br_pick_waves(P.nbits_total, BRX2_WAVES, num_cus);
+        hipLaunchKernelGGL(k_bootstrap_xfft_k2, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), brx2_lds_bytes(w), stream, P);
+        return hipGetLastError();
+    }
     const int w = br_pick_waves(P.nbits_total, BR_WAVES_PER_BLOCK, num_cus);
     hipLaunchKernelGGL(k_bootstrap_xfft, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), brx_lds_bytes(w), stream, P);
     return hipGetLastError();
@@ -146,9 +227,15 @@ hipError_t launch_bootstrap_xfft(const BrLaunch &P, int num_cus, hipStream_t str
 
 hipError_t launch_blind_rotate_accum_xfft(i32 *accum, const cplx *bkx, const i32 *bara, long bara_stride, int row0, int n_rows,
                                           int external_mul_only, long batch, const cplx *tw1, const cplx *tw2, u32 *park,
-                                          hipStream_t stream)
+                                          int mask_size, hipStream_t stream)
 {
     if (batch == 0) return hipSuccess;
+    if (mask_size == 2) {
+        hipLaunchKernelGGL(k_blind_rotate_accum_xfft_k2, dim3(blocks_for(batch, BRX2_WAVES)), dim3(64 * BRX2_WAVES),
+                           brx2_lds_bytes(BRX2_WAVES), stream, accum, bkx, bara, bara_stride, row0, n_rows, external_mul_only,
+                           batch, tw1, tw2);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_blind_rotate_accum_xfft, dim3(blocks_for(batch, BR_WAVES_PER_BLOCK)), dim3(BR_BLOCK_THREADS),
                        brx_lds_bytes(BR_WAVES_PER_BLOCK), stream, accum, bkx, bara, bara_stride, row0, n_rows, external_mul_only,
                        batch, tw1, tw2, park);

@@ -232,3 +232,25 @@ def bootstrap_bit_xfft(bkx, n, src0, p0, src1, p1, c0, mu):
                                  _p(a1, c_i32p), _p(b1, c_i32p), ctypes.c_int32(p1),
                                  ctypes.c_int32(c0), ctypes.c_int32(mu))
     return out_a, out_b[0]
+
+
+def xfft_external_product_k2(T, row):
+    """tlwe_mask_size = 2: T int32 [3, 1024], row = bkx_from_coeffs of one TGSW row (18 polynomials) -> int32 [3, 1024]"""
+    T = numpy.ascontiguousarray(T, numpy.int32)
+    row = numpy.ascontiguousarray(row, numpy.complex128)
+    assert T.shape == (3, 1024) and row.size == 18 * 2 * 512
+    res = numpy.empty((3, 1024), numpy.int32)
+    lib().emu_xfft_external_product_k2(_p(res, c_i32p), _p(T, c_i32p), _p(row.view(numpy.float64), c_f64p))
+    return res
+
+
+def bootstrap_bit_xfft_k2(bkx, n, src0, p0, src1, p1, c0, mu):
+    a0 = numpy.ascontiguousarray(src0[0], numpy.int32); b0 = numpy.ascontiguousarray(src0[1], numpy.int32).reshape(1)
+    a1 = numpy.ascontiguousarray(src1[0], numpy.int32); b1 = numpy.ascontiguousarray(src1[1], numpy.int32).reshape(1)
+    out_a = numpy.empty(2048, numpy.int32); out_b = numpy.empty(1, numpy.int32)
+    bkx = numpy.ascontiguousarray(bkx, numpy.complex128)
+    lib().emu_bootstrap_bit_xfft_k2(_p(out_a, c_i32p), _p(out_b, c_i32p), _p(bkx.view(numpy.float64), c_f64p),
+                                    ctypes.c_int(n), _p(a0, c_i32p), _p(b0, c_i32p), ctypes.c_int32(p0),
+                                    _p(a1, c_i32p), _p(b1, c_i32p), ctypes.c_int32(p1),
+                                    ctypes.c_int32(c0), ctypes.c_int32(mu))
+    return out_a, out_b[0]

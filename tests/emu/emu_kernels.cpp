@@ -546,4 +546,36 @@ void emu_bootstrap_bit_xfft(i32 *out_a, i32 *out_b, const double *bkx, int n,
     });
 }
 
+// tlwe_mask_size = 2 on the exact engine: one external product, T int32 [3][1024], row = 18 split polynomials
+void emu_xfft_external_product_k2(i32 *res, const i32 *T, const double *row)
+{
+    ftables();
+    std::vector<cplx> xbuf(2 * FFT_XBUF_ELEMS);
+    std::vector<i32> accv(3 * 1024);
+    BrFftLdsK lds{xbuf.data(), xbuf.data() + FFT_XBUF_ELEMS, accv.data(), g_ftw1, g_ftw2};
+    emu_run_wave([&](int lane) {
+        FftLane L = fft_lane_init(lane);
+        brxk_external_product<2>(
+            [&](int m, u32(&t)[16]) { for (int r = 0; r < 16; r++) t[r] = (u32)T[m * 1024 + lane + 64 * r]; },
+            [&](int mo, int r, u32 v) { res[mo * 1024 + lane + 64 * r] = (i32)v; }, (const cplx *)row, lds, L);
+    });
+}
+
+void emu_bootstrap_bit_xfft_k2(i32 *out_a, i32 *out_b, const double *bkx, int n,
+                               const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,
+                               i32 c0, i32 mu)
+{
+    ftables();
+    std::vector<cplx> xbuf(2 * FFT_XBUF_ELEMS);
+    std::vector<i32> accv(3 * 1024);
+    BrFftLdsK lds{xbuf.data(), xbuf.data() + FFT_XBUF_ELEMS, accv.data(), g_ftw1, g_ftw2};
+    BrSource s0{a0, b0, 0, 0, p0}, s1{a1, b1, 0, 0, p1};
+    emu_run_wave([&](int lane) {
+        FftLane L = fft_lane_init(lane);
+        u32 acc[3][16];
+        brxk_bootstrap_body<2>(acc, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L);
+        br_extract<2>(out_a, out_b, acc, lane);
+    });
+}
+
 }  // extern "C"

@@ -143,3 +143,50 @@ def test_blind_rotation_reduced_key_equals_ntt_oracle(orc):
     ea, eb = orc.bootstrap_extract(bk_ntt, ta[None, :], tb, MU)
     ga, gb = emu.bootstrap_bit_xfft(bkx, n, (a0, b0), 1, (a1, b1), 1, -MU, MU)
     assert (ga == ea[0]).all() and gb == eb[0]
+
+
+def _exact_external_product_k2(T, tgsw_row):
+    """tlwe_mask_size = 2: T [3,1024] int32, tgsw_row [3,2,3,1024] int32"""
+    res = numpy.zeros((3, 1024), numpy.int64)
+    for m in range(3):
+        ds = _digits(T[m])
+        for d in range(2):
+            for mo in range(3):
+                res[mo] += _negacyclic(ds[d], tgsw_row[m, d, mo])
+    return (res & 0xFFFFFFFF).astype(numpy.uint32).view(numpy.int32)
+
+
+def test_mask_size_2_external_product_random_and_extreme(orc):
+    """six digit polynomials per sum (bound 0.055): random full-range inputs and everything at its extreme"""
+    rs = numpy.random.RandomState(9)
+    tmin = numpy.uint32((0 - (2**31 + 2**21)) % 2**32).view(numpy.int32)
+    tmax = numpy.uint32(((1023 << 22) | (1023 << 12)) - (2**31 + 2**21)).view(numpy.int32)
+    cases = [(rs.randint(-2**31, 2**31, size=(3, 1024), dtype=numpy.int32), rs.randint(-2**31, 2**31, size=(3, 2, 3, 1024), dtype=numpy.int32)),
+             (numpy.where(rs.rand(3, 1024) < 0.5, tmax, tmin).astype(numpy.int32),
+              numpy.where(rs.rand(3, 2, 3, 1024) < 0.5, numpy.int32(2**31 - 1), numpy.int32(-2**31)).astype(numpy.int32)),
+             (numpy.full((3, 1024), tmin, numpy.int32), numpy.full((3, 2, 3, 1024), numpy.int32(-2**31), numpy.int32))]
+    for T, row in cases:
+        emu.xfft_margin()
+        got = emu.xfft_external_product_k2(T, emu.bkx_from_coeffs(row))
+        assert (got == _exact_external_product_k2(T, row)).all()
+        frac, mag = emu.xfft_margin()
+        assert frac < 0.055 and mag <= 1.5 * 2.0**36 + 1, (frac, mag)
+    T, row = cases[0]
+    ntt = orc.tgsw_external_mul(T[None], orc.tlwe_transform_samples(row[None]), 0)[0]
+    assert (ntt == _exact_external_product_k2(T, row)).all()
+
+
+def test_mask_size_2_blind_rotation_reduced_key_equals_ntt_oracle(orc):
+    rs = numpy.random.RandomState(64)
+    n = 5
+    tgsw = rs.randint(-2**31, 2**31, size=(n, 3, 2, 3, 1024), dtype=numpy.int32)
+    bk_ntt = orc.tlwe_transform_samples(tgsw)
+    bkx = emu.bkx_from_coeffs(tgsw)
+    MU = 2**29
+    a0 = rs.randint(-2**31, 2**31, size=n, dtype=numpy.int32); a1 = rs.randint(-2**31, 2**31, size=n, dtype=numpy.int32)
+    a0[2] = 0; a1[2] = 0
+    b0 = rs.randint(-2**31, 2**31, size=1, dtype=numpy.int32); b1 = rs.randint(-2**31, 2**31, size=1, dtype=numpy.int32)
+    ta = (a0 + a1).astype(numpy.int32); tb = (numpy.int32(-MU) + b0 + b1).astype(numpy.int32)
+    ea, eb = orc.bootstrap_extract(bk_ntt, ta[None, :], tb, MU)
+    ga, gb = emu.bootstrap_bit_xfft_k2(bkx, n, (a0, b0), 1, (a1, b1), 1, -MU, MU)
+    assert (ga == ea[0]).all() and gb == eb[0]

@@ -183,12 +183,11 @@ def test_engine_refusals_and_key_changes(thr, H, orc, oracle_keys):
     from nufhe_amd import _lib
     from nufhe_amd.bootstrap import NativeCloudKey
     from nufhe_amd.device import ptr
-    # not an NTT / k = 1 key
-    for kw in (dict(transform_type='FFT'), dict(mask_size=2)):
-        native = NativeCloudKey(thr, 500, **kw)
-        with pytest.raises(ValueError, match='exact-FFT engine serves NTT keys'):
-            native.set_engine('exact-fft')
-        native.destroy()
+    # not an NTT key (tlwe_mask_size 2 is served: tests/test_mask_size_2.py)
+    native = NativeCloudKey(thr, 500, transform_type='FFT')
+    with pytest.raises(ValueError, match='exact-FFT engine serves NTT keys'):
+        native.set_engine('exact-fft')
+    native.destroy()
     with pytest.raises(ValueError, match='unknown engine'):
         NativeCloudKey(thr, 4).set_engine('fast')
     # a synthetic key of random field elements is not the transform of int32 polynomials: refused at first use, by name

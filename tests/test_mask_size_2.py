@@ -264,6 +264,95 @@ def test_gpu_k2_keyswitch_on_the_matrix_cores(k2_env, thr, H, orc):
 
 
 @pytest.mark.gpu
+def test_gpu_k2_exact_engine_external_mul_vs_oracle_and_native(thr, H, orc):
+    """tlwe_mask_size = 2 on the exact-FFT engine (brxk_* in csrc/blind_rotate_xfft.h: six digit polynomials per sum,
+    bound 0.055): random full-range and all-extreme inputs against the oracle's prime-field result and the native kernels."""
+    from nufhe_amd.bootstrap import NativeCloudKey
+    from nufhe_amd.device import ptr
+    # (the reference-made external-product fixture multiplies by random field elements, which no int32 key transforms
+    # to: the engine refuses it by name -- tests/test_gpu_xfft.py; the reference-made NAND golden is in the next test)
+    rs = numpy.random.RandomState(76)
+    accum = rs.randint(-2**31, 2**31, size=(7, 3, 1024), dtype=numpy.int32)
+    tgsw = rs.randint(-2**31, 2**31, size=(3, 3, 2, 3, 1024), dtype=numpy.int32)
+    bk = numpy.ascontiguousarray(orc.tlwe_transform_samples(tgsw), numpy.uint64)
+    native = NativeCloudKey(thr, 3, 'NTT', 2)
+    _call("nufhe_bk_upload_reference", native.handle, bk.ctypes.data_as(ctypes.c_void_p))
+    native.set_engine('exact-fft')
+    for row in (0, 2):
+        acc = H.dev(thr, accum)
+        _call("nufhe_external_mul", thr.handle, native.handle, ptr(acc), row, 7)
+        assert (H.host(acc) == orc.tgsw_external_mul(accum, bk, row)).all()
+    native.destroy()
+    # every digit at +-512, every key coefficient at +-2^31: the sums reach their largest magnitude
+    rs = numpy.random.RandomState(77)
+    tmin = numpy.uint32((0 - (2**31 + 2**21)) % 2**32).view(numpy.int32)
+    tmax = numpy.uint32(((1023 << 22) | (1023 << 12)) - (2**31 + 2**21)).view(numpy.int32)
+    accum = numpy.where(rs.rand(5, 3, 1024) < 0.5, tmax, tmin).astype(numpy.int32)
+    tgsw = numpy.where(rs.rand(2, 3, 2, 3, 1024) < 0.5, numpy.int32(2**31 - 1), numpy.int32(-2**31)).astype(numpy.int32)
+    bk = numpy.ascontiguousarray(orc.tlwe_transform_samples(tgsw), numpy.uint64)
+    out = {}
+    for engine in ('native', 'exact-fft'):
+        native = NativeCloudKey(thr, 2, 'NTT', 2)
+        _call("nufhe_bk_upload_reference", native.handle, bk.ctypes.data_as(ctypes.c_void_p))
+        native.set_engine(engine)
+        acc = H.dev(thr, accum)
+        _call("nufhe_external_mul", thr.handle, native.handle, ptr(acc), 1, 5)
+        out[engine] = H.host(acc)
+        native.destroy()
+    assert (out['exact-fft'] == out['native']).all()
+    assert (out['native'] == orc.tgsw_external_mul(accum, bk, 1)).all()
+
+
+@pytest.mark.gpu
+def test_gpu_k2_exact_engine_gates_vs_reference_oracle_and_native(k2_env, thr, H, orc, golden_k2, k2_inputs):
+    """k = 2 gates on the exact engine: the reference's NAND golden, NAND / XOR / MUX on a ragged batch vs the oracle,
+    a heterogeneous gate batch, the step-by-step driver, and a 5 x CUs - 3 bit batch against the native ring kernel on
+    every word."""
+    import torch
+    import nufhe_amd
+    _, lwe_key, _, ck, cts, _ = k2_inputs
+    vm = k2_env['vm']; params = k2_env['params']; key = k2_env['cloud_key']
+    rng = orc.DeterministicRNG(1213)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    key.set_engine('exact-fft')
+    try:
+        assert key.engine == 'exact-fft'
+        d = [H.ciphertext_from_arrays(thr, c, params) for c in cts]
+        ra, rb, rcv = H.ct_arrays(vm.gate_nand(d[0], d[1]))
+        assert (ra == golden_k2['nand_k2_a']).all() and (rb == golden_k2['nand_k2_b']).all()
+        assert (rcv == golden_k2['nand_k2_cv']).all()
+        B = 37
+        ms = [rng.uniform_bool((B,)).astype(bool) for _ in range(3)]
+        cs = [orc.encrypt(rng, lwe_key, m, k2_env['oparams']) for m in ms]
+        ds = [H.ciphertext_from_arrays(thr, c, params) for c in cs]
+        for name, got, exp, truth in (
+                ('nand', vm.gate_nand(ds[0], ds[1]), orc.gate('gate_nand', ck, cs[0], cs[1]), ~(ms[0] & ms[1])),
+                ('xor', vm.gate_xor(ds[0], ds[1]), orc.gate('gate_xor', ck, cs[0], cs[1]), ms[0] ^ ms[1]),
+                ('mux', vm.gate_mux(ds[0], ds[1], ds[2]), orc.gate_mux(ck, cs[0], cs[1], cs[2]),
+                 numpy.where(ms[0], ms[1], ms[2]))):
+            ga = H.ct_arrays(got)
+            assert all((g == e).all() for g, e in zip(ga, exp)), name
+            assert (k2_env['ctx'].decrypt(k2_env['sk'], got) == truth).all(), name
+        rx, ry = vm.gate_batch([('gate_xor', ds[0][:9], ds[1][:9]), ('gate_mux', ds[0][9:13], ds[1][9:13], ds[2][9:13])])
+        ex = orc.gate('gate_xor', ck, tuple(x[:9] for x in cs[0]), tuple(x[:9] for x in cs[1]))
+        ey = orc.gate_mux(ck, *(tuple(x[9:13] for x in c) for c in cs))
+        assert all((g == e).all() for g, e in zip(H.ct_arrays(rx), ex))
+        assert all((g == e).all() for g, e in zip(H.ct_arrays(ry), ey))
+        pp = nufhe_amd.PerformanceParameters(params, single_kernel_bootstrap=False)
+        vm2 = k2_env['ctx'].make_virtual_machine(key, perf_params=pp)
+        assert all((g == e).all() for g, e in zip(H.ct_arrays(vm2.gate_xor(ds[0][:9], ds[1][:9])), ex))
+        Bl = 5 * cus - 3
+        ml = [rng.uniform_bool((Bl,)).astype(bool) for _ in range(2)]
+        dl = [H.ciphertext_from_arrays(thr, orc.encrypt(rng, lwe_key, m, k2_env['oparams']), params) for m in ml]
+        exact = H.ct_arrays(vm.gate_nand(dl[0], dl[1]))
+        key.set_engine('native')
+        native = H.ct_arrays(vm.gate_nand(dl[0], dl[1]))
+        assert all((x == y).all() for x, y in zip(exact, native))
+    finally:
+        key.set_engine('native')
+
+
+@pytest.mark.gpu
 def test_gpu_k2_context_end_to_end(thr):
     """Public API with tlwe_mask_size=2 (test/test_gates.py:96-100): GPU key generation, all binary
     gates + MUX on 64 bits, serialization round trip of the k = 2 cloud key."""

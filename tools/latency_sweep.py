@@ -16,11 +16,14 @@ from nufhe_amd.operators_integer import uint_min, uintarray_to_bitarray, bitarra
 
 def main():
     transform = sys.argv[1] if len(sys.argv) > 1 else 'NTT'
+    engine = sys.argv[2] if len(sys.argv) > 2 else 'native'           # 'exact-fft': the fp64 engine of NTT keys
     ctx = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(123))
     sk, ck = ctx.make_key_pair(transform_type=transform)
+    if engine != 'native':
+        ck.set_engine(engine)
     vm = ctx.make_virtual_machine(ck)
     rs = numpy.random.RandomState(1)
-    out = {"transform": transform, "nand_ms": {}, "mux_ms": {}}
+    out = {"transform": transform, "engine": engine, "nand_ms": {}, "mux_ms": {}}
     for B in (1, 32, 128, 256, 512, 1024, 2048, 3000, 4096, 8192):
         m = [rs.randint(0, 2, size=B).astype(bool) for _ in range(3)]
         c = [ctx.encrypt(sk, x) for x in m]
