@@ -719,6 +719,181 @@ FF_FN void brxk_bootstrap_body(u32 (&acc)[K + 1][16], const BrSource &s0, const 
         for (int r = 0; r < 16; r++) acc[m][r] = (u32)lds.acc[m * 1024 + lane + 64 * r];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Quad variant of the exact engine (k = 1, small batches): FOUR wavefronts per bit, one transform each way per wave.
+//   forward side : wave w = 2 m + d decomposes digit d of (X^a - 1) ACC_m and transforms it -> X_w, left in its exchange
+//                  buffer (idle until the inverse transform) for the three other waves
+//   product side : wave w = 2 mo + h sums  X_q (.) BK_row[q >> 1][q & 1][mo][half h]  over q = 0..3 in the order of the
+//                  one-wave kernel (the same fp64 values), transforms back, rounds, and adds  lo  (h = 0)  or  hi << 16
+//                  (h = 1) into ACC_mo with LDS atomics (integer additions commute: the result does not depend on
+//                  which wave comes first)
+// Three team barriers per step: X visible | every X read (buffers free for the inverse) | ACC complete.  No registers
+// to speak of (8 complex sums), so the 32 key words of a step are requested in front of and inside the forward transform
+// and have arrived when the products begin.  46 KiB of LDS per team: up to three teams per work-group.
+// ---------------------------------------------------------------------------------------------------------------------
+struct BrXfftQuadLds {
+    cplx *xbuf;              // this wave's exchange buffer (FFT_XBUF_ELEMS complex)
+    const cplx *xbuf_team;   // the team's four buffers, FFT_XBUF_ELEMS apart: wave q's transformed digit polynomial
+    i32 *acc;                // [2][1024], shared by the team
+    uint16_t *bara;          // [BR_MAX_LWE], shared
+    const cplx *tw1;
+    const cplx *tw2;
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BRXQ_LDS_ADD(p, v) ((void)__hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+#else
+#define BRXQ_LDS_ADD(p, v) ((void)(*(p) += (v)))
+#endif
+
+template <int W, class TeamSync>
+FF_FN void brxq_step(u32 a, const cplx *row, const BrXfftQuadLds &lds, const FftLane &L, TeamSync &&team_sync BR_PROBE_ARG)
+{
+    BR_PROBE_BEGIN();
+    constexpr int M = W >> 1, D = W & 1;          // forward side
+    constexpr int MO = W >> 1, H = W & 1;         // product side
+    const int lane = L.lane;
+    // key[q][r] = BK_row[q >> 1][q & 1][MO][half H], register r of this lane
+    cplx key[4][8];
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef u32 brx_u32x4 __attribute__((ext_vector_type(4)));
+    u32 voff = (u32)lane * (u32)sizeof(cplx);
+    asm volatile("" : "+v"(voff));
+    const u32 voff_hi = voff + 4096u;
+    auto load_key = [&](int q) {
+        // one descriptor per polynomial half (8 KiB): every offset is an instruction immediate, no scalar offset operand
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(row + (long)(q * 2 + MO) * BKX_POLY_ELEMS + H * BKF_POLY_ELEMS), (short)0, BKF_POLY_ELEMS * (int)sizeof(cplx),
+            0x00020000);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            union { brx_u32x4 w; cplx c; } u;
+            u.w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (r < 4 ? voff : voff_hi) + (u32)((r & 3) * 1024), 0, BRX_KEY_AUX);
+            key[q][r] = u.c;
+        }
+    };
+#else
+    auto load_key = [&](int q) {
+        const cplx *p = row + (long)(q * 2 + MO) * BKX_POLY_ELEMS + H * BKF_POLY_ELEMS + lane;
+#pragma unroll
+        for (int r = 0; r < 8; r++) key[q][r] = p[r * 64];
+    };
+#endif
+    // The 32 KiB of key words a wave needs per step are requested in four pieces of 8 KiB: in front of the rotation,
+    // behind the two exchange writes of the forward transform, and behind the transform.  All at once in front of the
+    // rotation the four waves of a team queue 128 KiB at the CU's one L2 port (64 bytes per clock) and the issue of
+    // the requests itself stalls for ~2 k cycles (tools/probe_xfft.py).
+    load_key(0);
+    BR_ISSUE_FENCE();
+    cplx x[1][8];
+    {
+        u32 T[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const u32 j = (u32)(lane + 64 * r);
+            const u32 t = (j - a) & 2047u;
+            const u32 v = (u32)lds.acc[M * 1024 + (t & 1023u)];
+            T[r] = ((t & 1024u) ? 0u - v : v) - (u32)lds.acc[M * 1024 + j];     // (X^a - 1) ACC_M, polynomials_cpu.py:46-58
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) x[0][r] = cplx{(double)br_digit<D>(T[r]), -(double)br_digit<D>(T[r + 8])};   // a_j - i a_{j+512}
+    }
+    cplx *const buf1[1] = {lds.xbuf};
+    BR_PROBE_MARK(0);
+    fft_forward_n<1>(x, buf1, lds.tw1, lds.tw2, L, [&](int stage) {
+        BR_ISSUE_FENCE();       // (fences on both sides: the requests stay where they are written)
+        load_key(1 + stage);
+        BR_ISSUE_FENCE();
+    });
+    BR_PROBE_MARK(1);
+    WAVE_SYNC();        // every lane is done with the exchange buffer
+#pragma unroll
+    for (int r = 0; r < 8; r++) lds.xbuf[r * 64 + lane] = x[0][r];
+    BR_ISSUE_FENCE();
+    load_key(3);
+    team_sync();        // (1) the four transformed digit polynomials are visible; every wave has read ACC
+    BR_PROBE_MARK(2);
+    cplx sum[1][8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) sum[0][r] = cplx{0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        cplx xq[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) xq[r] = lds.xbuf_team[q * FFT_XBUF_ELEMS + r * 64 + lane];   // (its own too: 32 registers less across the barrier)
+#pragma unroll
+        for (int r = 0; r < 8; r++) c_fma_acc(sum[0][r], xq[r], key[q][r]);
+        BR_ISSUE_FENCE();       // (one polynomial's X words in flight at a time: left alone all 24 reads are hoisted, 96 registers)
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the products are finished HERE: left alone the scheduler sinks half of them below the barrier and keeps their
+        // operands (key and X words) alive across it -- 50 registers spilled
+#pragma unroll
+        for (int r = 0; r < 8; r++) asm volatile("" : "+v"(sum[0][r].re), "+v"(sum[0][r].im));
+#endif
+    }
+    BR_PROBE_MARK(3);
+    team_sync();        // (2) every wave has read every X: the exchange buffers are free again
+    BR_PROBE_MARK(4);
+    fft_inverse_n<1>(sum, buf1, lds.tw1, lds.tw2, L);
+    BR_PROBE_MARK(5);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const u32 re = xfft_round_lo32(sum[0][r].re), im = xfft_round_lo32(-sum[0][r].im);
+        BRXQ_LDS_ADD((u32 *)lds.acc + MO * 1024 + lane + 64 * r, H ? re << 16 : re);
+        BRXQ_LDS_ADD((u32 *)lds.acc + MO * 1024 + lane + 64 * (r + 8), H ? im << 16 : im);
+    }
+    BR_PROBE_MARK(6);
+    team_sync();        // (3) ACC complete
+    BR_PROBE_MARK(7);
+}
+
+template <int W, class TeamSync>
+FF_FN void brxq_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSource &s1, i32 c0, long bit,
+                          const cplx *bk, int n, i32 mu, const BrXfftQuadLds &lds, const FftLane &L, TeamSync &&team_sync)
+{
+    const int tid = 64 * W + L.lane;
+    for (int i = tid; i < n; i += 256) {
+        u32 v = 0;
+        if (s0.p) v += (u32)s0.p * (u32)s0.a[bit * s0.a_stride + i];
+        if (s1.p) v += (u32)s1.p * (u32)s1.a[bit * s1.a_stride + i];
+        lds.bara[i] = (uint16_t)br_modswitch(v);
+    }
+    u32 vb = (u32)c0;
+    if (s0.p) vb += (u32)s0.p * (u32)s0.b[bit * s0.b_stride];
+    if (s1.p) vb += (u32)s1.p * (u32)s1.b[bit * s1.b_stride];
+    const u32 barb = br_modswitch(vb);
+    for (int j = tid; j < 1024; j += 256) {
+        const u32 t = ((u32)j + barb) & 2047u;
+        lds.acc[j] = 0;
+        lds.acc[1024 + j] = (t < 1024u) ? mu : (i32)(0u - (u32)mu);
+    }
+    WAVE_SYNC();
+    team_sync();
+#if defined(BR_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+    BrProbe probe_ = {};
+    const long long probe_w0 = clock64(), probe_r0 = wall_clock64();
+#endif
+    for (int i = 0; i < n; i++) {
+        const u32 a = WAVE_UNIFORM((u32)lds.bara[i]);
+        if (a == 0) continue;        // (all four waves read the same word)
+        brxq_step<W>(a, bk + (long)i * BKX_ROW_ELEMS, lds, L, team_sync BR_PROBE_PASS);
+    }
+#if defined(BR_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+    if (L.lane == 0) {
+        for (int i = 0; i < 8; i++) atomicAdd(&g_br_probe[i], (unsigned long long)probe_.t[i]);
+        atomicAdd(&g_br_probe[14], (unsigned long long)(clock64() - probe_w0));
+        atomicAdd(&g_br_probe[13], 1ull);
+        atomicAdd(&g_br_probe[12], (unsigned long long)(wall_clock64() - probe_r0));   // 100 MHz
+    }
+#endif
+    // sample extraction (tlwe_cpu.py:55-58)
+    for (int j = tid; j < 1024; j += 256) {
+        const u32 v = (u32)lds.acc[j];
+        out_a[(1024 - j) & 1023] = (i32)(j == 0 ? v : 0u - v);
+    }
+    if (tid == 0) *out_b = lds.acc[1024];
+}
+
 // Key preparation: one TGSW polynomial (int32 coefficients) -> its two balanced halves, each as the (a_j, -a_{j+512})
 // input of the forward transform (kernels.hip k_bkx_from_coeffs).  K = lo + 2^16 hi with lo = sign-extended low half.
 FF_FN void xfft_split(i32 k, i32 &lo, i32 &hi)

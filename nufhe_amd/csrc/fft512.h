@@ -191,9 +191,15 @@ FF_FN void fft_tw2_load(FftTw2Regs &t, const cplx *tw2, const FftLane &L)
     for (int c = 0; c < 8; c++) t.v[c] = tw2[c * 8 + L.a];
 }
 
-template <int NX, class TW2>
+struct FftNoHook {
+    FF_HD inline void operator()(int) const {}
+};
+
+// hook(0), hook(1): called once behind the writes of exchange 1 / exchange 2 -- where the wave would otherwise only wait
+// for LDS (the quad kernel of the exact engine requests bootstrapping-key words there)
+template <int NX, class TW2, class Hook = FftNoHook>
 FF_FN void fft_forward_n(cplx (&x)[NX][8], cplx *const (&xbuf)[NX], const cplx *tw1, const TW2 &tw2,
-                         const FftLane &L)
+                         const FftLane &L, Hook &&hook = Hook())
 {
 #pragma unroll
     for (int t = 0; t < NX; t++) dft8_pretwisted_fwd(x[t]);
@@ -204,6 +210,7 @@ FF_FN void fft_forward_n(cplx (&x)[NX][8], cplx *const (&xbuf)[NX], const cplx *
 #pragma unroll
         for (int t = 0; t < NX; t++) xbuf[t][L.x1w + k2 * FFT_ROW] = c_mul(x[t][i], w);
     }
+    hook(0);
     WAVE_SYNC();
 #pragma unroll
     for (int t = 0; t < NX; t++)
@@ -220,6 +227,7 @@ FF_FN void fft_forward_n(cplx (&x)[NX][8], cplx *const (&xbuf)[NX], const cplx *
             xbuf[t][L.x2a + 8 * c + ((L.a + c) & 7)] = v;
         }
     }
+    hook(1);
     WAVE_SYNC();
     // now this lane is (k2, c = lane & 7); read a = 0..7
 #pragma unroll

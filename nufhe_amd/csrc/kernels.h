@@ -149,7 +149,8 @@ hipError_t launch_bkf_from_coeffs(cplx *out, const i32 *in, long polys, const cp
                                   hipStream_t stream);
 // exact-FFT engine (kernels_xfft.hip)
 hipError_t xfft_init();
-hipError_t launch_bootstrap_xfft(const BrLaunch &P, int mask_size, int num_cus, hipStream_t stream);
+// quad_max_bits: batches up to here run four waves per bit (k = 1)
+hipError_t launch_bootstrap_xfft(const BrLaunch &P, int mask_size, int num_cus, long quad_max_bits, hipStream_t stream);
 hipError_t launch_blind_rotate_accum_xfft(i32 *accum, const cplx *bkx, const i32 *bara, long bara_stride, int row0, int n_rows,
                                           int external_mul_only, long batch, const cplx *tw1, const cplx *tw2, u32 *park,
                                           int mask_size, hipStream_t stream);

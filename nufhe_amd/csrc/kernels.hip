@@ -1386,6 +1386,9 @@ BrTuning br_tuning_for(const char *arch_name, int num_cus)
     return T;
 }
 
+#ifndef BRX_QUAD_CUS
+#define BRX_QUAD_CUS 2
+#endif
 hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, const BrTuning &T, hipStream_t stream)
 {
     if (P.nbits_total == 0) return hipSuccess;
@@ -1395,7 +1398,8 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, con
     const int num_cus = T.num_cus;
     if (transform == BR_TRANSFORM_XFFT) {
         if (mask_size == 1 && !P.park) return hipErrorInvalidValue;
-        return launch_bootstrap_xfft(P, mask_size, num_cus, stream);
+        // exact engine: four waves per bit up to BRX_QUAD_CUS x CUs bits (the team switch at 0 turns it off), then one wave per bit
+        return launch_bootstrap_xfft(P, mask_size, num_cus, T.team_max_bits > 0 ? (long)BRX_QUAD_CUS * num_cus : 0, stream);
     }
     const long team_max_bits = transform == 0 ? T.team_max_bits : 2 * T.team_max_bits_fft;    // (FFT: halved again below)
     const long pair_max_bits = transform == 0 ? (mask_size == 1 ? T.pair_max_bits_ntt : (long)T.ring_k2)

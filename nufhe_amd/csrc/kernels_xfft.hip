@@ -170,6 +170,66 @@ __global__ __launch_bounds__(64 * BRX2_WAVES, 1) void k_blind_rotate_accum_xfft_
         for (int r = 0; r < 16; r++) my[m * 1024 + lane + 64 * r] = lds.acc[m * 1024 + lane + 64 * r];
 }
 
+// ---- small batches, k = 1: four waves per bit (brxq_*), up to BRXQ_MAX_TEAMS teams per work-group ----
+// LDS: tables | arrival words of the team barriers (in the pacing block) | pad | per team: ACC 8 KiB, bara 1 KiB, 4 exchange buffers
+#define BRXQ_MAX_TEAMS 2
+#define XQUAD_LDS_BYTES (2 * 1024 * 4 + BR_MAX_LWE * 2 + 4 * WAVE_FXBUF_BYTES)
+static_assert(XQUAD_LDS_BYTES % 256 == 0, "per-team LDS regions of k_bootstrap_xfft_quad are 256-byte aligned");
+static constexpr size_t brxq_lds_bytes(int teams) { return FTABLE_LDS_BYTES + BR_PACE_BYTES + BRX_BASE_PAD + (size_t)teams * XQUAD_LDS_BYTES; }
+static_assert(brxq_lds_bytes(BRXQ_MAX_TEAMS) <= 160 * 1024, "LDS budget of k_bootstrap_xfft_quad");
+static_assert(4 * BRXQ_MAX_TEAMS * 4 <= BR_PACE_BYTES, "arrival words of the team barriers");
+
+// ONE_TEAM: the work-group IS the team (batches up to 1 x CUs bits, the latency case): s_barrier instead of the arrival words
+template <bool ONE_TEAM>
+__global__ __launch_bounds__(ONE_TEAM ? 256 : 256 * BRXQ_MAX_TEAMS, 1) void k_bootstrap_xfft_quad(BrLaunch P)
+{
+    load_ftables((const cplx *)P.tw_a, (const cplx *)P.tw_b);      // (zeroes the arrival words, ends with a work-group barrier)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int team = ONE_TEAM ? 0 : wave >> 2, w = wave & 3;
+    const long gbit = ONE_TEAM ? (long)blockIdx.x : (long)blockIdx.x * (blockDim.x >> 8) + team;    // teams per group chosen at launch
+    if (gbit >= P.nbits_total) return;                                 // (all four waves of the team)
+    const int job = gbit >= P.bits_per_job ? 1 : 0;
+    const long bit = gbit - (job ? P.bits_per_job : 0);
+    unsigned char *base = g_smem + FTABLE_LDS_BYTES + BR_PACE_BYTES + BRX_BASE_PAD + team * XQUAD_LDS_BYTES;
+    BrXfftQuadLds lds;
+    lds.acc = (i32 *)base;
+    lds.bara = (uint16_t *)(base + 2 * 1024 * 4);
+    lds.xbuf_team = (const cplx *)(base + 2 * 1024 * 4 + BR_MAX_LWE * 2);
+    lds.xbuf = (cplx *)lds.xbuf_team + w * FFT_XBUF_ELEMS;
+    lds.tw1 = (const cplx *)g_smem;
+    lds.tw2 = (const cplx *)g_smem + FFT_TW1_ELEMS;
+    // team barrier: one arrival counter per wave; a wave publishes its count and waits until all four have reached it
+    typedef __attribute__((address_space(3))) volatile u32 lds_vu32;
+    lds_vu32 *arrive = (lds_vu32 *)((u32 *)(g_smem + FTABLE_LDS_BYTES) + 4 * team);
+    u32 seq = 0;
+    auto team_sync = [&] {
+        if (ONE_TEAM) {
+            __syncthreads();
+            return;
+        }
+        seq++;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        arrive[w] = seq;
+        for (;;) {
+            const u32 a0 = arrive[0], a1 = arrive[1], a2 = arrive[2], a3 = arrive[3];
+            const i32 d0 = (i32)(a0 - seq), d1 = (i32)(a1 - seq), d2 = (i32)(a2 - seq), d3 = (i32)(a3 - seq);
+            if (__builtin_amdgcn_readfirstlane((d0 | d1 | d2 | d3)) >= 0) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    const FftLane L = fft_lane_init(lane);
+    i32 *out_a = P.out_a + gbit * P.out_a_stride, *out_b = P.out_b + gbit * P.out_b_stride;
+    const BrSource &s0 = P.job[job].s0, &s1 = P.job[job].s1;
+    const i32 c0 = P.job[job].c0;
+    switch (w) {
+    case 0: brxq_bootstrap<0>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    case 1: brxq_bootstrap<1>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    case 2: brxq_bootstrap<2>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    default: brxq_bootstrap<3>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    }
+}
+
 // Split key image: one wave per (polynomial, half).  K = lo + 2^16 hi (xfft_split), each half through the forward
 // transform, stored in the wave layout of the product phase: [poly][half][reg][lane].
 #define BKX_WAVES_PER_BLOCK 4
@@ -208,13 +268,28 @@ hipError_t xfft_init()
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap_xfft_k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)brx2_lds_bytes(BRX2_WAVES));
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_bootstrap_xfft_quad<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)brxq_lds_bytes(BRXQ_MAX_TEAMS));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_bootstrap_xfft_quad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)brxq_lds_bytes(1));
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void *)k_blind_rotate_accum_xfft_k2, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)brx2_lds_bytes(BRX2_WAVES));
 }
 
-hipError_t launch_bootstrap_xfft(const BrLaunch &P, int mask_size, int num_cus, hipStream_t stream)
+hipError_t launch_bootstrap_xfft(const BrLaunch &P, int mask_size, int num_cus, long quad_max_bits, hipStream_t stream)
 {
     if (P.nbits_total == 0) return hipSuccess;
+    if (mask_size == 1 && P.nbits_total <= quad_max_bits) {
+        // small batch: 4 waves per bit; as few teams per work-group as still give one round
+        long teams = (P.nbits_total + num_cus - 1) / num_cus;
+        if (teams > BRXQ_MAX_TEAMS) teams = BRXQ_MAX_TEAMS;
+        if (teams == 1)
+            hipLaunchKernelGGL(k_bootstrap_xfft_quad<true>, dim3((unsigned)P.nbits_total), dim3(256), brxq_lds_bytes(1), stream, P);
+        else
+            hipLaunchKernelGGL(k_bootstrap_xfft_quad<false>, dim3(blocks_for(P.nbits_total, (int)teams)), dim3(256 * (unsigned)teams),
+                               brxq_lds_bytes((int)teams), stream, P);
+        return hipGetLastError();
+    }
     if (mask_size == 2) {
         const int w = br_pick_waves(P.nbits_total, BRX2_WAVES, num_cus);
         hipLaunchKernelGGL(k_bootstrap_xfft_k2, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), brx2_lds_bytes(w), stream, P);

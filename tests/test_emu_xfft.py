@@ -190,3 +190,23 @@ def test_mask_size_2_blind_rotation_reduced_key_equals_ntt_oracle(orc):
     ea, eb = orc.bootstrap_extract(bk_ntt, ta[None, :], tb, MU)
     ga, gb = emu.bootstrap_bit_xfft_k2(bkx, n, (a0, b0), 1, (a1, b1), 1, -MU, MU)
     assert (ga == ea[0]).all() and gb == eb[0]
+
+
+def test_quad_kernel_body_equals_ntt_oracle_and_the_one_wave_body(orc):
+    """four waves per bit (brxq_*): forward side by (polynomial, digit), product side by (output, key half), ACC through
+    LDS atomics -- the same words as the oracle's prime-field path and as the one-wave body, full-range key and inputs"""
+    rs = numpy.random.RandomState(65)
+    n = 6
+    tgsw = rs.randint(-2**31, 2**31, size=(n, 2, 2, 2, 1024), dtype=numpy.int32)
+    bk_ntt = orc.tlwe_transform_samples(tgsw)
+    bkx = emu.bkx_from_coeffs(tgsw)
+    MU = 2**29
+    a0 = rs.randint(-2**31, 2**31, size=n, dtype=numpy.int32); a1 = rs.randint(-2**31, 2**31, size=n, dtype=numpy.int32)
+    a0[3] = 0; a1[3] = 0        # one step with X^0 - 1 = 0: skipped by all four waves
+    b0 = rs.randint(-2**31, 2**31, size=1, dtype=numpy.int32); b1 = rs.randint(-2**31, 2**31, size=1, dtype=numpy.int32)
+    ta = (a0 + a1).astype(numpy.int32); tb = (numpy.int32(-MU) + b0 + b1).astype(numpy.int32)
+    ea, eb = orc.bootstrap_extract(bk_ntt, ta[None, :], tb, MU)
+    ga, gb = emu.bootstrap_bit_xfft_quad(bkx, n, (a0, b0), 1, (a1, b1), 1, -MU, MU)
+    assert (ga == ea[0]).all() and gb == eb[0]
+    wa, wb = emu.bootstrap_bit_xfft(bkx, n, (a0, b0), 1, (a1, b1), 1, -MU, MU)
+    assert (ga == wa).all() and gb == wb

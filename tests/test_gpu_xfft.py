@@ -140,10 +140,12 @@ def test_gates_every_word_vs_oracle_ragged_batch(env, H, thr, orc):
     assert (ma == expm[0]).all() and (mb == expm[1]).all() and (mcv == expm[2]).all()
 
 
-@pytest.mark.parametrize("B", [1, 257, 2048, 4096, 4100])
+@pytest.mark.parametrize("B", [1, 257, 511, 2048, 4096, 4100])
 def test_engines_agree_word_for_word_at_every_batch_size(env, H, B):
-    """the native engine switches kernel families with the batch size (team8 / pair / wave + tail); the exact engine
-    must give the same ciphertexts at each of them"""
+    """the native engine switches kernel families with the batch size (team8 / pair / wave + tail), the exact engine
+    between four waves per bit (up to 2 x CUs bits: 1, 257 = one and two teams per work-group with a ragged last group;
+    MUX on 257 and 511 bits = 514 / 1022 rotations: the wave kernel, and the job boundary inside a two-team group at 1 bit)
+    and one wave per bit: the same ciphertexts everywhere"""
     vm = env['vm']; ctx = env['ctx']; sk = env['secret_key']; key = env['cloud_key']
     rng = numpy.random.RandomState(B)
     ms = [rng.randint(0, 2, size=(B,)).astype(bool) for _ in range(3)]
@@ -158,6 +160,35 @@ def test_engines_agree_word_for_word_at_every_batch_size(env, H, B):
     for g in range(2):
         for x, y in zip(out['exact-fft'][g], out['native'][g]):
             assert int((x != y).sum()) == 0
+    assert (ctx.decrypt(sk, vm.gate_nand(cs[0], cs[1])) == ~(ms[0] & ms[1])).all()
+
+
+def test_quad_kernel_equals_wave_kernel_and_oracle(env, H, thr, orc):
+    """k_bootstrap_xfft_quad (four waves per bit, brxq_*) against k_bootstrap_xfft (team switch at 0) on every word of a
+    2 x CUs - 5 bit NAND (two teams per work-group, ragged last group) and a 301-bit MUX (602 rotations > 2 x CUs on the
+    wave kernel either way; 100 bits = 200 rotations: job boundary inside the quad launch); oracle on the first bits"""
+    import torch
+    from nufhe_amd import _lib
+    vm = env['vm']; ctx = env['ctx']; sk = env['secret_key']; ck = env['ck']
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    rng = numpy.random.RandomState(4242)
+    B = 2 * cus - 5
+    ms = [rng.randint(0, 2, size=(B,)).astype(bool) for _ in range(3)]
+    cs = [ctx.encrypt(sk, m) for m in ms]
+    quad = (H.ct_arrays(vm.gate_nand(cs[0], cs[1])), H.ct_arrays(vm.gate_mux(cs[0][:100], cs[1][:100], cs[2][:100])))
+    try:
+        _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, 0)
+        wave = (H.ct_arrays(vm.gate_nand(cs[0], cs[1])), H.ct_arrays(vm.gate_mux(cs[0][:100], cs[1][:100], cs[2][:100])))
+    finally:
+        _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, -1)
+    for g in range(2):
+        for x, y in zip(quad[g], wave[g]):
+            assert int((x != y).sum()) == 0
+    host = [H.ct_arrays(c[:6]) for c in cs]
+    exp = orc.gate('gate_nand', ck, host[0][:2], host[1][:2])
+    assert all((q[:6] == e).all() for q, e in zip(quad[0], exp))
+    expm = orc.gate_mux(ck, *[tuple(h[:2]) for h in host])
+    assert all((q[:6] == e).all() for q, e in zip(quad[1], expm))
     assert (ctx.decrypt(sk, vm.gate_nand(cs[0], cs[1])) == ~(ms[0] & ms[1])).all()
 
 

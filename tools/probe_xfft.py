@@ -29,6 +29,9 @@ for _ in range(reps):
 lib.nufhe_probe_read_xfft(buf)
 names = ['rotate + park store', 'digits + fwd pair m=0', 'mac m=0 (64 key loads)', 'digits + fwd pair m=1', 'mac m=1 (64 key loads)',
          'inverse pair lo + park load + round', 'inverse pair hi', 'round hi + mirror write']
+if bits <= 512:     # the four-waves-per-bit kernel (brxq_step): every wave of a team is counted
+    names = ['key requests + rotation + digits', 'forward transform', 'X write + team barrier 1', 'X reads + products',
+             'team barrier 2', 'inverse transform', 'rounding + ACC atomics', 'team barrier 3']
 waves = buf[13] / reps
 iters = 500.0 * waves
 print('blind-rotate wall time per wave: %.3f ms -> shader clock %.3f GHz' % (buf[12] / max(1, buf[13]) * 1e-5, buf[14] / max(1, buf[12]) * 0.1))
