@@ -102,7 +102,8 @@ int nufhe_cloudkey_destroy(nufhe_cloudkey *key);
  *   NUFHE_ENGINE_EXACT_FFT  the fp64 folded FFT on a key whose coefficients are split into two balanced 16-bit halves:
  *                           all sums stay below 2^36, where the worst-case fp64 error (0.037) cannot
  *                           change a rounding -- the same words as the native engine for every key and every input,
- *                           at ~0.5 x its time (tlwe_mask_size 1 and 2).  The split image (65.5 MB for n = 500, k = 1) is
+ *                           at ~0.5 x its time on large batches and ~0.4 x on small ones (four waves per bit up to
+ *                           2 x CUs bits; tlwe_mask_size 1 and 2).  The split image (65.5 MB for n = 500, k = 1) is
  *                           derived from the uploaded key on first use; key images / downloads are unaffected. */
 #define NUFHE_ENGINE_NATIVE 0
 #define NUFHE_ENGINE_EXACT_FFT 1

@@ -727,12 +727,14 @@ FF_FN void brxk_bootstrap_body(u32 (&acc)[K + 1][16], const BrSource &s0, const 
 //                  one-wave kernel (the same fp64 values), transforms back, rounds, and adds  lo  (h = 0)  or  hi << 16
 //                  (h = 1) into ACC_mo with LDS atomics (integer additions commute: the result does not depend on
 //                  which wave comes first)
-// Three team barriers per step: X visible | every X read (buffers free for the inverse) | ACC complete.  No registers
+// Three team barriers per step: X visible | every X read (buffers free for the inverse; not needed when the inverse
+// transform has an exchange buffer of its own: SPLIT, one team per work-group) | ACC complete.  No registers
 // to speak of (8 complex sums), so the 32 key words of a step are requested in front of and inside the forward transform
 // and have arrived when the products begin.  46 KiB of LDS per team: up to three teams per work-group.
 // ---------------------------------------------------------------------------------------------------------------------
 struct BrXfftQuadLds {
     cplx *xbuf;              // this wave's exchange buffer (FFT_XBUF_ELEMS complex)
+    cplx *xbuf_inv;          // SPLIT: a second one for the inverse transform (then barrier 2 is not needed); else = xbuf
     const cplx *xbuf_team;   // the team's four buffers, FFT_XBUF_ELEMS apart: wave q's transformed digit polynomial
     i32 *acc;                // [2][1024], shared by the team
     uint16_t *bara;          // [BR_MAX_LWE], shared
@@ -746,7 +748,7 @@ struct BrXfftQuadLds {
 #define BRXQ_LDS_ADD(p, v) ((void)(*(p) += (v)))
 #endif
 
-template <int W, class TeamSync>
+template <int W, bool SPLIT, class TeamSync>
 FF_FN void brxq_step(u32 a, const cplx *row, const BrXfftQuadLds &lds, const FftLane &L, TeamSync &&team_sync BR_PROBE_ARG)
 {
     BR_PROBE_BEGIN();
@@ -820,7 +822,7 @@ FF_FN void brxq_step(u32 a, const cplx *row, const BrXfftQuadLds &lds, const Fft
     for (int q = 0; q < 4; q++) {
         cplx xq[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) xq[r] = lds.xbuf_team[q * FFT_XBUF_ELEMS + r * 64 + lane];   // (its own too: 32 registers less across the barrier)
+        for (int r = 0; r < 8; r++) xq[r] = q == W ? x[0][r] : lds.xbuf_team[q * FFT_XBUF_ELEMS + r * 64 + lane];
 #pragma unroll
         for (int r = 0; r < 8; r++) c_fma_acc(sum[0][r], xq[r], key[q][r]);
         BR_ISSUE_FENCE();       // (one polynomial's X words in flight at a time: left alone all 24 reads are hoisted, 96 registers)
@@ -832,9 +834,10 @@ FF_FN void brxq_step(u32 a, const cplx *row, const BrXfftQuadLds &lds, const Fft
 #endif
     }
     BR_PROBE_MARK(3);
-    team_sync();        // (2) every wave has read every X: the exchange buffers are free again
+    if (!SPLIT) team_sync();        // (2) every wave has read every X: the exchange buffers are free again
     BR_PROBE_MARK(4);
-    fft_inverse_n<1>(sum, buf1, lds.tw1, lds.tw2, L);
+    cplx *const buf2[1] = {SPLIT ? lds.xbuf_inv : lds.xbuf};
+    fft_inverse_n<1>(sum, buf2, lds.tw1, lds.tw2, L);
     BR_PROBE_MARK(5);
 #pragma unroll
     for (int r = 0; r < 8; r++) {
@@ -847,7 +850,7 @@ FF_FN void brxq_step(u32 a, const cplx *row, const BrXfftQuadLds &lds, const Fft
     BR_PROBE_MARK(7);
 }
 
-template <int W, class TeamSync>
+template <int W, bool SPLIT, class TeamSync>
 FF_FN void brxq_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSource &s1, i32 c0, long bit,
                           const cplx *bk, int n, i32 mu, const BrXfftQuadLds &lds, const FftLane &L, TeamSync &&team_sync)
 {
@@ -876,7 +879,7 @@ FF_FN void brxq_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSo
     for (int i = 0; i < n; i++) {
         const u32 a = WAVE_UNIFORM((u32)lds.bara[i]);
         if (a == 0) continue;        // (all four waves read the same word)
-        brxq_step<W>(a, bk + (long)i * BKX_ROW_ELEMS, lds, L, team_sync BR_PROBE_PASS);
+        brxq_step<W, SPLIT>(a, bk + (long)i * BKX_ROW_ELEMS, lds, L, team_sync BR_PROBE_PASS);
     }
 #if defined(BR_PROBE) && defined(__HIP_DEVICE_COMPILE__)
     if (L.lane == 0) {

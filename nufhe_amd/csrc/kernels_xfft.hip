@@ -175,7 +175,8 @@ __global__ __launch_bounds__(64 * BRX2_WAVES, 1) void k_blind_rotate_accum_xfft_
 #define BRXQ_MAX_TEAMS 2
 #define XQUAD_LDS_BYTES (2 * 1024 * 4 + BR_MAX_LWE * 2 + 4 * WAVE_FXBUF_BYTES)
 static_assert(XQUAD_LDS_BYTES % 256 == 0, "per-team LDS regions of k_bootstrap_xfft_quad are 256-byte aligned");
-static constexpr size_t brxq_lds_bytes(int teams) { return FTABLE_LDS_BYTES + BR_PACE_BYTES + BRX_BASE_PAD + (size_t)teams * XQUAD_LDS_BYTES; }
+// (a lone team has room for a second exchange buffer per wave: no barrier in front of the inverse transform)
+static constexpr size_t brxq_lds_bytes(int teams) { return FTABLE_LDS_BYTES + BR_PACE_BYTES + BRX_BASE_PAD + (size_t)teams * XQUAD_LDS_BYTES + (teams == 1 ? 4 * WAVE_FXBUF_BYTES : 0); }
 static_assert(brxq_lds_bytes(BRXQ_MAX_TEAMS) <= 160 * 1024, "LDS budget of k_bootstrap_xfft_quad");
 static_assert(4 * BRXQ_MAX_TEAMS * 4 <= BR_PACE_BYTES, "arrival words of the team barriers");
 
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(ONE_TEAM ? 256 : 256 * BRXQ_MAX_TEAMS, 1) void k_bo
     lds.bara = (uint16_t *)(base + 2 * 1024 * 4);
     lds.xbuf_team = (const cplx *)(base + 2 * 1024 * 4 + BR_MAX_LWE * 2);
     lds.xbuf = (cplx *)lds.xbuf_team + w * FFT_XBUF_ELEMS;
+    lds.xbuf_inv = ONE_TEAM ? lds.xbuf + 4 * FFT_XBUF_ELEMS : lds.xbuf;
     lds.tw1 = (const cplx *)g_smem;
     lds.tw2 = (const cplx *)g_smem + FFT_TW1_ELEMS;
     // team barrier: one arrival counter per wave; a wave publishes its count and waits until all four have reached it
@@ -223,10 +225,10 @@ __global__ __launch_bounds__(ONE_TEAM ? 256 : 256 * BRXQ_MAX_TEAMS, 1) void k_bo
     const BrSource &s0 = P.job[job].s0, &s1 = P.job[job].s1;
     const i32 c0 = P.job[job].c0;
     switch (w) {
-    case 0: brxq_bootstrap<0>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
-    case 1: brxq_bootstrap<1>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
-    case 2: brxq_bootstrap<2>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
-    default: brxq_bootstrap<3>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    case 0: brxq_bootstrap<0, ONE_TEAM>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    case 1: brxq_bootstrap<1, ONE_TEAM>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    case 2: brxq_bootstrap<2, ONE_TEAM>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    default: brxq_bootstrap<3, ONE_TEAM>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
     }
 }
 

@@ -256,7 +256,7 @@ def bootstrap_bit_xfft_k2(bkx, n, src0, p0, src1, p1, c0, mu):
     return out_a, out_b[0]
 
 
-def bootstrap_bit_xfft_quad(bkx, n, src0, p0, src1, p1, c0, mu):
+def bootstrap_bit_xfft_quad(bkx, n, src0, p0, src1, p1, c0, mu, split=False):
     """k = 1, four waves per bit (brxq_*): the same outputs as bootstrap_bit_xfft"""
     a0 = numpy.ascontiguousarray(src0[0], numpy.int32); b0 = numpy.ascontiguousarray(src0[1], numpy.int32).reshape(1)
     a1 = numpy.ascontiguousarray(src1[0], numpy.int32); b1 = numpy.ascontiguousarray(src1[1], numpy.int32).reshape(1)
@@ -265,5 +265,5 @@ def bootstrap_bit_xfft_quad(bkx, n, src0, p0, src1, p1, c0, mu):
     lib().emu_bootstrap_bit_xfft_quad(_p(out_a, c_i32p), _p(out_b, c_i32p), _p(bkx.view(numpy.float64), c_f64p),
                                       ctypes.c_int(n), _p(a0, c_i32p), _p(b0, c_i32p), ctypes.c_int32(p0),
                                       _p(a1, c_i32p), _p(b1, c_i32p), ctypes.c_int32(p1),
-                                      ctypes.c_int32(c0), ctypes.c_int32(mu))
+                                      ctypes.c_int32(c0), ctypes.c_int32(mu), ctypes.c_int(1 if split else 0))
     return out_a, out_b[0]

@@ -581,22 +581,30 @@ void emu_bootstrap_bit_xfft_k2(i32 *out_a, i32 *out_b, const double *bkx, int n,
 // the 4-wave quad variant of the exact engine (brxq_*): 256 fibres
 void emu_bootstrap_bit_xfft_quad(i32 *out_a, i32 *out_b, const double *bkx, int n,
                                  const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,
-                                 i32 c0, i32 mu)
+                                 i32 c0, i32 mu, int split)
 {
     ftables();
-    std::vector<cplx> xbuf(4 * FFT_XBUF_ELEMS);
+    std::vector<cplx> xbuf(8 * FFT_XBUF_ELEMS);
     std::vector<i32> accbuf(2 * 1024);
     std::vector<uint16_t> bara(BR_MAX_LWE);
     BrSource s0{a0, b0, 0, 0, p0}, s1{a1, b1, 0, 0, p1};
     emu_run_team(4, [&](int w, int lane) {
-        BrXfftQuadLds lds{xbuf.data() + w * FFT_XBUF_ELEMS, xbuf.data(), accbuf.data(), bara.data(), g_ftw1, g_ftw2};
+        BrXfftQuadLds lds{xbuf.data() + w * FFT_XBUF_ELEMS, xbuf.data() + (split ? 4 + w : w) * FFT_XBUF_ELEMS, xbuf.data(), accbuf.data(), bara.data(), g_ftw1, g_ftw2};
         FftLane L = fft_lane_init(lane);
         auto sync = [] { emu_team_sync(); };
         switch (w) {
-        case 0: brxq_bootstrap<0>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync); break;
-        case 1: brxq_bootstrap<1>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync); break;
-        case 2: brxq_bootstrap<2>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync); break;
-        default: brxq_bootstrap<3>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync); break;
+        case 0: if (split) brxq_bootstrap<0, true>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync);
+                else brxq_bootstrap<0, false>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync);
+                break;
+        case 1: if (split) brxq_bootstrap<1, true>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync);
+                else brxq_bootstrap<1, false>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync);
+                break;
+        case 2: if (split) brxq_bootstrap<2, true>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync);
+                else brxq_bootstrap<2, false>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync);
+                break;
+        default: if (split) brxq_bootstrap<3, true>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync);
+                else brxq_bootstrap<3, false>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync);
+                break;
         }
     });
 }

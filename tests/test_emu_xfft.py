@@ -206,7 +206,8 @@ def test_quad_kernel_body_equals_ntt_oracle_and_the_one_wave_body(orc):
     b0 = rs.randint(-2**31, 2**31, size=1, dtype=numpy.int32); b1 = rs.randint(-2**31, 2**31, size=1, dtype=numpy.int32)
     ta = (a0 + a1).astype(numpy.int32); tb = (numpy.int32(-MU) + b0 + b1).astype(numpy.int32)
     ea, eb = orc.bootstrap_extract(bk_ntt, ta[None, :], tb, MU)
-    ga, gb = emu.bootstrap_bit_xfft_quad(bkx, n, (a0, b0), 1, (a1, b1), 1, -MU, MU)
-    assert (ga == ea[0]).all() and gb == eb[0]
+    for split in (False, True):      # (True: the one-team build, a second exchange buffer instead of barrier 2)
+        ga, gb = emu.bootstrap_bit_xfft_quad(bkx, n, (a0, b0), 1, (a1, b1), 1, -MU, MU, split=split)
+        assert (ga == ea[0]).all() and gb == eb[0]
     wa, wb = emu.bootstrap_bit_xfft(bkx, n, (a0, b0), 1, (a1, b1), 1, -MU, MU)
     assert (ga == wa).all() and gb == wb
