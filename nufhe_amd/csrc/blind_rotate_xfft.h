@@ -735,8 +735,8 @@ FF_FN void brxk_bootstrap_body(u32 (&acc)[K + 1][16], const BrSource &s0, const 
 struct BrXfftQuadLds {
     cplx *xbuf;              // this wave's exchange buffer (FFT_XBUF_ELEMS complex)
     cplx *xbuf_inv;          // SPLIT: a second one for the inverse transform (then barrier 2 is not needed); else = xbuf
-    const cplx *xbuf_team;   // the team's four buffers, FFT_XBUF_ELEMS apart: wave q's transformed digit polynomial
-    i32 *acc;                // [2][1024], shared by the team
+    const cplx *xbuf_team;   // the team's 2 (K + 1) buffers, FFT_XBUF_ELEMS apart: wave q's transformed digit polynomial
+    i32 *acc;                // [K + 1][1024], shared by the team
     uint16_t *bara;          // [BR_MAX_LWE], shared
     const cplx *tw1;
     const cplx *tw2;
@@ -748,15 +748,18 @@ struct BrXfftQuadLds {
 #define BRXQ_LDS_ADD(p, v) ((void)(*(p) += (v)))
 #endif
 
-template <int W, bool SPLIT, class TeamSync>
+// tlwe_mask_size = K: NQ = 2 (K + 1) waves per bit ((K + 1) input polynomials x 2 digits = (K + 1) outputs x 2 key halves),
+// key rows [m][d][mo][half][reg][lane]; six terms per sum for K = 2 (error bound 0.055, see brxk_* above)
+template <int W, int K, bool SPLIT, class TeamSync>
 FF_FN void brxq_step(u32 a, const cplx *row, const BrXfftQuadLds &lds, const FftLane &L, TeamSync &&team_sync BR_PROBE_ARG)
 {
     BR_PROBE_BEGIN();
+    constexpr int NQ = 2 * (K + 1);
     constexpr int M = W >> 1, D = W & 1;          // forward side
     constexpr int MO = W >> 1, H = W & 1;         // product side
     const int lane = L.lane;
     // key[q][r] = BK_row[q >> 1][q & 1][MO][half H], register r of this lane
-    cplx key[4][8];
+    cplx key[NQ][8];
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef u32 brx_u32x4 __attribute__((ext_vector_type(4)));
     u32 voff = (u32)lane * (u32)sizeof(cplx);
@@ -765,8 +768,8 @@ FF_FN void brxq_step(u32 a, const cplx *row, const BrXfftQuadLds &lds, const Fft
     auto load_key = [&](int q) {
         // one descriptor per polynomial half (8 KiB): every offset is an instruction immediate, no scalar offset operand
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(row + (long)(q * 2 + MO) * BKX_POLY_ELEMS + H * BKF_POLY_ELEMS), (short)0, BKF_POLY_ELEMS * (int)sizeof(cplx),
-            0x00020000);
+            (void *)(row + (long)(q * (K + 1) + MO) * BKX_POLY_ELEMS + H * BKF_POLY_ELEMS), (short)0,
+            BKF_POLY_ELEMS * (int)sizeof(cplx), 0x00020000);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             union { brx_u32x4 w; cplx c; } u;
@@ -776,15 +779,15 @@ FF_FN void brxq_step(u32 a, const cplx *row, const BrXfftQuadLds &lds, const Fft
     };
 #else
     auto load_key = [&](int q) {
-        const cplx *p = row + (long)(q * 2 + MO) * BKX_POLY_ELEMS + H * BKF_POLY_ELEMS + lane;
+        const cplx *p = row + (long)(q * (K + 1) + MO) * BKX_POLY_ELEMS + H * BKF_POLY_ELEMS + lane;
 #pragma unroll
         for (int r = 0; r < 8; r++) key[q][r] = p[r * 64];
     };
 #endif
-    // The 32 KiB of key words a wave needs per step are requested in four pieces of 8 KiB: in front of the rotation,
+    // The 32 KiB of key words a wave needs per step (k = 1) are requested in four pieces of 8 KiB: in front of the rotation,
     // behind the two exchange writes of the forward transform, and behind the transform.  All at once in front of the
     // rotation the four waves of a team queue 128 KiB at the CU's one L2 port (64 bytes per clock) and the issue of
-    // the requests itself stalls for ~2 k cycles (tools/probe_xfft.py).
+    // the requests itself stalls for ~2 k cycles (tools/probe_xfft.py).  (k = 2: pieces 4 and 5 two products ahead.)
     load_key(0);
     BR_ISSUE_FENCE();
     cplx x[1][8];
@@ -813,19 +816,21 @@ FF_FN void brxq_step(u32 a, const cplx *row, const BrXfftQuadLds &lds, const Fft
     for (int r = 0; r < 8; r++) lds.xbuf[r * 64 + lane] = x[0][r];
     BR_ISSUE_FENCE();
     load_key(3);
-    team_sync();        // (1) the four transformed digit polynomials are visible; every wave has read ACC
+    team_sync();        // (1) the transformed digit polynomials are visible; every wave has read ACC
     BR_PROBE_MARK(2);
     cplx sum[1][8];
 #pragma unroll
     for (int r = 0; r < 8; r++) sum[0][r] = cplx{0.0, 0.0};
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < NQ; q++) {
+        if (q >= 1 && q + 3 < NQ) load_key(q + 3);      // (k = 2; behind the fence of product q - 1: key[q - 1] is dead)
         cplx xq[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) xq[r] = q == W ? x[0][r] : lds.xbuf_team[q * FFT_XBUF_ELEMS + r * 64 + lane];
+        for (int r = 0; r < 8; r++)     // (k = 2 re-reads its own transform: 32 registers less across the barrier)
+            xq[r] = (q == W && K == 1) ? x[0][r] : lds.xbuf_team[q * FFT_XBUF_ELEMS + r * 64 + lane];
 #pragma unroll
         for (int r = 0; r < 8; r++) c_fma_acc(sum[0][r], xq[r], key[q][r]);
-        BR_ISSUE_FENCE();       // (one polynomial's X words in flight at a time: left alone all 24 reads are hoisted, 96 registers)
+        BR_ISSUE_FENCE();       // (one polynomial's X words in flight at a time: left alone all reads are hoisted, 96+ registers)
 #if defined(__HIP_DEVICE_COMPILE__)
         // the products are finished HERE: left alone the scheduler sinks half of them below the barrier and keeps their
         // operands (key and X words) alive across it -- 50 registers spilled
@@ -850,12 +855,13 @@ FF_FN void brxq_step(u32 a, const cplx *row, const BrXfftQuadLds &lds, const Fft
     BR_PROBE_MARK(7);
 }
 
-template <int W, bool SPLIT, class TeamSync>
+template <int W, int K, bool SPLIT, class TeamSync>
 FF_FN void brxq_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSource &s1, i32 c0, long bit,
                           const cplx *bk, int n, i32 mu, const BrXfftQuadLds &lds, const FftLane &L, TeamSync &&team_sync)
 {
+    constexpr int THREADS = 64 * 2 * (K + 1);
     const int tid = 64 * W + L.lane;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += THREADS) {
         u32 v = 0;
         if (s0.p) v += (u32)s0.p * (u32)s0.a[bit * s0.a_stride + i];
         if (s1.p) v += (u32)s1.p * (u32)s1.a[bit * s1.a_stride + i];
@@ -865,10 +871,11 @@ FF_FN void brxq_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSo
     if (s0.p) vb += (u32)s0.p * (u32)s0.b[bit * s0.b_stride];
     if (s1.p) vb += (u32)s1.p * (u32)s1.b[bit * s1.b_stride];
     const u32 barb = br_modswitch(vb);
-    for (int j = tid; j < 1024; j += 256) {
+    for (int j = tid; j < 1024; j += THREADS) {
         const u32 t = ((u32)j + barb) & 2047u;
-        lds.acc[j] = 0;
-        lds.acc[1024 + j] = (t < 1024u) ? mu : (i32)(0u - (u32)mu);
+#pragma unroll
+        for (int m = 0; m < K; m++) lds.acc[m * 1024 + j] = 0;
+        lds.acc[K * 1024 + j] = (t < 1024u) ? mu : (i32)(0u - (u32)mu);
     }
     WAVE_SYNC();
     team_sync();
@@ -878,8 +885,8 @@ FF_FN void brxq_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSo
 #endif
     for (int i = 0; i < n; i++) {
         const u32 a = WAVE_UNIFORM((u32)lds.bara[i]);
-        if (a == 0) continue;        // (all four waves read the same word)
-        brxq_step<W, SPLIT>(a, bk + (long)i * BKX_ROW_ELEMS, lds, L, team_sync BR_PROBE_PASS);
+        if (a == 0) continue;        // (all waves of the team read the same word)
+        brxq_step<W, K, SPLIT>(a, bk + (long)i * BK_ROW_POLYS(K) * BKX_POLY_ELEMS, lds, L, team_sync BR_PROBE_PASS);
     }
 #if defined(BR_PROBE) && defined(__HIP_DEVICE_COMPILE__)
     if (L.lane == 0) {
@@ -890,11 +897,12 @@ FF_FN void brxq_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSo
     }
 #endif
     // sample extraction (tlwe_cpu.py:55-58)
-    for (int j = tid; j < 1024; j += 256) {
+    for (int j = tid; j < K * 1024; j += THREADS) {
+        const int m = j >> 10, jj = j & 1023;
         const u32 v = (u32)lds.acc[j];
-        out_a[(1024 - j) & 1023] = (i32)(j == 0 ? v : 0u - v);
+        out_a[m * 1024 + ((1024 - jj) & 1023)] = (i32)(jj == 0 ? v : 0u - v);
     }
-    if (tid == 0) *out_b = lds.acc[1024];
+    if (tid == 0) *out_b = lds.acc[K * 1024];
 }
 
 // Key preparation: one TGSW polynomial (int32 coefficients) -> its two balanced halves, each as the (a_j, -a_{j+512})

@@ -225,10 +225,45 @@ __global__ __launch_bounds__(ONE_TEAM ? 256 : 256 * BRXQ_MAX_TEAMS, 1) void k_bo
     const BrSource &s0 = P.job[job].s0, &s1 = P.job[job].s1;
     const i32 c0 = P.job[job].c0;
     switch (w) {
-    case 0: brxq_bootstrap<0, ONE_TEAM>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
-    case 1: brxq_bootstrap<1, ONE_TEAM>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
-    case 2: brxq_bootstrap<2, ONE_TEAM>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
-    default: brxq_bootstrap<3, ONE_TEAM>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    case 0: brxq_bootstrap<0, 1, ONE_TEAM>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    case 1: brxq_bootstrap<1, 1, ONE_TEAM>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    case 2: brxq_bootstrap<2, 1, ONE_TEAM>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    default: brxq_bootstrap<3, 1, ONE_TEAM>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    }
+}
+
+// tlwe_mask_size = 2, small batches: six waves per bit, the work-group is the team (batches up to 1 x CUs bits).
+// LDS: tables | pad | ACC 12 KiB, bara 1 KiB, 6 + 6 exchange buffers
+static constexpr size_t brxq2_lds_bytes() { return FTABLE_LDS_BYTES + BR_PACE_BYTES + BRX_BASE_PAD + 3 * 1024 * 4 + BR_MAX_LWE * 2 + 12 * WAVE_FXBUF_BYTES; }
+static_assert(brxq2_lds_bytes() <= 160 * 1024, "LDS budget of k_bootstrap_xfft_hex_k2");
+__global__ __launch_bounds__(384, 1) void k_bootstrap_xfft_hex_k2(BrLaunch P)
+{
+    load_ftables((const cplx *)P.tw_a, (const cplx *)P.tw_b);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const long gbit = (long)blockIdx.x;
+    const int job = gbit >= P.bits_per_job ? 1 : 0;
+    const long bit = gbit - (job ? P.bits_per_job : 0);
+    unsigned char *base = g_smem + FTABLE_LDS_BYTES + BR_PACE_BYTES + BRX_BASE_PAD;
+    BrXfftQuadLds lds;
+    lds.acc = (i32 *)base;
+    lds.bara = (uint16_t *)(base + 3 * 1024 * 4);
+    lds.xbuf_team = (const cplx *)(base + 3 * 1024 * 4 + BR_MAX_LWE * 2);
+    lds.xbuf = (cplx *)lds.xbuf_team + w * FFT_XBUF_ELEMS;
+    lds.xbuf_inv = lds.xbuf + 6 * FFT_XBUF_ELEMS;
+    lds.tw1 = (const cplx *)g_smem;
+    lds.tw2 = (const cplx *)g_smem + FFT_TW1_ELEMS;
+    auto team_sync = [] { __syncthreads(); };
+    const FftLane L = fft_lane_init(lane);
+    i32 *out_a = P.out_a + gbit * P.out_a_stride, *out_b = P.out_b + gbit * P.out_b_stride;
+    const BrSource &s0 = P.job[job].s0, &s1 = P.job[job].s1;
+    const i32 c0 = P.job[job].c0;
+    switch (w) {
+    case 0: brxq_bootstrap<0, 2, true>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    case 1: brxq_bootstrap<1, 2, true>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    case 2: brxq_bootstrap<2, 2, true>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    case 3: brxq_bootstrap<3, 2, true>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    case 4: brxq_bootstrap<4, 2, true>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    default: brxq_bootstrap<5, 2, true>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
     }
 }
 
@@ -274,6 +309,8 @@ hipError_t xfft_init()
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap_xfft_quad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)brxq_lds_bytes(1));
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_bootstrap_xfft_hex_k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)brxq2_lds_bytes());
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void *)k_blind_rotate_accum_xfft_k2, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)brx2_lds_bytes(BRX2_WAVES));
 }
@@ -290,6 +327,11 @@ hipError_t launch_bootstrap_xfft(const BrLaunch &P, int mask_size, int num_cus, 
         else
             hipLaunchKernelGGL(k_bootstrap_xfft_quad<false>, dim3(blocks_for(P.nbits_total, (int)teams)), dim3(256 * (unsigned)teams),
                                brxq_lds_bytes((int)teams), stream, P);
+        return hipGetLastError();
+    }
+    if (mask_size == 2 && quad_max_bits > 0 && P.nbits_total <= num_cus) {
+        // small batch, k = 2: six waves per bit, one bit per CU
+        hipLaunchKernelGGL(k_bootstrap_xfft_hex_k2, dim3((unsigned)P.nbits_total), dim3(384), brxq2_lds_bytes(), stream, P);
         return hipGetLastError();
     }
     if (mask_size == 2) {

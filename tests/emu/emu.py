@@ -267,3 +267,16 @@ def bootstrap_bit_xfft_quad(bkx, n, src0, p0, src1, p1, c0, mu, split=False):
                                       _p(a1, c_i32p), _p(b1, c_i32p), ctypes.c_int32(p1),
                                       ctypes.c_int32(c0), ctypes.c_int32(mu), ctypes.c_int(1 if split else 0))
     return out_a, out_b[0]
+
+
+def bootstrap_bit_xfft_hex_k2(bkx, n, src0, p0, src1, p1, c0, mu):
+    """tlwe_mask_size = 2, six waves per bit (brxq_* with K = 2): the same outputs as bootstrap_bit_xfft_k2"""
+    a0 = numpy.ascontiguousarray(src0[0], numpy.int32); b0 = numpy.ascontiguousarray(src0[1], numpy.int32).reshape(1)
+    a1 = numpy.ascontiguousarray(src1[0], numpy.int32); b1 = numpy.ascontiguousarray(src1[1], numpy.int32).reshape(1)
+    out_a = numpy.empty(2048, numpy.int32); out_b = numpy.empty(1, numpy.int32)
+    bkx = numpy.ascontiguousarray(bkx, numpy.complex128)
+    lib().emu_bootstrap_bit_xfft_hex_k2(_p(out_a, c_i32p), _p(out_b, c_i32p), _p(bkx.view(numpy.float64), c_f64p),
+                                        ctypes.c_int(n), _p(a0, c_i32p), _p(b0, c_i32p), ctypes.c_int32(p0),
+                                        _p(a1, c_i32p), _p(b1, c_i32p), ctypes.c_int32(p1),
+                                        ctypes.c_int32(c0), ctypes.c_int32(mu))
+    return out_a, out_b[0]

@@ -593,18 +593,44 @@ void emu_bootstrap_bit_xfft_quad(i32 *out_a, i32 *out_b, const double *bkx, int 
         FftLane L = fft_lane_init(lane);
         auto sync = [] { emu_team_sync(); };
         switch (w) {
-        case 0: if (split) brxq_bootstrap<0, true>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync);
-                else brxq_bootstrap<0, false>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync);
+        case 0: if (split) brxq_bootstrap<0, 1, true>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync);
+                else brxq_bootstrap<0, 1, false>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync);
                 break;
-        case 1: if (split) brxq_bootstrap<1, true>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync);
-                else brxq_bootstrap<1, false>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync);
+        case 1: if (split) brxq_bootstrap<1, 1, true>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync);
+                else brxq_bootstrap<1, 1, false>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync);
                 break;
-        case 2: if (split) brxq_bootstrap<2, true>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync);
-                else brxq_bootstrap<2, false>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync);
+        case 2: if (split) brxq_bootstrap<2, 1, true>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync);
+                else brxq_bootstrap<2, 1, false>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync);
                 break;
-        default: if (split) brxq_bootstrap<3, true>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync);
-                else brxq_bootstrap<3, false>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync);
+        default: if (split) brxq_bootstrap<3, 1, true>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync);
+                else brxq_bootstrap<3, 1, false>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync);
                 break;
+        }
+    });
+}
+
+// six waves per bit, tlwe_mask_size = 2 (brxq_* with K = 2): 384 fibres; out_a has 2048 entries
+void emu_bootstrap_bit_xfft_hex_k2(i32 *out_a, i32 *out_b, const double *bkx, int n,
+                                   const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,
+                                   i32 c0, i32 mu)
+{
+    ftables();
+    std::vector<cplx> xbuf(12 * FFT_XBUF_ELEMS);
+    std::vector<i32> accbuf(3 * 1024);
+    std::vector<uint16_t> bara(BR_MAX_LWE);
+    BrSource s0{a0, b0, 0, 0, p0}, s1{a1, b1, 0, 0, p1};
+    emu_run_team(6, [&](int w, int lane) {
+        BrXfftQuadLds lds{xbuf.data() + w * FFT_XBUF_ELEMS, xbuf.data() + (6 + w) * FFT_XBUF_ELEMS, xbuf.data(), accbuf.data(),
+                          bara.data(), g_ftw1, g_ftw2};
+        FftLane L = fft_lane_init(lane);
+        auto sync = [] { emu_team_sync(); };
+        switch (w) {
+        case 0: brxq_bootstrap<0, 2, true>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync); break;
+        case 1: brxq_bootstrap<1, 2, true>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync); break;
+        case 2: brxq_bootstrap<2, 2, true>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync); break;
+        case 3: brxq_bootstrap<3, 2, true>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync); break;
+        case 4: brxq_bootstrap<4, 2, true>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync); break;
+        default: brxq_bootstrap<5, 2, true>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bkx, n, mu, lds, L, sync); break;
         }
     });
 }

@@ -190,6 +190,9 @@ def test_mask_size_2_blind_rotation_reduced_key_equals_ntt_oracle(orc):
     ea, eb = orc.bootstrap_extract(bk_ntt, ta[None, :], tb, MU)
     ga, gb = emu.bootstrap_bit_xfft_k2(bkx, n, (a0, b0), 1, (a1, b1), 1, -MU, MU)
     assert (ga == ea[0]).all() and gb == eb[0]
+    # six waves per bit (brxq_* with K = 2): the same words
+    ha, hb = emu.bootstrap_bit_xfft_hex_k2(bkx, n, (a0, b0), 1, (a1, b1), 1, -MU, MU)
+    assert (ha == ea[0]).all() and hb == eb[0]
 
 
 def test_quad_kernel_body_equals_ntt_oracle_and_the_one_wave_body(orc):

@@ -341,6 +341,16 @@ def test_gpu_k2_exact_engine_gates_vs_reference_oracle_and_native(k2_env, thr, H
         pp = nufhe_amd.PerformanceParameters(params, single_kernel_bootstrap=False)
         vm2 = k2_env['ctx'].make_virtual_machine(key, perf_params=pp)
         assert all((g == e).all() for g, e in zip(H.ct_arrays(vm2.gate_xor(ds[0][:9], ds[1][:9])), ex))
+        # up to 1 x CUs bits: six waves per bit (k_bootstrap_xfft_hex_k2); the same gate with the team switch at 0 runs
+        # the one-wave kernel: equal on every word (the 37-bit gates above ran on the six-wave kernel)
+        from nufhe_amd import _lib
+        six = H.ct_arrays(vm.gate_mux(ds[0], ds[1], ds[2]))
+        try:
+            _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, 0)
+            one = H.ct_arrays(vm.gate_mux(ds[0], ds[1], ds[2]))
+        finally:
+            _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, -1)
+        assert all((x == y).all() for x, y in zip(six, one))
         Bl = 5 * cus - 3
         ml = [rng.uniform_bool((Bl,)).astype(bool) for _ in range(2)]
         dl = [H.ciphertext_from_arrays(thr, orc.encrypt(rng, lwe_key, m, k2_env['oparams']), params) for m in ml]
