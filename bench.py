@@ -679,6 +679,25 @@ def main():
                 "gates_per_s_per_gpu": B / dt, "correct": ok, "mux_ms_per_step_per_gpu": 1e3 * dtm,
                 "note": "same NTT key, same ciphertexts, the other engine of nufhe_cloudkey_set_engine; bit-identical "
                         "outputs by construction (include/nufhe_hip.h), checked under `parity`"}
+        if world == 1 and args.transform == "NTT" and B >= 256:
+            # small batches (one dependent gate of a circuit at a time: latency, not throughput): the first 1 / 256 bits of
+            # the same ciphertexts on both engines of the NTT key, 10 calls each
+            small = {}
+            for engine in ("native", "exact-fft"):
+                cloud_key.set_engine(engine)
+                try:
+                    for nb in (1, 256):
+                        a_s, b_s = cs[0][:nb], cs[1][:nb]
+                        dest_s = vm.empty_ciphertext((nb,))
+                        dts = measure(lambda: vm.gate_nand(a_s, b_s, dest=dest_s), nsteps=10)
+                        small["%s_%d_bits" % (engine.replace("-", "_"), nb)] = {
+                            "ms_per_gate_call": 1e3 * dts,
+                            "correct": bool((ctx.decrypt(secret_key, dest_s) == ~(ms[0][:nb] & ms[1][:nb])).all())}
+                finally:
+                    cloud_key.set_engine(args.engine)
+            small["note"] = ("NAND on the first 1 / 256 bits: native = 8 waves per bit on the u64 kernels (k_bootstrap_team8), "
+                             "exact-fft = 4 waves per bit (k_bootstrap_xfft_quad); identical output words")
+            other["small_batch_latency"] = small
         if world == 1:
             ctx_k = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(123), thread=thr)
             k2 = {}
