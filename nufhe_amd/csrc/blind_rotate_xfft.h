@@ -72,35 +72,14 @@ FF_FN u32 xfft_round_lo32(double v)
 // MAC of the two transformed digit polynomials (d = 0, 1) of input polynomial m against both halves of
 // BK_row[m][d][mo], mo = 0, 1: sum[h][mo][r] += x[d][r] * key[m][d][mo][h][r].  The 64 key loads of an m (1 KiB per load
 // and wave, consecutive in memory) are software-pipelined in groups as in brf_mac_pair.
-// BRX_SYNC: waves of a work-group that meet at a barrier in front of each multiply-accumulate phase request the same key
-// lines at the same time, so that the CU's vector L1 (32 KiB) serves all but the first of them: the key stream from L2
-// (64 bytes per clock and CU at best) is what the product phase waits for -- timing-only builds with half the key loads
-// run 18 % faster (profiles/r06_xfft_experiments.txt).  0: free-running waves; 1: s_barrier over the whole work-group.
-#ifndef BRX_SYNC
-#define BRX_SYNC 0
-#endif
-#if BRX_SYNC == 1 && defined(__HIP_DEVICE_COMPILE__)
-#define BRX_GROUP_SYNC() __builtin_amdgcn_s_barrier()
-#else
-#define BRX_GROUP_SYNC() ((void)0)
-#endif
-#if defined(BRX_MAC_PRIO) && defined(__HIP_DEVICE_COMPILE__)
-#define BRX_MAC_PRIO_BEGIN() __builtin_amdgcn_s_setprio(BRX_MAC_PRIO)
-#define BRX_MAC_PRIO_END() __builtin_amdgcn_s_setprio(1)
-#else
-#define BRX_MAC_PRIO_BEGIN() ((void)0)
-#define BRX_MAC_PRIO_END() ((void)0)
-#endif
-// BRX_FRESH_LANE: the ~27 lane-dependent LDS addresses of the exchanges are loop invariants that the compiler keeps in
-// registers across the product phases (and partly spills).  Re-deriving the lane record from an opaque copy of the lane
-// index in front of every transform group makes them phase-local: ~30 more integer instructions per group, ~25 registers
-// free while the key loads are in flight.
-#ifndef BRX_FRESH_LANE
-#define BRX_FRESH_LANE 1
-#endif
+
+// The ~27 lane-dependent LDS addresses of the exchanges are loop invariants that the compiler keeps in registers across
+// the product phases (and partly spills).  Re-deriving the lane record from an opaque copy of the lane index in front of
+// every transform group makes them phase-local: ~30 more integer instructions per group, ~25 registers free while the
+// key loads are in flight (256 VGPRs + 56 B scratch -> 252, none).
 FF_FN FftLane brx_fresh_lane(const FftLane &L)
 {
-#if BRX_FRESH_LANE && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
     int lane = L.lane;
     asm volatile("" : "+v"(lane));
     return fft_lane_init(lane);
@@ -114,12 +93,6 @@ FF_FN FftLane brx_fresh_lane(const FftLane &L)
 #ifndef BRX_PARK_AUX
 #define BRX_PARK_AUX 17      /* cache policy bits of the parking loads / stores (bit 0 sc0, bit 1 nt, bit 4 sc1): sc0 sc1 = past the
                                 vector L1, which the key stream owns (20.7 -> 19.3 ms) */
-#endif
-#ifndef BRX_PARK_LOAD
-#define BRX_PARK_LOAD 2      /* when the parked accumulator is requested: 0 behind the first inverse pair, 1 before the second, 2 behind it */
-#endif
-#ifndef BRX_ORDER
-#define BRX_ORDER 0      /* 0: schedule A (forward pair, MAC of both halves, twice; then the inverse pairs); 1: schedule B below */
 #endif
 #ifndef BRX_KEY_GROUP
 #define BRX_KEY_GROUP 2
@@ -146,19 +119,6 @@ FF_FN void brx_mac_pair(cplx (&sum)[2][2][8], const cplx (&x)[2][8], const cplx 
     const cplx *base = row + (long)m * 4 * BKX_POLY_ELEMS + lane;
     auto load = [&](int gi) { return base[gi * 64]; };
 #endif
-#if defined(BRX_ABLATE_HALF_LOADS)
-    // TIMING ONLY (wrong results): every second key load is replaced by the value of the one before it
-    auto load_real = load;
-    cplx last_ = cplx{1.0, 0.0};
-    auto load2 = [&](int gi) { if ((gi & 8) == 0) last_ = load_real(gi); return last_; };
-#define load load2
-#elif defined(BRX_ABLATE_NO_LOADS)
-    // TIMING ONLY (wrong results): no key loads at all, one load per MAC phase keeps the operand opaque
-    auto load_real = load;
-    cplx last_ = load_real(0);
-    auto load2 = [&](int gi) { return cplx{last_.re + (double)gi, last_.im}; };
-#define load load2
-#endif
     cplx q[D + 1][G];
 #pragma unroll
     for (int j = 0; j < D; j++)
@@ -184,79 +144,6 @@ FF_FN void brx_mac_pair(cplx (&sum)[2][2][8], const cplx (&x)[2][8], const cplx 
     }
 }
 
-// Schedule B (BRX_ORDER 1): both forward pairs first, then per key half: MAC of all four transformed digit polynomials
-// against that half of the row -> inverse pair -> round.  Live at the peak (the first inverse pair): the four transformed
-// polynomials (128 registers) + one pair of sums (64) + the transform's temporaries, against 4 pairs of sums (128) + a
-// forward pair in flight + T[1] of schedule A.
-//   sum[mo][r] += sum_{m,d} x[m][d][r] * key[m][d][mo][h][r]
-template <int D = BRX_KEY_DEPTH>
-FF_FN void brx_mac_half(cplx (&sum)[2][8], const cplx (&x)[2][2][8], const cplx *row, int h, int lane)
-{
-    constexpr int G = BRX_KEY_GROUP, NG = 64 / G;
-    // load index gi = ((m * 2 + d) * 2 + mo) * 8 + r  ->  element ((m * 4 + d * 2 + mo) * 2 + h) * 512 + r * 64 + lane
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef u32 brx_u32x4 __attribute__((ext_vector_type(4)));
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(row + (long)h * BKF_POLY_ELEMS), (short)0, (BKX_ROW_ELEMS - BKF_POLY_ELEMS) * (int)sizeof(cplx), 0x00020000);
-    const u32 voff = (u32)lane * (u32)sizeof(cplx);
-    auto load = [&](int gi) {
-        const int byte = ((gi >> 3) * BKX_POLY_ELEMS + (gi & 7) * 64) * (int)sizeof(cplx);
-        union { brx_u32x4 w; cplx c; } u;
-        u.w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + (u32)(byte & 4095), byte & ~4095, 0);
-        return u.c;
-    };
-#else
-    const cplx *base = row + (long)h * BKF_POLY_ELEMS + lane;
-    auto load = [&](int gi) { return base[(gi >> 3) * BKX_POLY_ELEMS + (gi & 7) * 64]; };
-#endif
-    cplx q[D + 1][G];
-#pragma unroll
-    for (int j = 0; j < D; j++)
-#pragma unroll
-        for (int i = 0; i < G; i++) q[j][i] = load(j * G + i);
-#pragma unroll
-    for (int g = 0; g < NG; g++) {
-        if (g + D < NG) {
-#pragma unroll
-            for (int i = 0; i < G; i++) q[D][i] = load((g + D) * G + i);
-            BR_ISSUE_FENCE();
-        }
-#pragma unroll
-        for (int i = 0; i < G; i++) {
-            const int gi = g * G + i;
-            const int r = gi & 7, mo = (gi >> 3) & 1, d = (gi >> 4) & 1, m = gi >> 5;
-            if (m == 0 && d == 0) {            // first term of this sum: no accumulator to add to
-                sum[mo][r].re = x[m][d][r].re * q[0][i].re;
-                sum[mo][r].re = fma(-x[m][d][r].im, q[0][i].im, sum[mo][r].re);
-                sum[mo][r].im = x[m][d][r].re * q[0][i].im;
-                sum[mo][r].im = fma(x[m][d][r].im, q[0][i].re, sum[mo][r].im);
-            } else
-                c_fma_acc(sum[mo][r], x[m][d][r], q[0][i]);
-        }
-#pragma unroll
-        for (int j = 0; j < D; j++)
-#pragma unroll
-            for (int i = 0; i < G; i++) q[j][i] = q[j + 1][i];
-    }
-}
-
-// x[m][d] = forward transform of digit d of T[m], all four
-template <class TW2>
-FF_FN void brx_forward_all(cplx (&x)[2][2][8], const u32 (&T)[2][16], const BrXfftLds &lds, const TW2 &tw2, const FftLane &L)
-{
-    cplx *const bufs[2] = {lds.xbufA, lds.xbufB};
-#pragma unroll
-    for (int m = 0; m < 2; m++) {
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            x[m][0][r] = cplx{(double)br_digit<0>(T[m][r]), -(double)br_digit<0>(T[m][r + 8])};   // a_j - i a_{j+512}
-            x[m][1][r] = cplx{(double)br_digit<1>(T[m][r]), -(double)br_digit<1>(T[m][r + 8])};
-        }
-        fft_forward_n<2>(x[m], bufs, lds.tw1, tw2, L);
-    }
-}
-
-#undef load
 // sum[h][mo][r] = (a_{lane + 64 r}, a_{lane + 64 r + 512}) BEFORE rounding of  sum_{m,d} digit_d(T_m) (*) K_h[m][d][mo]
 template <class TW2>
 FF_FN void brx_external_product_sums(cplx (&sum)[2][2][8], const u32 (&T)[2][16], const cplx *row, const BrXfftLds &lds,
@@ -279,10 +166,7 @@ FF_FN void brx_external_product_sums(cplx (&sum)[2][2][8], const u32 (&T)[2][16]
         }
         fft_forward_n<2>(x, bufs, lds.tw1, tw2, brx_fresh_lane(L));
         BR_PROBE_MARK(1 + 2 * m);
-        BRX_GROUP_SYNC();
-        BRX_MAC_PRIO_BEGIN();
         brx_mac_pair(sum, x, row, m, L.lane);
-        BRX_MAC_PRIO_END();
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("" ::: "memory");      // keep the key loads of the next polynomial below this point (register pressure)
 #endif
@@ -296,24 +180,6 @@ FF_FN void brx_external_product(u32 (&res)[2][16], const u32 (&T)[2][16], const 
                                 const TW2 &tw2, const FftLane &L)
 {
     cplx *const bufs[2] = {lds.xbufA, lds.xbufB};
-#if BRX_ORDER == 1
-    cplx x[2][2][8];
-    brx_forward_all(x, T, lds, tw2, L);
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        cplx sum[2][8];
-        brx_mac_half(sum, x, row, h, L.lane);
-        fft_inverse_2s<true>(sum, bufs, lds.tw1, tw2, L);
-#pragma unroll
-        for (int mo = 0; mo < 2; mo++)
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const u32 re = xfft_round_lo32(sum[mo][r].re), im = xfft_round_lo32(sum[mo][r].im);
-                res[mo][r] = h == 0 ? re : res[mo][r] + (re << 16);
-                res[mo][r + 8] = h == 0 ? im : res[mo][r + 8] + (im << 16);
-            }
-    }
-#else
     cplx sum[2][2][8];
 #if defined(BR_PROBE) && defined(__HIP_DEVICE_COMPILE__)
     BrProbe probe_ = {};
@@ -335,7 +201,6 @@ FF_FN void brx_external_product(u32 (&res)[2][16], const u32 (&T)[2][16], const 
             res[mo][r] += xfft_round_lo32(sum[1][mo][r].re) << 16;
             res[mo][r + 8] += xfft_round_lo32(sum[1][mo][r].im) << 16;
         }
-#endif
 }
 
 // the accumulator of this lane <-> its global parking slots: word (m, r) of lane l at park[((m * 16 + r) / 4) * 256 + l * 4 + r % 4]
@@ -349,7 +214,7 @@ struct alignas(16) brx_u4 {
 // them: a scratch reload in front of every other parking store / load, 3 k ticks per iteration.)  `park` MUST be wave-uniform.
 FF_FN void brx_park_store(u32 *park, const u32 (&acc)[2][16], int lane)
 {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(BRX_PARK_POINTERS)
+#if defined(__HIP_DEVICE_COMPILE__)
     typedef u32 brx_u32x4 __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)park, (short)0, 2048 * (int)sizeof(u32), 0x00020000);
     // offsets: the lane part in a register the compiler cannot see through (so that the constant part stays an
@@ -377,7 +242,7 @@ FF_FN void brx_park_store(u32 *park, const u32 (&acc)[2][16], int lane)
 
 FF_FN void brx_park_load(u32 (&acc)[2][16], const u32 *park, int lane)
 {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(BRX_PARK_POINTERS)
+#if defined(__HIP_DEVICE_COMPILE__)
     typedef u32 brx_u32x4 __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)park, (short)0, 2048 * (int)sizeof(u32), 0x00020000);
     u32 voff = (u32)lane * 16u;
@@ -445,52 +310,14 @@ FF_FN void brx_step(u32 (&acc)[2][16], u32 a, const cplx *row, const BrXfftLds &
     }
     WAVE_SYNC();    // every lane has read the mirror before buffer B is reused for exchanges
     brx_park_store(lds.park, acc, lane);
-#if BRX_ORDER == 1
-    cplx x[2][2][8];
-    brx_forward_all(x, T, lds, tw2, L);
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        cplx sum[2][8];
-        brx_mac_half(sum, x, row, h, lane);
-        fft_inverse_2s<true>(sum, bufs, lds.tw1, tw2, L);
-        if (h == 0) brx_park_load(acc, lds.park, lane);
-#pragma unroll
-        for (int mo = 0; mo < 2; mo++)
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                acc[mo][r] += xfft_round_lo32(sum[mo][r].re) << (16 * h);
-                acc[mo][r + 8] += xfft_round_lo32(sum[mo][r].im) << (16 * h);
-            }
-    }
-#else
     cplx sum[2][2][8];
     BR_PROBE_MARK(0);
     brx_external_product_sums(sum, T, row, lds, tw2, L BR_PROBE_PASS);
     const FftLane Li = brx_fresh_lane(L);
     fft_inverse_2s<true>(sum[0], bufs, lds.tw1, tw2, Li);
-#if BRX_PARK_LOAD == 0
-    // the parked accumulator comes back behind the first inverse pair and takes the rounded low halves at once
-    brx_park_load(acc, lds.park, lane);
-#pragma unroll
-    for (int mo = 0; mo < 2; mo++)
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            acc[mo][r] += xfft_round_lo32(sum[0][mo][r].re);
-            acc[mo][r + 8] += xfft_round_lo32(sum[0][mo][r].im);
-        }
-    BR_PROBE_MARK(5);
-    fft_inverse_2s<true>(sum[1], bufs, lds.tw1, tw2, L);
-    BR_PROBE_MARK(6);
-#pragma unroll
-    for (int mo = 0; mo < 2; mo++)
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            acc[mo][r] += xfft_round_lo32(sum[1][mo][r].re) << 16;
-            acc[mo][r + 8] += xfft_round_lo32(sum[1][mo][r].im) << 16;
-        }
-#else
-    // the rounded low halves wait in 32 registers; the parked accumulator is requested with the whole second inverse
-    // pair in front of its first use (1), or behind it (2)
+    // the rounded low halves wait in 32 registers; the parked accumulator is requested BEHIND the second inverse pair
+    // (requested earlier -- behind the first pair, in front of the second, or in front of its last pass, whole or half --
+    // the 32 words do not fit beside the transform: 56-192 B of scratch, 19.9-23.6 ms; profiles/r06_xfft_experiments.txt 4c, 11)
     u32 res[2][16];
 #pragma unroll
     for (int mo = 0; mo < 2; mo++)
@@ -499,16 +326,10 @@ FF_FN void brx_step(u32 (&acc)[2][16], u32 a, const cplx *row, const BrXfftLds &
             res[mo][r] = xfft_round_lo32(sum[0][mo][r].re);
             res[mo][r + 8] = xfft_round_lo32(sum[0][mo][r].im);
         }
-#if BRX_PARK_LOAD == 1
-    brx_park_load(acc, lds.park, lane);
-    BR_ISSUE_FENCE();
-#endif
     BR_PROBE_MARK(5);
     fft_inverse_2s<true>(sum[1], bufs, lds.tw1, tw2, Li);
     BR_PROBE_MARK(6);
-#if BRX_PARK_LOAD == 2
     brx_park_load(acc, lds.park, lane);
-#endif
 #pragma unroll
     for (int mo = 0; mo < 2; mo++)
 #pragma unroll
@@ -516,8 +337,6 @@ FF_FN void brx_step(u32 (&acc)[2][16], u32 a, const cplx *row, const BrXfftLds &
             acc[mo][r] += res[mo][r] + (xfft_round_lo32(sum[1][mo][r].re) << 16);
             acc[mo][r + 8] += res[mo][r + 8] + (xfft_round_lo32(sum[1][mo][r].im) << 16);
         }
-#endif
-#endif
 #pragma unroll
     for (int mo = 0; mo < 2; mo++)
 #pragma unroll
@@ -531,13 +350,6 @@ FF_FN void brx_blind_rotate(u32 (&acc)[2][16], const cplx *bk, int n, u32 barb, 
 {
     brx_init_acc(acc, barb, mu, lds, L.lane);
     const BrFftLds f = brx_as_fft_lds(lds);
-#if defined(BRX_TW2_REGS)
-    FftTw2Regs tw2r;
-    fft_tw2_load(tw2r, lds.tw2, L);
-#define BRX_TW2 tw2r
-#else
-#define BRX_TW2 lds.tw2
-#endif
 #if defined(BR_PROBE) && defined(__HIP_DEVICE_COMPILE__)
     BrProbe probe_ = {};
     const long long probe_w0 = clock64(), probe_r0 = wall_clock64();
@@ -545,14 +357,8 @@ FF_FN void brx_blind_rotate(u32 (&acc)[2][16], const cplx *bk, int n, u32 barb, 
     for (int i = 0; i < n; i++) {
         br_pace(lds.pace, (u32)i);
         const u32 a = WAVE_UNIFORM((u32)*brf_bara_slot(f, i));
-#if BRX_SYNC == 0
-        if (a == 0) continue;        // (with a group barrier inside the step every wave runs every step: X^0 - 1 = 0 adds nothing)
-#endif
-#if defined(BRX_ABLATE_ROW0)
-        brx_step(acc, a, bk + (long)(i & 3) * BKX_ROW_ELEMS, lds, lds.tw2, L BR_PROBE_PASS);      // TIMING ONLY: four hot rows
-#else
-        brx_step(acc, a, bk + (long)i * BKX_ROW_ELEMS, lds, BRX_TW2, L BR_PROBE_PASS);
-#endif
+        if (a == 0) continue;        // (X^0 - 1) ACC = 0: the external product adds nothing
+        brx_step(acc, a, bk + (long)i * BKX_ROW_ELEMS, lds, lds.tw2, L BR_PROBE_PASS);
     }
     br_pace_done(lds.pace);
 #if defined(BR_PROBE) && defined(__HIP_DEVICE_COMPILE__)

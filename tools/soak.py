@@ -25,12 +25,17 @@ def soak(ctx, vm, sk, B, reps, gate):
 
 def main():
     total = 0
-    for tr in ('NTT', 'FFT'):
+    # `python tools/soak.py exact-fft`: the NTT key on the exact-FFT engine only (team barriers through arrival words and
+    # s_barrier, LDS atomics into the accumulator, parked accumulators in global memory)
+    engine = sys.argv[1] if len(sys.argv) > 1 else None
+    for tr in (('NTT',) if engine else ('NTT', 'FFT')):
         ctx = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(5))
         sk, ck = ctx.make_key_pair(transform_type=tr)
+        if engine:
+            ck.set_engine(engine)
         vm = ctx.make_virtual_machine(ck)
-        print(tr)
-        for B, reps in ((4096, 60 if tr == 'NTT' else 200), (2500, 60), (1000, 100), (400, 150), (200, 300), (7, 300)):
+        print(tr, engine or '')
+        for B, reps in ((4096, 60 if tr == 'NTT' else 200), (2500, 60), (1000, 100), (400, 150), (200, 300), (7, 300)) + (((512, 150), (300, 150)) if engine else ()):
             total += soak(ctx, vm, sk, B, reps, 'nand')
         total += soak(ctx, vm, sk, 300, 100, 'mux')
     print("TOTAL differing runs:", total)
