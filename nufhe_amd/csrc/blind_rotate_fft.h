@@ -919,3 +919,160 @@ FF_FN void brfr_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSo
     }
     if (tid == 0) *out_b = lds.acc[K * 1024];
 }
+
+// ------------------------------------------------------------------------------------------
+// Quad variant of the FFT path (k = 1, batches up to 1 x CUs bits: the latency case), the counterpart of brxq_* in
+// blind_rotate_xfft.h: FOUR wavefronts per bit, the work-group is the team (s_barrier).
+//   forward side : wave w = 2 m + d transforms digit d of (X^a - 1) ACC_m and leaves it in its first exchange buffer
+//   product side : wave w = 2 mo + p sums  X_q (.) BK_row[q >> 1][q & 1][mo]  over q = 2 p, 2 p + 1;  the waves p = 1 hand
+//                  their partial sums over through their second buffer, the waves p = 0 add them, transform back, round and
+//                  update ACC_mo (which only they write)
+// fp64 sums as (q0 + q1) + (q2 + q3): another association than the one-wave kernel's running sum -- covered by the
+// path's stated tolerance, identical after rounding on every tested input (as brfp_*, brfr_*).
+// Key words: 16 per wave and step, requested in front of the rotation and behind the first exchange write of the forward
+// transform.  Three barriers per step: X visible | partial sums visible | ACC complete.
+// ------------------------------------------------------------------------------------------
+struct BrFftQuadLds {
+    cplx *xbuf;              // this wave's exchange buffer of the forward transform; then its transformed digit polynomial
+    cplx *xbuf_inv;          // its second buffer: p = 1: the partial sum it hands over; p = 0: exchanges of the inverse transform
+    const cplx *xbuf_team;   // the team's four first buffers, FFT_XBUF_ELEMS apart
+    const cplx *partner_inv; // second buffer of wave w ^ 1
+    i32 *acc;                // [2][1024], shared by the team
+    uint16_t *bara;          // [BR_MAX_LWE], shared
+    const cplx *tw1;
+    const cplx *tw2;
+};
+
+template <int W, class TeamSync>
+FF_FN void brfq_step(u32 a, const cplx *row, const BrFftQuadLds &lds, const FftLane &L, TeamSync &&team_sync)
+{
+    constexpr int M = W >> 1, D = W & 1;          // forward side
+    constexpr int MO = W >> 1, P = W & 1;         // product side
+    const int lane = L.lane;
+    cplx key[2][8];                               // key[i][r] = BK_row[q >> 1][q & 1][MO], q = 2 P + i
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef u32 brf_u32x4 __attribute__((ext_vector_type(4)));
+    u32 voff = (u32)lane * (u32)sizeof(cplx);
+    asm volatile("" : "+v"(voff));
+    const u32 voff_hi = voff + 4096u;
+    auto load_key = [&](int i) {
+        // one descriptor per polynomial (8 KiB): every offset is an instruction immediate, no scalar offset operand
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(row + (long)((2 * P + i) * 2 + MO) * BKF_POLY_ELEMS), (short)0, BKF_POLY_ELEMS * (int)sizeof(cplx), 0x00020000);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            union { brf_u32x4 w; cplx c; } u;
+            u.w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (r < 4 ? voff : voff_hi) + (u32)((r & 3) * 1024), 0, 0);
+            key[i][r] = u.c;
+        }
+    };
+#else
+    auto load_key = [&](int i) {
+        const cplx *p = row + (long)((2 * P + i) * 2 + MO) * BKF_POLY_ELEMS + lane;
+#pragma unroll
+        for (int r = 0; r < 8; r++) key[i][r] = p[r * 64];
+    };
+#endif
+    load_key(0);
+    BR_ISSUE_FENCE();
+    cplx x[1][8];
+    {
+        u32 T[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const u32 j = (u32)(lane + 64 * r);
+            const u32 t = (j - a) & 2047u;
+            const u32 v = (u32)lds.acc[M * 1024 + (t & 1023u)];
+            T[r] = ((t & 1024u) ? 0u - v : v) - (u32)lds.acc[M * 1024 + j];     // (X^a - 1) ACC_M, polynomials_cpu.py:46-58
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) x[0][r] = cplx{(double)br_digit<D>(T[r]), -(double)br_digit<D>(T[r + 8])};   // a_j - i a_{j+512}
+    }
+    cplx *const buf1[1] = {lds.xbuf};
+    fft_forward_n<1>(x, buf1, lds.tw1, lds.tw2, L, [&](int stage) {
+        if (stage == 0) {
+            BR_ISSUE_FENCE();       // (fences on both sides: the requests stay where they are written)
+            load_key(1);
+            BR_ISSUE_FENCE();
+        }
+    });
+    WAVE_SYNC();        // every lane is done with the exchange buffer
+#pragma unroll
+    for (int r = 0; r < 8; r++) lds.xbuf[r * 64 + lane] = x[0][r];
+    team_sync();        // (1) the four transformed digit polynomials are visible; every wave has read ACC
+    cplx sum[1][8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) sum[0][r] = cplx{0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        constexpr int Q0 = 2 * P;
+        cplx xq[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) xq[r] = (Q0 + i == W) ? x[0][r] : lds.xbuf_team[(Q0 + i) * FFT_XBUF_ELEMS + r * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 8; r++) c_fma_acc(sum[0][r], xq[r], key[i][r]);
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the products are finished HERE (cf. brxq_step: left alone the scheduler sinks them below the barrier)
+#pragma unroll
+        for (int r = 0; r < 8; r++) asm volatile("" : "+v"(sum[0][r].re), "+v"(sum[0][r].im));
+#endif
+    }
+    if (P == 1) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) lds.xbuf_inv[r * 64 + lane] = sum[0][r];
+        team_sync();    // (2) partial sums visible
+        team_sync();    // (3) ACC complete
+        return;
+    }
+    team_sync();        // (2)
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const cplx o = lds.partner_inv[r * 64 + lane];
+        sum[0][r].re += o.re;
+        sum[0][r].im += o.im;
+    }
+    WAVE_SYNC();
+    cplx *const buf2[1] = {lds.xbuf_inv};
+    fft_inverse_n<1>(sum, buf2, lds.tw1, lds.tw2, L);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        lds.acc[MO * 1024 + lane + 64 * r] += (i32)fft_round_to_u32(sum[0][r].re);
+        lds.acc[MO * 1024 + lane + 64 * (r + 8)] += (i32)fft_round_to_u32(-sum[0][r].im);
+    }
+    team_sync();        // (3)
+}
+
+template <int W, class TeamSync>
+FF_FN void brfq_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSource &s1, i32 c0, long bit,
+                          const cplx *bk, int n, i32 mu, const BrFftQuadLds &lds, const FftLane &L, TeamSync &&team_sync)
+{
+    const int tid = 64 * W + L.lane;
+    for (int i = tid; i < n; i += 256) {
+        u32 v = 0;
+        if (s0.p) v += (u32)s0.p * (u32)s0.a[bit * s0.a_stride + i];
+        if (s1.p) v += (u32)s1.p * (u32)s1.a[bit * s1.a_stride + i];
+        lds.bara[i] = (uint16_t)br_modswitch(v);
+    }
+    u32 vb = (u32)c0;
+    if (s0.p) vb += (u32)s0.p * (u32)s0.b[bit * s0.b_stride];
+    if (s1.p) vb += (u32)s1.p * (u32)s1.b[bit * s1.b_stride];
+    const u32 barb = br_modswitch(vb);
+    for (int j = tid; j < 1024; j += 256) {
+        const u32 t = ((u32)j + barb) & 2047u;
+        lds.acc[j] = 0;
+        lds.acc[1024 + j] = (t < 1024u) ? mu : (i32)(0u - (u32)mu);
+    }
+    WAVE_SYNC();
+    team_sync();
+    for (int i = 0; i < n; i++) {
+        const u32 a = WAVE_UNIFORM((u32)lds.bara[i]);
+        if (a == 0) continue;        // (all four waves read the same word)
+        brfq_step<W>(a, bk + (long)i * BKF_ROW_ELEMS, lds, L, team_sync);
+    }
+    // sample extraction (tlwe_cpu.py:55-58)
+    for (int j = tid; j < 1024; j += 256) {
+        const u32 v = (u32)lds.acc[j];
+        out_a[(1024 - j) & 1023] = (i32)(j == 0 ? v : 0u - v);
+    }
+    if (tid == 0) *out_b = lds.acc[1024];
+}

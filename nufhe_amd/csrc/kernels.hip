@@ -1456,6 +1456,10 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, con
             const int w = br_pick_waves(P.nbits_total, BR_WAVES_K(2), num_cus);
             hipLaunchKernelGGL(k_bootstrap<2>, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), br_lds_bytes(2, w), stream, P);
         }
+    } else if (transform == 1 && mask_size == 1 && pair_max_bits > 0 && T.team_max_bits_fft > 0 && P.nbits_total <= num_cus) {
+        // latency case, FFT: four waves per bit, one bit per CU (1.9 ms against 2.7 ms of the pair kernel); both the pair and
+        // the team switch at 0 turn it off
+        return launch_bootstrap_fft_quad(P, stream);
     } else if (transform == 1 && mask_size == 1 && pair_max_bits > 0 && P.nbits_total <= pair_max_bits) {
         // small and medium batches, FFT: 2 waves per bit, 1 to 3 pairs per work-group (ahead of the 4-wave team kernel at
         // every size: 2.9 vs 3.0 ms up to 1 x CUs bits, 3.1 ms up to 2 x CUs, 3.7 ms up to 3 x CUs); any non-zero pair

@@ -148,13 +148,15 @@ def bkf_from_reference(bk):
     return out
 
 
-def bootstrap_bit_fft(bk_internal, n, src0, p0, src1, p1, c0, mu, team=False, mask_size=1, pair=False, ring=False):
+def bootstrap_bit_fft(bk_internal, n, src0, p0, src1, p1, c0, mu, team=False, mask_size=1, pair=False, ring=False, quad=False):
     a0 = numpy.ascontiguousarray(src0[0], numpy.int32); b0 = numpy.ascontiguousarray(src0[1], numpy.int32).reshape(1)
     a1 = numpy.ascontiguousarray(src1[0], numpy.int32); b1 = numpy.ascontiguousarray(src1[1], numpy.int32).reshape(1)
     out_a = numpy.empty(1024 * mask_size, numpy.int32); out_b = numpy.empty(1, numpy.int32)
     fn = lib().emu_bootstrap_bit_fft_team if team else lib().emu_bootstrap_bit_fft
     if pair:
         fn = lib().emu_bootstrap_bit_fft_pair
+    if quad:
+        fn = lib().emu_bootstrap_bit_fft_quad
     if mask_size == 2:
         fn = lib().emu_bootstrap_bit_fft_team_k2 if team else lib().emu_bootstrap_bit_fft_k2
         if ring:

@@ -635,4 +635,28 @@ void emu_bootstrap_bit_xfft_hex_k2(i32 *out_a, i32 *out_b, const double *bkx, in
     });
 }
 
+// the 4-wave quad variant of the FFT body (brfq_*): 256 fibres, two exchange buffers per wave
+void emu_bootstrap_bit_fft_quad(i32 *out_a, i32 *out_b, const double *bk_internal, int n,
+                                const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,
+                                i32 c0, i32 mu)
+{
+    ftables();
+    std::vector<cplx> xbuf(8 * FFT_XBUF_ELEMS);
+    std::vector<i32> accbuf(2 * 1024);
+    std::vector<uint16_t> bara(BR_MAX_LWE);
+    BrSource s0{a0, b0, 0, 0, p0}, s1{a1, b1, 0, 0, p1};
+    emu_run_team(4, [&](int w, int lane) {
+        BrFftQuadLds lds{xbuf.data() + w * FFT_XBUF_ELEMS, xbuf.data() + (4 + w) * FFT_XBUF_ELEMS, xbuf.data(),
+                         xbuf.data() + (4 + (w ^ 1)) * FFT_XBUF_ELEMS, accbuf.data(), bara.data(), g_ftw1, g_ftw2};
+        FftLane L = fft_lane_init(lane);
+        auto sync = [] { emu_team_sync(); };
+        switch (w) {
+        case 0: brfq_bootstrap<0>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bk_internal, n, mu, lds, L, sync); break;
+        case 1: brfq_bootstrap<1>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bk_internal, n, mu, lds, L, sync); break;
+        case 2: brfq_bootstrap<2>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bk_internal, n, mu, lds, L, sync); break;
+        default: brfq_bootstrap<3>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bk_internal, n, mu, lds, L, sync); break;
+        }
+    });
+}
+
 }  // extern "C"

@@ -210,7 +210,7 @@ def test_bootstrap_wave_body_fft_full_key(orc, oracle_keys):
 
 
 def test_bootstrap_fft_bodies_reduced_key(orc):
-    """The three FFT bodies for k = 1 (one wave per bit, the 4-wave team, the 2-wave pair) on a reduced number of rows of
+    """The four FFT bodies for k = 1 (one wave per bit, the 4-wave team, the 2-wave pair, the 4-wave quad) on a reduced number of rows of
     a full-range int32 TGSW key == the EXACT (NTT) oracle on the same key (their fp64 sums associate differently; all of
     them round to the exact integers)."""
     from oracle import oracle_fft as of
@@ -227,7 +227,7 @@ def test_bootstrap_fft_bodies_reduced_key(orc):
     b1 = rs.randint(-2**31, 2**31, size=1, dtype=numpy.int32)
     ta = (a0 + a1).astype(numpy.int32); tb = (numpy.int32(-MU) + b0 + b1).astype(numpy.int32)
     ea, eb = orc.bootstrap_extract(bk_ntt, ta[None, :], tb, MU)
-    for kw in ({}, {'team': True}, {'pair': True}):
+    for kw in ({}, {'team': True}, {'pair': True}, {'quad': True}):
         ga, gb = emu.bootstrap_bit_fft(bkf, n, (a0, b0), 1, (a1, b1), 1, -MU, MU, **kw)
         assert (ga == ea[0]).all() and gb == eb[0], kw
 

@@ -320,9 +320,10 @@ def test_config5_fft_context_end_to_end_4096(thr):
 
 
 def test_fft_small_batch_team_kernel(fft_env, thr, H, orc):
-    """The three FFT kernels on a small batch -- one wave per bit, the 4-wave team (taken when the pair kernel is
-    switched off), the 2-wave pair (default) -- vs the exact (NTT) oracle: within the path's tolerance; observed:
-    identical words."""
+    """The four FFT kernels on a small batch -- one wave per bit, the 4-wave team (taken when the pair kernel is
+    switched off), the 2-wave pair (team switch at 0), the 4-wave quad (default up to 1 x CUs bits: k_bootstrap_fft_quad, the
+    MUX = 140 rotations puts its job boundary inside the launch) -- vs the exact (NTT) oracle: within the path's tolerance;
+    observed: identical words."""
     from nufhe_amd import _lib
     vm = fft_env['vm']; ck = fft_env['ck']; lwe_key = fft_env['lwe_key']
     rng = orc.DeterministicRNG(31337)
@@ -333,8 +334,8 @@ def test_fft_small_batch_team_kernel(fft_env, thr, H, orc):
     exp = {'nand': orc.gate('gate_nand', ck, cs[0], cs[1]), 'mux': orc.gate_mux(ck, cs[0], cs[1], cs[2])}
     got = {}
     try:
-        # (team limit, pair limit): wave-per-bit kernel; team kernel; default switches = pair kernel
-        for limit in ((0, 0), (-1, 0), (-1, -1)):
+        # (team limit, pair limit): wave-per-bit kernel; team kernel; pair kernel; default switches = quad kernel
+        for limit in ((0, 0), (-1, 0), (0, -1), (-1, -1)):
             _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, limit[0])
             _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, limit[1])
             got[limit] = {'nand': H.ct_arrays(vm.gate_nand(ds[0], ds[1])), 'mux': H.ct_arrays(vm.gate_mux(ds[0], ds[1], ds[2]))}
@@ -342,14 +343,14 @@ def test_fft_small_batch_team_kernel(fft_env, thr, H, orc):
         _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, -1)
         _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, -1)
     for name in ('nand', 'mux'):
-        for limit in ((0, 0), (-1, 0), (-1, -1)):
+        for limit in ((0, 0), (-1, 0), (0, -1), (-1, -1)):
             ra, rb, rcv = got[limit][name]
             da = (ra.astype(numpy.int64) - exp[name][0].astype(numpy.int64) + 2**31) % 2**32 - 2**31
             db = (rb.astype(numpy.int64) - exp[name][1].astype(numpy.int64) + 2**31) % 2**32 - 2**31
             assert numpy.abs(da).max() <= FFT_TOLERANCE_LSB and numpy.abs(db).max() <= FFT_TOLERANCE_LSB, (name, limit)
             assert (rcv == exp[name][2]).all()
-        same = all((x == y).all() for k in ((-1, 0), (-1, -1)) for x, y in zip(got[(0, 0)][name], got[k][name]))
-        print("FFT %s: team and pair kernels == wave kernel: %s; words differing from the exact path: %d" % (
+        same = all((x == y).all() for k in ((-1, 0), (0, -1), (-1, -1)) for x, y in zip(got[(0, 0)][name], got[k][name]))
+        print("FFT %s: team, pair and quad kernels == wave kernel: %s; words differing from the exact path: %d" % (
             name, same, int((got[(-1, -1)][name][0] != exp[name][0]).sum())))
 
 
