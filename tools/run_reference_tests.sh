@@ -4,6 +4,8 @@
 # shipped to the GPU box by gpurun) beside tests/reference_suite/conftest.py and records their hashes.  Step 2 (on the GPU
 # box): `tools/run_reference_tests.sh run` executes them and writes gpurun_out/r06_reference_tests_unmodified.log.
 #   tools/run_reference_tests.sh stage && gpurun --timeout 1800 -- 'tools/run_reference_tests.sh run'
+# `NUFHE_NTT_ENGINE=exact-fft tools/run_reference_tests.sh run exact_fft`: the same files with every NTT key on the exact-FFT
+# engine (log ..._unmodified_exact_fft.log).
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 DIR="$ROOT/tools/scratch/reftests"
 FILES="test_api_high_level.py test_api_low_level.py test_gates.py utils.py"
@@ -15,11 +17,12 @@ if [ "$1" = "stage" ]; then
     exit 0
 fi
 mkdir -p "$ROOT/gpurun_out"
-LOG="$ROOT/gpurun_out/r06_reference_tests_unmodified.log"
+LOG="$ROOT/gpurun_out/r06_reference_tests_unmodified${2:+_$2}.log"
 cd "$DIR" || exit 1
 {
     echo "== the reference's test files, unmodified (sha256 below; staged from /root/reference/test by tools/run_reference_tests.sh),"
     echo "== run with PYTHONPATH=<repo root>: 'import nufhe' is the alias package nufhe -> nufhe_amd; conftest = tests/reference_suite/conftest.py"
+    echo "== NUFHE_NTT_ENGINE=${NUFHE_NTT_ENGINE:-native} (engine of every NTT key: native u64 kernels | exact-fft)"
     sha256sum -c SHA256SUMS
     cat SHA256SUMS
     export PYTHONPATH="$ROOT:$DIR"
