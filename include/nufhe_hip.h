@@ -300,6 +300,8 @@ int nufhe_tlwe_encrypt_zero(nufhe_ctx *ctx, int32_t *d_result_a, const int32_t *
  * bit per CU at a time), larger batches the throughput kernel (one wavefront per bit).  bits < 0 restores the
  * defaults (in ciphertext bits: the CU count); 0 disables the
  * small-batch kernels.  Results are bit-identical either way (FFT: identical on every tested input).
+ * The same switch (zero / non-zero) governs the four- / six-wavefronts-per-bit kernels of the fp64 paths: exact-FFT engine
+ * up to 2 x CUs bits (k = 2: 1 x CUs), FFT keys up to 1 x CUs bits (the latter only while the pair switch below is on).
  * No reference counterpart (the reference always splits a bit over 512+ threads, blind_rotate.py:89-187). */
 int nufhe_ctx_set_team_max_bits(nufhe_ctx *ctx, long bits);
 /* k = 1 only.  NTT: batches above the small-batch limit and up to `bits` run the medium-batch kernel (2 wavefronts
