@@ -93,3 +93,38 @@ def test_captured_uint_min(side_stream_env):
         assert (bitarray_to_uintarray(ctx.decrypt(secret, replayed)) == numpy.minimum(xs[2], xs[3])).all()
         uint_min(thr, cloud, answer, a, b)
         assert answer == replayed
+
+
+def test_captured_chain_on_the_exact_engine(side_stream_env):
+    """The same kind of circuit with the NTT key on the exact-FFT engine (the split key image and the parking buffer exist
+    after the eager run): the capture holds the quad kernel (3 bits) / the one-wave kernel with its parked accumulators
+    (600 bits) and replays to the eager words, also for new inputs written in place."""
+    import torch
+    import nufhe_amd as nufhe
+    e = side_stream_env
+    ctx, secret, stream = e['ctx'], e['secret'], e['stream']
+    rs = numpy.random.RandomState(7)
+    with torch.cuda.stream(stream):
+        secret2, cloud = ctx.make_key_pair()
+        cloud.set_engine('exact-fft')
+        vm = ctx.make_virtual_machine(cloud)
+        for B in (3, 600):
+            ms = [rs.randint(0, 2, B).astype(bool) for _ in range(3)]
+            cs = [ctx.encrypt(secret2, m) for m in ms]
+
+            def circuit():
+                t = vm.gate_nand(cs[0], cs[1])
+                return vm.gate_mux(t, cs[2], cs[0])
+            eager = circuit()                                   # (builds the image / sizes the parking buffer)
+            g = nufhe.GateGraph(e['thr'])
+            out = g.capture(circuit)
+            g.replay()
+            assert out == eager
+            ms2 = [rs.randint(0, 2, B).astype(bool) for _ in range(3)]
+            for c, m in zip(cs, ms2):
+                c[...] = ctx.encrypt(secret2, m)
+            expect = circuit()
+            g.replay()
+            assert out == expect
+            assert (ctx.decrypt(secret2, out) == numpy.where(~(ms2[0] & ms2[1]), ms2[2], ms2[0])).all()
+            g.close()

@@ -192,6 +192,27 @@ def test_quad_kernel_equals_wave_kernel_and_oracle(env, H, thr, orc):
     assert (ctx.decrypt(sk, vm.gate_nand(cs[0], cs[1])) == ~(ms[0] & ms[1])).all()
 
 
+def test_exact_engine_switch_points_plus_minus_one_bit(env, H):
+    """the exact engine's dispatch: one quad team per work-group up to 1 x CUs rotations, two up to 2 x CUs, then one
+    wave per bit; tlwe_mask_size = 1.  NAND at each switch point and one bit beyond == the native engine, every word."""
+    import torch
+    vm = env['vm']; ctx = env['ctx']; sk = env['secret_key']; key = env['cloud_key']
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    rng = numpy.random.RandomState(99)
+    B = 2 * cus + 1
+    ms = [rng.randint(0, 2, size=(B,)).astype(bool) for _ in range(2)]
+    cs = [ctx.encrypt(sk, m) for m in ms]
+    try:
+        key.set_engine('native')
+        ref = H.ct_arrays(vm.gate_nand(cs[0], cs[1]))
+        key.set_engine('exact-fft')
+        for size in (cus, cus + 1, 2 * cus, 2 * cus + 1):
+            got = H.ct_arrays(vm.gate_nand(cs[0][:size], cs[1][:size]))
+            assert all((g == r[:size]).all() for g, r in zip(got, ref)), size
+    finally:
+        key.set_engine('exact-fft')
+
+
 def test_gate_batch_and_stepwise_driver_on_the_exact_engine(env, H, orc):
     import nufhe_amd
     vm = env['vm']; ctx = env['ctx']; sk = env['secret_key']; ck = env['ck']
