@@ -21,6 +21,8 @@ from nufhe_amd.operators_integer import uint_min, uint_min_many, uintarray_to_bi
 
 ctx = nufhe.Context(rng=nufhe.DeterministicRNG(123))
 secret, cloud = ctx.make_key_pair()
+if len(sys.argv) > 1:
+    cloud.set_engine(sys.argv[1])          # `python tools/circuit_batch.py exact-fft`
 vm = ctx.make_virtual_machine(cloud)
 thr = ctx.thread
 rs = numpy.random.RandomState(7)

@@ -13,6 +13,8 @@ with torch.cuda.stream(stream):
     thr = DeviceThread(0)
     ctx = nufhe.Context(rng=nufhe.DeterministicRNG(43), thread=thr)
     secret, cloud = ctx.make_key_pair()
+    engine = sys.argv[1] if len(sys.argv) > 1 else 'native'       # `python tools/graph_batch_timing.py exact-fft`
+    cloud.set_engine(engine)
     C, M, W = 4, 4, 16
     ca = [ctx.encrypt(secret, uintarray_to_bitarray(rs.randint(0, 2**W, M).astype(numpy.uint16))) for _ in range(C)]
     cb = [ctx.encrypt(secret, uintarray_to_bitarray(rs.randint(0, 2**W, M).astype(numpy.uint16))) for _ in range(C)]
@@ -30,4 +32,4 @@ with torch.cuda.stream(stream):
     g = nufhe.GateGraph(thr)
     g.capture(circuit)
     replay = timed(g.replay)
-    print(json.dumps({"four_uint_min_4x16_lock_step": {"eager_ms": eager, "one_graph_replay_ms": replay, "batches": W + 2}}))
+    print(json.dumps({"engine": engine, "four_uint_min_4x16_lock_step": {"eager_ms": eager, "one_graph_replay_ms": replay, "batches": W + 2}}))
