@@ -1399,7 +1399,15 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, con
     if (transform == BR_TRANSFORM_XFFT) {
         if (mask_size == 1 && !P.park) return hipErrorInvalidValue;
         // exact engine: four waves per bit up to BRX_QUAD_CUS x CUs bits (the team switch at 0 turns it off), then one wave per bit
-        return launch_bootstrap_xfft(P, mask_size, num_cus, T.team_max_bits > 0 ? (long)BRX_QUAD_CUS * num_cus : 0, stream);
+        const long quad_max = T.team_max_bits > 0 ? (long)BRX_QUAD_CUS * num_cus : 0;
+        if (mask_size == 1 && quad_max > 0 && P.nbits_total > quad_max && P.nbits_total <= 2 * quad_max) {
+            // up to twice that: two rounds of the quad kernel (3.3 ms + 2.0 ... 3.3 ms) are ahead of one round of lone
+            // waves on the one-wave kernel (7.2 ms)
+            hipError_t e = launch_bootstrap_xfft(br_sub_launch(P, 0, quad_max), mask_size, num_cus, quad_max, stream);
+            if (e != hipSuccess) return e;
+            return launch_bootstrap_xfft(br_sub_launch(P, quad_max, P.nbits_total), mask_size, num_cus, quad_max, stream);
+        }
+        return launch_bootstrap_xfft(P, mask_size, num_cus, quad_max, stream);
     }
     const long team_max_bits = transform == 0 ? T.team_max_bits : 2 * T.team_max_bits_fft;    // (FFT: halved again below)
     const long pair_max_bits = transform == 0 ? (mask_size == 1 ? T.pair_max_bits_ntt : (long)T.ring_k2)
