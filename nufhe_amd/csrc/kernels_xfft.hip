@@ -370,8 +370,10 @@ hipError_t launch_bootstrap_xfft(const BrLaunch &P, int mask_size, int num_cus, 
                                brxq_lds_bytes((int)teams), stream, P);
         return hipGetLastError();
     }
-    if (mask_size == 2 && quad_max_bits > 0 && P.nbits_total <= num_cus) {
-        // small batch, k = 2: six waves per bit, one bit per CU
+    // k = 2: six waves per bit, one bit per CU at a time (rounds of 1 x CUs bits in 3.45 ms), or one wave per bit (rounds of
+    // 4 x CUs bits in 12.9 ms): whichever needs less time for this batch (measured: 3.06 ms per further round, ratio 0.24)
+    const long hex_rounds = (P.nbits_total + num_cus - 1) / num_cus, wave_rounds = (P.nbits_total + 4L * num_cus - 1) / (4L * num_cus);
+    if (mask_size == 2 && quad_max_bits > 0 && 240 * hex_rounds < 1000 * wave_rounds) {
         hipLaunchKernelGGL(k_bootstrap_xfft_hex_k2, dim3((unsigned)P.nbits_total), dim3(384), brxq2_lds_bytes(), stream, P);
         return hipGetLastError();
     }

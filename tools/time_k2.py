@@ -24,7 +24,7 @@ for tr, ring in runs:
         ck.set_engine('exact-fft')
         print('engine exact-fft')
     vm = ctx.make_virtual_machine(ck)
-    for B in (32, 256, 512, 1024, 1536, 4096):
+    for B in (32, 256, 512, 768, 1024, 1536, 2048, 3000, 4096):
         m = numpy.random.RandomState(1).randint(0, 2, size=B).astype(bool)
         c1 = ctx.encrypt(sk, m); c2 = ctx.encrypt(sk, ~m)
         r = vm.gate_nand(c1, c2); torch.cuda.synchronize()
