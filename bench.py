@@ -906,6 +906,15 @@ def main():
                                     "gather.backend -- kernel times, parity and value are real, gather_ms is the fallback's")
         if other:
             result["other_configs"] = other
+            oe = next((v for k, v in other.items() if k.startswith("gate_nand_") and k.endswith("_engine_NTT")), None)
+            if oe and args.gate == "nand":
+                # both engines of the NTT key side by side (same key, same ciphertexts, identical output words: `parity`);
+                # `value` above is the engine named in `engine` -- by default the u64 prime-field kernels BASELINE names
+                result["engines_side_by_side"] = {
+                    args.engine: {"ms_per_step": ms_per_step, "gates_per_s": gates_per_s},
+                    oe["engine"]: {"ms_per_step": oe["ms_per_step_per_gpu"], "gates_per_s": world * oe["gates_per_s_per_gpu"]},
+                    "small_batch_ms_per_gate": {k: v["ms_per_gate_call"] for k, v in other.get("small_batch_latency", {}).items()
+                                                if isinstance(v, dict)}}
         if world == 1 and not args.no_cpu_baseline:
             nthreads = os.cpu_count() or 1
             # ~10-20 s of oracle time for the headline gate on the box's 128 host threads (about 17 ms per bit)
