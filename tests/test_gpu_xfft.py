@@ -194,13 +194,14 @@ def test_quad_kernel_equals_wave_kernel_and_oracle(env, H, thr, orc):
 
 def test_exact_engine_switch_points_plus_minus_one_bit(env, H):
     """the exact engine's dispatch: one quad team per work-group up to 1 x CUs rotations, two up to 2 x CUs, two launches
-    of the quad kernel (head of 2 x CUs + tail) up to 4 x CUs, then one wave per bit; tlwe_mask_size = 1.  NAND at each
+    of the quad kernel (head of 2 x CUs + tail) up to 4 x CUs, then one wave per bit -- whole rounds of 8 x CUs bits, a tail of
+    up to 2 x CUs bits back on the quad kernel; tlwe_mask_size = 1.  NAND at each
     switch point and one bit beyond == the native engine, every word; a MUX whose second job starts inside the head launch."""
     import torch
     vm = env['vm']; ctx = env['ctx']; sk = env['secret_key']; key = env['cloud_key']
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     rng = numpy.random.RandomState(99)
-    B = 4 * cus + 1
+    B = 10 * cus + 1
     ms = [rng.randint(0, 2, size=(B,)).astype(bool) for _ in range(3)]
     cs = [ctx.encrypt(sk, m) for m in ms]
     M = cus + 44                                        # MUX: 2 M rotations, job boundary at M < 2 x CUs (inside the head)
@@ -211,7 +212,7 @@ def test_exact_engine_switch_points_plus_minus_one_bit(env, H):
         key.set_engine('exact-fft')
         got_mux = H.ct_arrays(vm.gate_mux(cs[0][:M], cs[1][:M], cs[2][:M]))
         assert all((g == r).all() for g, r in zip(got_mux, ref_mux))
-        for size in (cus, cus + 1, 2 * cus, 2 * cus + 1, 3 * cus - 1, 4 * cus, 4 * cus + 1):
+        for size in (cus, cus + 1, 2 * cus, 2 * cus + 1, 3 * cus - 1, 4 * cus, 4 * cus + 1, 8 * cus + 1, 10 * cus, 10 * cus + 1):
             got = H.ct_arrays(vm.gate_nand(cs[0][:size], cs[1][:size]))
             assert all((g == r[:size]).all() for g, r in zip(got, ref)), size
     finally:
