@@ -1490,6 +1490,18 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, con
         // (pair kernel switched off:) small batch, FFT: 4 waves per bit, one bit per CU
         hipLaunchKernelGGL(k_bootstrap_fft_team, dim3((unsigned)P.nbits_total), dim3(64 * BRT_WAVES), TEAMF_LDS_BYTES, stream, P);
     } else if (transform == 1 && mask_size == 1) {
+        // whole rounds of 8 x CUs bits here; a tail of up to 2 x CUs bits, which the quad / pair kernels finish sooner (2.0 ... 2.9 ms)
+        // than another round of thinly filled work-groups (4 ms), goes to them in a second launch (2060 bits 10.1 -> 8.7 ms)
+        const long round_bits = (long)BR_WAVES_PER_BLOCK * num_cus;
+        const long tail = P.nbits_total % round_bits, head = P.nbits_total - tail;
+        if (head > 0 && tail > 0 && pair_max_bits > 0 && tail <= 2L * num_cus) {
+            const BrLaunch H = br_sub_launch(P, 0, head);
+            hipLaunchKernelGGL(k_bootstrap_fft, dim3(blocks_for(head, BR_WAVES_PER_BLOCK)), dim3(64 * BR_WAVES_PER_BLOCK),
+                               brf_lds_bytes(BR_WAVES_PER_BLOCK), stream, H);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            return launch_bootstrap(br_sub_launch(P, head, P.nbits_total), transform, mask_size, T, stream);
+        }
         const int w = br_pick_waves(P.nbits_total, BR_WAVES_PER_BLOCK, num_cus);
         hipLaunchKernelGGL(k_bootstrap_fft, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), brf_lds_bytes(w), stream, P);
     } else if (transform == 1 && mask_size == 2 && P.nbits_total <= team_max_bits / 2) {

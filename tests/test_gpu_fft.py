@@ -410,3 +410,33 @@ def test_fft_mux_job_boundary_inside_a_multi_pair_group(fft_env, thr, H, orc):
         d = numpy.abs((x.astype(numpy.int64) - y.astype(numpy.int64) + 2**31) % 2**32 - 2**31).max()
         assert d <= FFT_TOLERANCE_LSB
     assert (pair[2] == wave[2]).all()
+
+
+def test_fft_ragged_large_batch_head_and_tail(fft_env, thr, H, orc):
+    """8 x CUs + 5 bits: whole rounds on the one-wave kernel + a 5-bit tail on the quad kernel (a second launch); 9 x CUs + 1:
+    tail on the pair kernel; 10 x CUs + 1: one launch.  Against the one-wave kernel alone (both switches at 0) on every
+    word: within the path's tolerance; observed: identical."""
+    import torch
+    from nufhe_amd import _lib
+    vm = fft_env['vm']; lwe_key = fft_env['lwe_key']
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    rng = orc.DeterministicRNG(2024)
+    B = 10 * cus + 1
+    ms = [rng.uniform_bool((B,)).astype(bool) for _ in range(2)]
+    ds = [H.ciphertext_from_arrays(thr, orc.encrypt(rng, lwe_key, m), fft_env['params']) for m in ms]
+
+    def dev(x, y):
+        return numpy.abs((x.astype(numpy.int64) - y.astype(numpy.int64) + 2**31) % 2**32 - 2**31).max()
+    try:
+        _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, 0)
+        _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, 0)
+        wave = H.ct_arrays(vm.gate_nand(ds[0], ds[1]))
+    finally:
+        _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, -1)
+        _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, -1)
+    for size in (8 * cus + 5, 9 * cus + 1, 10 * cus + 1):
+        got = H.ct_arrays(vm.gate_nand(ds[0][:size], ds[1][:size]))
+        assert dev(got[0], wave[0][:size]) <= FFT_TOLERANCE_LSB and dev(got[1], wave[1][:size]) <= FFT_TOLERANCE_LSB, size
+        assert (got[2] == wave[2][:size]).all()
+        print("FFT ragged batch of %d bits vs the one-wave kernel: differing words: %d" % (
+            size, int((got[0] != wave[0][:size]).sum() + (got[1] != wave[1][:size]).sum())))

@@ -1,11 +1,13 @@
-"""NAND timing at batch sizes around whole rounds of the one-wave kernels (8 x CUs bits): `python tools/time_ragged.py [engine]`"""
+"""NAND timing at batch sizes around whole rounds of the one-wave kernels (8 x CUs bits):
+`python tools/time_ragged.py [native | exact-fft | FFT]` (FFT: an FFT key)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy, torch, nufhe_amd
 engine = sys.argv[1] if len(sys.argv) > 1 else 'exact-fft'
 ctx = nufhe_amd.Context(rng=nufhe_amd.DeterministicRNG(1))
-sk, ck = ctx.make_key_pair()
-ck.set_engine(engine)
+sk, ck = ctx.make_key_pair(transform_type='FFT' if engine == 'FFT' else 'NTT')
+if engine != 'FFT':
+    ck.set_engine(engine)
 vm = ctx.make_virtual_machine(ck)
 out = {}
 for B in (2048, 2060, 2304, 2560, 3000, 3072, 4096, 4100, 4352, 4608, 5000, 6144, 6200):
