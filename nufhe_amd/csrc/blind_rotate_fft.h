@@ -935,21 +935,25 @@ FF_FN void brfr_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSo
 struct BrFftQuadLds {
     cplx *xbuf;              // this wave's exchange buffer of the forward transform; then its transformed digit polynomial
     cplx *xbuf_inv;          // its second buffer: p = 1: the partial sum it hands over; p = 0: exchanges of the inverse transform
-    const cplx *xbuf_team;   // the team's four first buffers, FFT_XBUF_ELEMS apart
+    const cplx *xbuf_team;   // the team's 2 (K + 1) first buffers, FFT_XBUF_ELEMS apart
     const cplx *partner_inv; // second buffer of wave w ^ 1
-    i32 *acc;                // [2][1024], shared by the team
+    i32 *acc;                // [K + 1][1024], shared by the team
     uint16_t *bara;          // [BR_MAX_LWE], shared
     const cplx *tw1;
     const cplx *tw2;
 };
 
-template <int W, class TeamSync>
+// tlwe_mask_size = K: 2 (K + 1) waves per bit; wave 2 mo + p sums the K + 1 transformed digit polynomials q = p (K + 1) ... of
+// output mo (key rows [m][d][mo][reg][lane], q = 2 m + d)
+template <int W, int K, class TeamSync>
 FF_FN void brfq_step(u32 a, const cplx *row, const BrFftQuadLds &lds, const FftLane &L, TeamSync &&team_sync)
 {
+    constexpr int NH = K + 1;                     // digit polynomials per product-side wave
     constexpr int M = W >> 1, D = W & 1;          // forward side
     constexpr int MO = W >> 1, P = W & 1;         // product side
+    constexpr int Q0 = P * NH;
     const int lane = L.lane;
-    cplx key[2][8];                               // key[i][r] = BK_row[q >> 1][q & 1][MO], q = 2 P + i
+    cplx key[NH][8];                              // key[i][r] = BK_row[q >> 1][q & 1][MO], q = Q0 + i
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef u32 brf_u32x4 __attribute__((ext_vector_type(4)));
     u32 voff = (u32)lane * (u32)sizeof(cplx);
@@ -958,7 +962,7 @@ FF_FN void brfq_step(u32 a, const cplx *row, const BrFftQuadLds &lds, const FftL
     auto load_key = [&](int i) {
         // one descriptor per polynomial (8 KiB): every offset is an instruction immediate, no scalar offset operand
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(row + (long)((2 * P + i) * 2 + MO) * BKF_POLY_ELEMS), (short)0, BKF_POLY_ELEMS * (int)sizeof(cplx), 0x00020000);
+            (void *)(row + (long)((Q0 + i) * (K + 1) + MO) * BKF_POLY_ELEMS), (short)0, BKF_POLY_ELEMS * (int)sizeof(cplx), 0x00020000);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             union { brf_u32x4 w; cplx c; } u;
@@ -968,7 +972,7 @@ FF_FN void brfq_step(u32 a, const cplx *row, const BrFftQuadLds &lds, const FftL
     };
 #else
     auto load_key = [&](int i) {
-        const cplx *p = row + (long)((2 * P + i) * 2 + MO) * BKF_POLY_ELEMS + lane;
+        const cplx *p = row + (long)((Q0 + i) * (K + 1) + MO) * BKF_POLY_ELEMS + lane;
 #pragma unroll
         for (int r = 0; r < 8; r++) key[i][r] = p[r * 64];
     };
@@ -990,22 +994,21 @@ FF_FN void brfq_step(u32 a, const cplx *row, const BrFftQuadLds &lds, const FftL
     }
     cplx *const buf1[1] = {lds.xbuf};
     fft_forward_n<1>(x, buf1, lds.tw1, lds.tw2, L, [&](int stage) {
-        if (stage == 0) {
+        if (1 + stage < NH) {
             BR_ISSUE_FENCE();       // (fences on both sides: the requests stay where they are written)
-            load_key(1);
+            load_key(1 + stage);
             BR_ISSUE_FENCE();
         }
     });
     WAVE_SYNC();        // every lane is done with the exchange buffer
 #pragma unroll
     for (int r = 0; r < 8; r++) lds.xbuf[r * 64 + lane] = x[0][r];
-    team_sync();        // (1) the four transformed digit polynomials are visible; every wave has read ACC
+    team_sync();        // (1) the transformed digit polynomials are visible; every wave has read ACC
     cplx sum[1][8];
 #pragma unroll
     for (int r = 0; r < 8; r++) sum[0][r] = cplx{0.0, 0.0};
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        constexpr int Q0 = 2 * P;
+    for (int i = 0; i < NH; i++) {
         cplx xq[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) xq[r] = (Q0 + i == W) ? x[0][r] : lds.xbuf_team[(Q0 + i) * FFT_XBUF_ELEMS + r * 64 + lane];
@@ -1042,12 +1045,13 @@ FF_FN void brfq_step(u32 a, const cplx *row, const BrFftQuadLds &lds, const FftL
     team_sync();        // (3)
 }
 
-template <int W, class TeamSync>
+template <int W, int K, class TeamSync>
 FF_FN void brfq_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSource &s1, i32 c0, long bit,
                           const cplx *bk, int n, i32 mu, const BrFftQuadLds &lds, const FftLane &L, TeamSync &&team_sync)
 {
+    constexpr int THREADS = 64 * 2 * (K + 1);
     const int tid = 64 * W + L.lane;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += THREADS) {
         u32 v = 0;
         if (s0.p) v += (u32)s0.p * (u32)s0.a[bit * s0.a_stride + i];
         if (s1.p) v += (u32)s1.p * (u32)s1.a[bit * s1.a_stride + i];
@@ -1057,22 +1061,24 @@ FF_FN void brfq_bootstrap(i32 *out_a, i32 *out_b, const BrSource &s0, const BrSo
     if (s0.p) vb += (u32)s0.p * (u32)s0.b[bit * s0.b_stride];
     if (s1.p) vb += (u32)s1.p * (u32)s1.b[bit * s1.b_stride];
     const u32 barb = br_modswitch(vb);
-    for (int j = tid; j < 1024; j += 256) {
+    for (int j = tid; j < 1024; j += THREADS) {
         const u32 t = ((u32)j + barb) & 2047u;
-        lds.acc[j] = 0;
-        lds.acc[1024 + j] = (t < 1024u) ? mu : (i32)(0u - (u32)mu);
+#pragma unroll
+        for (int m = 0; m < K; m++) lds.acc[m * 1024 + j] = 0;
+        lds.acc[K * 1024 + j] = (t < 1024u) ? mu : (i32)(0u - (u32)mu);
     }
     WAVE_SYNC();
     team_sync();
     for (int i = 0; i < n; i++) {
         const u32 a = WAVE_UNIFORM((u32)lds.bara[i]);
-        if (a == 0) continue;        // (all four waves read the same word)
-        brfq_step<W>(a, bk + (long)i * BKF_ROW_ELEMS, lds, L, team_sync);
+        if (a == 0) continue;        // (all waves of the team read the same word)
+        brfq_step<W, K>(a, bk + (long)i * BK_ROW_POLYS(K) * BKF_POLY_ELEMS, lds, L, team_sync);
     }
     // sample extraction (tlwe_cpu.py:55-58)
-    for (int j = tid; j < 1024; j += 256) {
+    for (int j = tid; j < K * 1024; j += THREADS) {
+        const int m = j >> 10, jj = j & 1023;
         const u32 v = (u32)lds.acc[j];
-        out_a[(1024 - j) & 1023] = (i32)(j == 0 ? v : 0u - v);
+        out_a[m * 1024 + ((1024 - jj) & 1023)] = (i32)(jj == 0 ? v : 0u - v);
     }
-    if (tid == 0) *out_b = lds.acc[1024];
+    if (tid == 0) *out_b = lds.acc[K * 1024];
 }

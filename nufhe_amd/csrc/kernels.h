@@ -156,6 +156,7 @@ hipError_t launch_blind_rotate_accum_xfft(i32 *accum, const cplx *bkx, const i32
                                           int mask_size, hipStream_t stream);
 // FFT keys, up to 1 x CUs bits: four waves per bit (kernels_xfft.hip, brfq_*)
 hipError_t launch_bootstrap_fft_quad(const BrLaunch &P, hipStream_t stream);
+hipError_t launch_bootstrap_fft_hex_k2(const BrLaunch &P, hipStream_t stream);      // tlwe_mask_size = 2: six waves per bit
 // int32 TGSW polynomials [polys][1024] -> split key image complex128 [polys][2][8][64] (blind_rotate_xfft.h)
 hipError_t launch_bkx_from_coeffs(cplx *out, const i32 *in, long polys, const cplx *tw1, const cplx *tw2, hipStream_t stream);
 // NTT key in the wave layout -> its int32 coefficients [polys][1024]

@@ -1504,6 +1504,9 @@ hipError_t launch_bootstrap(const BrLaunch &P, int transform, int mask_size, con
         }
         const int w = br_pick_waves(P.nbits_total, BR_WAVES_PER_BLOCK, num_cus);
         hipLaunchKernelGGL(k_bootstrap_fft, dim3(blocks_for(P.nbits_total, w)), dim3(64 * w), brf_lds_bytes(w), stream, P);
+    } else if (transform == 1 && mask_size == 2 && pair_max_bits > 0 && T.team_max_bits_fft > 0 && P.nbits_total <= num_cus) {
+        // latency case, FFT, k = 2: six waves per bit, one bit per CU; both the ring and the team switch at 0 turn it off
+        return launch_bootstrap_fft_hex_k2(P, stream);
     } else if (transform == 1 && mask_size == 2 && P.nbits_total <= team_max_bits / 2) {
         // small batch, FFT, k = 2: 3 waves per bit
         hipLaunchKernelGGL(k_bootstrap_fft_team_k2, dim3((unsigned)P.nbits_total), dim3(64 * 3), TEAMF2_LDS_BYTES, stream, P);

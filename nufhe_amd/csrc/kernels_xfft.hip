@@ -292,10 +292,10 @@ __global__ __launch_bounds__(256, 1) void k_bootstrap_fft_quad(BrLaunch P)
     const BrSource &s0 = P.job[job].s0, &s1 = P.job[job].s1;
     const i32 c0 = P.job[job].c0;
     switch (w) {
-    case 0: brfq_bootstrap<0>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
-    case 1: brfq_bootstrap<1>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
-    case 2: brfq_bootstrap<2>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
-    default: brfq_bootstrap<3>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    case 0: brfq_bootstrap<0, 1>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    case 1: brfq_bootstrap<1, 1>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    case 2: brfq_bootstrap<2, 1>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    default: brfq_bootstrap<3, 1>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
     }
 }
 
@@ -303,6 +303,46 @@ hipError_t launch_bootstrap_fft_quad(const BrLaunch &P, hipStream_t stream)
 {
     if (P.nbits_total == 0) return hipSuccess;
     hipLaunchKernelGGL(k_bootstrap_fft_quad, dim3((unsigned)P.nbits_total), dim3(256), brxq_lds_bytes(1), stream, P);
+    return hipGetLastError();
+}
+
+// tlwe_mask_size = 2, FFT keys, batches up to 1 x CUs bits: six waves per bit (brfq_* with K = 2); LDS as brxq2_lds_bytes()
+__global__ __launch_bounds__(384, 1) void k_bootstrap_fft_hex_k2(BrLaunch P)
+{
+    load_ftables((const cplx *)P.tw_a, (const cplx *)P.tw_b);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const long gbit = (long)blockIdx.x;
+    const int job = gbit >= P.bits_per_job ? 1 : 0;
+    const long bit = gbit - (job ? P.bits_per_job : 0);
+    unsigned char *base = g_smem + FTABLE_LDS_BYTES + BR_PACE_BYTES + BRX_BASE_PAD;
+    BrFftQuadLds lds;
+    lds.acc = (i32 *)base;
+    lds.bara = (uint16_t *)(base + 3 * 1024 * 4);
+    lds.xbuf_team = (const cplx *)(base + 3 * 1024 * 4 + BR_MAX_LWE * 2);
+    lds.xbuf = (cplx *)lds.xbuf_team + w * FFT_XBUF_ELEMS;
+    lds.xbuf_inv = lds.xbuf + 6 * FFT_XBUF_ELEMS;
+    lds.partner_inv = lds.xbuf_team + (6 + (w ^ 1)) * FFT_XBUF_ELEMS;
+    lds.tw1 = (const cplx *)g_smem;
+    lds.tw2 = (const cplx *)g_smem + FFT_TW1_ELEMS;
+    auto team_sync = [] { __syncthreads(); };
+    const FftLane L = fft_lane_init(lane);
+    i32 *out_a = P.out_a + gbit * P.out_a_stride, *out_b = P.out_b + gbit * P.out_b_stride;
+    const BrSource &s0 = P.job[job].s0, &s1 = P.job[job].s1;
+    const i32 c0 = P.job[job].c0;
+    switch (w) {
+    case 0: brfq_bootstrap<0, 2>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    case 1: brfq_bootstrap<1, 2>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    case 2: brfq_bootstrap<2, 2>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    case 3: brfq_bootstrap<3, 2>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    case 4: brfq_bootstrap<4, 2>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    default: brfq_bootstrap<5, 2>(out_a, out_b, s0, s1, c0, bit, (const cplx *)P.bk, P.n, P.mu, lds, L, team_sync); break;
+    }
+}
+
+hipError_t launch_bootstrap_fft_hex_k2(const BrLaunch &P, hipStream_t stream)
+{
+    if (P.nbits_total == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_bootstrap_fft_hex_k2, dim3((unsigned)P.nbits_total), dim3(384), brxq2_lds_bytes(), stream, P);
     return hipGetLastError();
 }
 
@@ -349,6 +389,8 @@ hipError_t xfft_init()
     e = hipFuncSetAttribute((const void *)k_bootstrap_xfft_quad<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)brxq_lds_bytes(1));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap_fft_quad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)brxq_lds_bytes(1));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_bootstrap_fft_hex_k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)brxq2_lds_bytes());
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_bootstrap_xfft_hex_k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)brxq2_lds_bytes());
     if (e != hipSuccess) return e;

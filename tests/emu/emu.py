@@ -161,6 +161,8 @@ def bootstrap_bit_fft(bk_internal, n, src0, p0, src1, p1, c0, mu, team=False, ma
         fn = lib().emu_bootstrap_bit_fft_team_k2 if team else lib().emu_bootstrap_bit_fft_k2
         if ring:
             fn = lib().emu_bootstrap_bit_fft_ring_k2
+        if quad:
+            fn = lib().emu_bootstrap_bit_fft_hex_k2
     fn(_p(out_a, c_i32p), _p(out_b, c_i32p), _p(bk_internal.view(numpy.float64), c_f64p),
                                 ctypes.c_int(n), _p(a0, c_i32p), _p(b0, c_i32p), ctypes.c_int32(p0),
                                 _p(a1, c_i32p), _p(b1, c_i32p), ctypes.c_int32(p1),

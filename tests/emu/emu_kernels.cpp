@@ -651,10 +651,36 @@ void emu_bootstrap_bit_fft_quad(i32 *out_a, i32 *out_b, const double *bk_interna
         FftLane L = fft_lane_init(lane);
         auto sync = [] { emu_team_sync(); };
         switch (w) {
-        case 0: brfq_bootstrap<0>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bk_internal, n, mu, lds, L, sync); break;
-        case 1: brfq_bootstrap<1>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bk_internal, n, mu, lds, L, sync); break;
-        case 2: brfq_bootstrap<2>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bk_internal, n, mu, lds, L, sync); break;
-        default: brfq_bootstrap<3>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bk_internal, n, mu, lds, L, sync); break;
+        case 0: brfq_bootstrap<0, 1>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bk_internal, n, mu, lds, L, sync); break;
+        case 1: brfq_bootstrap<1, 1>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bk_internal, n, mu, lds, L, sync); break;
+        case 2: brfq_bootstrap<2, 1>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bk_internal, n, mu, lds, L, sync); break;
+        default: brfq_bootstrap<3, 1>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bk_internal, n, mu, lds, L, sync); break;
+        }
+    });
+}
+
+// six waves per bit, tlwe_mask_size = 2, FFT body (brfq_* with K = 2): 384 fibres; out_a has 2048 entries
+void emu_bootstrap_bit_fft_hex_k2(i32 *out_a, i32 *out_b, const double *bk_internal, int n,
+                                  const i32 *a0, const i32 *b0, i32 p0, const i32 *a1, const i32 *b1, i32 p1,
+                                  i32 c0, i32 mu)
+{
+    ftables();
+    std::vector<cplx> xbuf(12 * FFT_XBUF_ELEMS);
+    std::vector<i32> accbuf(3 * 1024);
+    std::vector<uint16_t> bara(BR_MAX_LWE);
+    BrSource s0{a0, b0, 0, 0, p0}, s1{a1, b1, 0, 0, p1};
+    emu_run_team(6, [&](int w, int lane) {
+        BrFftQuadLds lds{xbuf.data() + w * FFT_XBUF_ELEMS, xbuf.data() + (6 + w) * FFT_XBUF_ELEMS, xbuf.data(),
+                         xbuf.data() + (6 + (w ^ 1)) * FFT_XBUF_ELEMS, accbuf.data(), bara.data(), g_ftw1, g_ftw2};
+        FftLane L = fft_lane_init(lane);
+        auto sync = [] { emu_team_sync(); };
+        switch (w) {
+        case 0: brfq_bootstrap<0, 2>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bk_internal, n, mu, lds, L, sync); break;
+        case 1: brfq_bootstrap<1, 2>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bk_internal, n, mu, lds, L, sync); break;
+        case 2: brfq_bootstrap<2, 2>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bk_internal, n, mu, lds, L, sync); break;
+        case 3: brfq_bootstrap<3, 2>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bk_internal, n, mu, lds, L, sync); break;
+        case 4: brfq_bootstrap<4, 2>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bk_internal, n, mu, lds, L, sync); break;
+        default: brfq_bootstrap<5, 2>(out_a, out_b, s0, s1, c0, 0, (const cplx *)bk_internal, n, mu, lds, L, sync); break;
         }
     });
 }

@@ -283,3 +283,6 @@ def test_bootstrap_wave_body_fft_mask_size_2(orc):
     # the 3-wave ring variant (no partial-sum buffer, yet another summation order)
     ga, gb = emu.bootstrap_bit_fft(bkf, n, (a0, b0), 1, (a1, b1), 1, -MU, MU, mask_size=2, ring=True)
     assert (ga == ea[0]).all() and gb == eb[0]
+    # the 6-wave team (brfq_* with K = 2: one transform each way per wave, partial sums handed over)
+    ga, gb = emu.bootstrap_bit_fft(bkf, n, (a0, b0), 1, (a1, b1), 1, -MU, MU, mask_size=2, quad=True)
+    assert (ga == ea[0]).all() and gb == eb[0]

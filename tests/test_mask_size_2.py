@@ -546,6 +546,42 @@ def test_gpu_k2_fft_ring_kernel_two_teams(k2_fft_env, thr, H, orc):
 
 
 @pytest.mark.gpu
+def test_gpu_k2_fft_six_wave_kernel(k2_fft_env, thr, H, orc):
+    """k = 2, FFT, up to 1 x CUs bits: six waves per bit (k_bootstrap_fft_hex_k2, brfq_* with K = 2) -- NAND on 37 bits and a MUX
+    on 21 bits (two jobs in one launch) vs the team kernel (team switch at -1 with the ring switch at 0 does NOT reach it: the
+    comparison runs the one-wave kernel, both switches at 0) on every word, and vs the exact oracle (tolerance; observed: 0)."""
+    from nufhe_amd import _lib
+    env = k2_fft_env
+    vm = env['vm']; params = env['params']; ck = env['ck']; lwe_key = env['lwe_key']
+    rng = orc.DeterministicRNG(616)
+    B = 37
+    msg = [rng.uniform_bool((B,)).astype(bool) for _ in range(3)]
+    cs = [orc.encrypt(rng, lwe_key, m, env['oparams']) for m in msg]
+    ds = [H.ciphertext_from_arrays(thr, c, params) for c in cs]
+
+    def dev(x, y):
+        return numpy.abs((x.astype(numpy.int64) - y.astype(numpy.int64) + 2**31) % 2**32 - 2**31).max()
+
+    def gates():
+        return (H.ct_arrays(vm.gate_nand(ds[0], ds[1])), H.ct_arrays(vm.gate_mux(ds[0][:21], ds[1][:21], ds[2][:21])))
+    try:
+        six = gates()
+        _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, 0)
+        _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, 0)
+        wave = gates()
+    finally:
+        _lib.call("nufhe_ctx_set_team_max_bits", thr.handle, -1)
+        _lib.call("nufhe_ctx_set_pair_max_bits", thr.handle, -1)
+    exp = (orc.gate('gate_nand', ck, cs[0], cs[1]), orc.gate_mux(ck, *(tuple(x[:21] for x in c) for c in cs)))
+    for g in range(2):
+        assert dev(six[g][0], wave[g][0]) <= FFT_TOLERANCE_LSB and dev(six[g][1], wave[g][1]) <= FFT_TOLERANCE_LSB
+        assert (six[g][2] == wave[g][2]).all()
+        assert dev(six[g][0], exp[g][0]) <= FFT_TOLERANCE_LSB and dev(six[g][1], exp[g][1]) <= FFT_TOLERANCE_LSB
+        print("k=2 FFT six-wave kernel vs one-wave kernel, gate %d: differing words: %d; vs the exact path: %d" % (
+            g, int((six[g][0] != wave[g][0]).sum() + (six[g][1] != wave[g][1]).sum()), int((six[g][0] != exp[g][0]).sum())))
+
+
+@pytest.mark.gpu
 def test_gpu_k2_fft_context_end_to_end(thr):
     """Public API: Context.make_key_pair(transform_type='FFT', tlwe_mask_size=2) on the GPU, gates on 200
     bits, serialization round trip of the key."""
