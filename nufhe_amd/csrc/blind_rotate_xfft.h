@@ -536,7 +536,8 @@ FF_FN void brxk_bootstrap_body(u32 (&acc)[K + 1][16], const BrSource &s0, const 
 // Three team barriers per step: X visible | every X read (buffers free for the inverse; not needed when the inverse
 // transform has an exchange buffer of its own: SPLIT, one team per work-group) | ACC complete.  No registers
 // to speak of (8 complex sums), so the 32 key words of a step are requested in front of and inside the forward transform
-// and have arrived when the products begin.  46 KiB of LDS per team: up to three teams per work-group.
+// and have arrived when the products begin.  46 KiB of LDS per team (82 KiB with the second buffers); two teams per
+// work-group at most: a third would fit the LDS but not the registers (245 of the 168 it would leave per wave).
 // ---------------------------------------------------------------------------------------------------------------------
 struct BrXfftQuadLds {
     cplx *xbuf;              // this wave's exchange buffer (FFT_XBUF_ELEMS complex)

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64 * BRX2_WAVES, 1) void k_blind_rotate_accum_xfft_
 
 // ---- small batches, k = 1: four waves per bit (brxq_*), up to BRXQ_MAX_TEAMS teams per work-group ----
 // LDS: tables | arrival words of the team barriers (in the pacing block) | pad | per team: ACC 8 KiB, bara 1 KiB, 4 exchange buffers
-#define BRXQ_MAX_TEAMS 2
+#define BRXQ_MAX_TEAMS 2      /* (registers: 245 per wave; a third team would leave 168) */
 #define XQUAD_LDS_BYTES (2 * 1024 * 4 + BR_MAX_LWE * 2 + 4 * WAVE_FXBUF_BYTES)
 static_assert(XQUAD_LDS_BYTES % 256 == 0, "per-team LDS regions of k_bootstrap_xfft_quad are 256-byte aligned");
 // (a lone team has room for a second exchange buffer per wave: no barrier in front of the inverse transform)
