@@ -231,6 +231,11 @@ def test_gate_batch_and_stepwise_driver_on_the_exact_engine(env, H, orc):
     exp = orc.gate('gate_or', ck, h[0][:2], h[1][:2])
     ra, rb, rcv = H.ct_arrays(r0)
     assert (ra == exp[0]).all() and (rb == exp[1]).all() and (rcv == exp[2]).all()
+    # a batch whose 300 + 2 x 200 + 2100 rotations go through every launch of the engine's dispatch: rounds on the one-wave
+    # kernel + a quad tail (2800 = 2048 + 752 -> 752 alone: two quad launches) -- every word equal to the single gates
+    big = [ctx.encrypt(sk, rng.randint(0, 2, size=(n,)).astype(bool)) for n in (300, 300, 200, 200, 200, 2100, 2100)]
+    b0, b1, b2 = vm.gate_batch([('gate_xnor', big[0], big[1]), ('gate_mux', big[2], big[3], big[4]), ('gate_nand', big[5], big[6])])
+    assert b0 == vm.gate_xnor(big[0], big[1]) and b1 == vm.gate_mux(big[2], big[3], big[4]) and b2 == vm.gate_nand(big[5], big[6])
     # the reference's multi-kernel mode (bootstrap.py:96-142) drives nufhe_blind_rotate step by step: same engine, same words
     pp = nufhe_amd.PerformanceParameters(env['cloud_key'].params, single_kernel_bootstrap=False)
     vm2 = ctx.make_virtual_machine(env['cloud_key'], perf_params=pp)
