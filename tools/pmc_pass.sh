@@ -1,12 +1,13 @@
 #!/bin/bash
 # pmc_pass.sh TAG "COUNTER1 COUNTER2 ..." -- one rocprofv3 --pmc pass (kernel-trace only) of a short NTT bench
+# (BENCH_ARGS="--bits 256 --engine exact-fft" for another workload)
 TAG=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc $@ --output-format csv -d "$OUT" -- \
-    python "$ROOT/bench.py" --steps 2 --warmup 1 --no-extra --no-cpu-baseline > /dev/null 2> "$OUT/log.txt"
+    python "$ROOT/bench.py" --steps 2 --warmup 1 --no-extra --no-cpu-baseline $BENCH_ARGS > /dev/null 2> "$OUT/log.txt"
 python - "$OUT" <<'PY'
 import csv, glob, os, sys, collections
 out = sys.argv[1]
