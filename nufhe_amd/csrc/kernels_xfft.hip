@@ -213,10 +213,12 @@ __global__ __launch_bounds__(ONE_TEAM ? 256 : 256 * BRXQ_MAX_TEAMS, 1) void k_bo
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         arrive[w] = seq;
         for (;;) {
-            const u32 a0 = arrive[0], a1 = arrive[1], a2 = arrive[2], a3 = arrive[3];
-            const i32 d0 = (i32)(a0 - seq), d1 = (i32)(a1 - seq), d2 = (i32)(a2 - seq), d3 = (i32)(a3 - seq);
+            // the team's four counters in one 16-byte read, no sleep between polls (4 separate reads + s_sleep 1: +1.5 %)
+            typedef u32 brx_u32x4 __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) volatile brx_u32x4 lds_vu32x4;
+            const brx_u32x4 v = *(lds_vu32x4 *)arrive;
+            const i32 d0 = (i32)(v.x - seq), d1 = (i32)(v.y - seq), d2 = (i32)(v.z - seq), d3 = (i32)(v.w - seq);
             if (__builtin_amdgcn_readfirstlane((d0 | d1 | d2 | d3)) >= 0) break;
-            __builtin_amdgcn_s_sleep(1);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
