@@ -97,8 +97,9 @@ def test_captured_uint_min(side_stream_env):
 
 def test_captured_chain_on_the_exact_engine(side_stream_env):
     """The same kind of circuit with the NTT key on the exact-FFT engine (the split key image and the parking buffer exist
-    after the eager run): the capture holds the quad kernel (3 bits) / the one-wave kernel with its parked accumulators
-    (600 bits) and replays to the eager words, also for new inputs written in place."""
+    after the eager run): the capture holds the quad kernel (3 bits) / two launches of the quad kernel for the NAND and the
+    one-wave kernel with its parked accumulators for the MUX's 1200 rotations (600 bits) and replays to the eager words, also for
+    new inputs written in place."""
     import torch
     import nufhe_amd as nufhe
     e = side_stream_env
